@@ -1,0 +1,1189 @@
+/*
+ * gold_oracle.c -- CPU ORACLE (test infrastructure, see gold_oracle.h).
+ *
+ * A plain-C restatement of the reference's algorithm for the batched-scalarmul
+ * hot path.  Every function cites the reference file:line (relative to the
+ * reference tree) whose behaviour it restates.  The representation is the
+ * arch_ref64 one: 8 limbs of 56 bits, 128-bit accumulators, every add/sub
+ * weakly reduced (src/arch_ref64/f_impl.h:6 GF_HEADROOM 9999), so that even raw
+ * limbs agree with an arch_ref64 build, not just canonical encodings.
+ */
+#include "gold_oracle.h"
+
+#include <pthread.h>
+#include <string.h>
+
+typedef unsigned __int128 u128;
+typedef __int128 s128;
+typedef uint64_t mask_t;
+
+#define LMASK ((1ull << 56) - 1)
+
+static inline mask_t is_zero64(uint64_t x) { /* all-ones iff x == 0 */
+    return (mask_t)(((u128)x - 1) >> 64);
+}
+
+/* =====================================================================
+ * Field GF(p), p = 2^448 - 2^224 - 1
+ * ===================================================================== */
+
+static const orc_gf FE_ZERO = {{0}};
+static const orc_gf FE_ONE = {{1}};
+/* src/f_generic.c:14-16 */
+static const orc_gf FE_P = {{LMASK, LMASK, LMASK, LMASK, LMASK - 1, LMASK, LMASK, LMASK}};
+
+/* src/arch_ref64/f_impl.h:30-38 : fold limb 7's overflow into limbs 0 and 4
+ * (2^448 = 2^224 + 1 mod p) and ripple every other limb's overflow one up. */
+static void fe_weak(orc_gf *a) {
+    uint64_t top = a->limb[7] >> 56;
+    a->limb[4] += top;
+    for (int i = 7; i > 0; i--)
+        a->limb[i] = (a->limb[i] & LMASK) + (a->limb[i - 1] >> 56);
+    a->limb[0] = (a->limb[0] & LMASK) + top;
+}
+
+/* src/arch_ref64/f_impl.h:10-15 (gf_add_RAW, includes one weak reduce) */
+static void fe_add_nr(orc_gf *c, const orc_gf *a, const orc_gf *b) {
+    for (int i = 0; i < 8; i++) c->limb[i] = a->limb[i] + b->limb[i];
+    fe_weak(c);
+}
+
+/* src/arch_ref64/f_impl.h:17-23 (gf_sub_RAW: bias by 2p, one weak reduce) */
+static void fe_sub_nr(orc_gf *c, const orc_gf *a, const orc_gf *b) {
+    const uint64_t two_p = 2 * LMASK;
+    for (int i = 0; i < 8; i++)
+        c->limb[i] = a->limb[i] - b->limb[i] + (i == 4 ? two_p - 2 : two_p);
+    fe_weak(c);
+}
+
+/* src/f_generic.c:107-117 : RAW op followed by a (second) weak reduce */
+void orc_gf_add(orc_gf *c, const orc_gf *a, const orc_gf *b) { fe_add_nr(c, a, b); fe_weak(c); }
+void orc_gf_sub(orc_gf *c, const orc_gf *a, const orc_gf *b) { fe_sub_nr(c, a, b); fe_weak(c); }
+#define fe_add orc_gf_add
+#define fe_sub orc_gf_sub
+
+/* src/arch_ref64/f_impl.c:7-166.  With phi = 2^224 and a = a0 + a1*phi,
+ * b = b0 + b1*phi, phi^2 = phi + 1 gives
+ *     a*b = (a0 b0 + a1 b1) + ((a0+a1)(b0+b1) - a0 b0) * phi.
+ * Each half has 4 limbs; column i of the low/high output halves is gathered
+ * in three accumulators, where products whose column index wraps past 4 limbs
+ * are multiplied by phi once more (hence the b-side operands b1, b0+b1,
+ * b0+2*b1 for the wrapped terms). */
+void orc_gf_mul(orc_gf *cs, const orc_gf *as, const orc_gf *bs) {
+    const uint64_t *a = as->limb, *b = bs->limb;
+    uint64_t sa[4], sb[4], sbb[4], c[8];
+    u128 lo = 0, hi = 0;
+    for (int i = 0; i < 4; i++) {
+        sa[i] = a[i] + a[i + 4];
+        sb[i] = b[i] + b[i + 4];
+        sbb[i] = sb[i] + b[i + 4];
+    }
+#pragma GCC unroll 4
+    for (int i = 0; i < 4; i++) {
+        u128 cross = 0;
+#pragma GCC unroll 4
+        for (int j = 0; j < 4; j++) {
+            if (j <= i) {
+                cross += (u128)a[j] * b[i - j];
+                hi += (u128)sa[j] * sb[i - j];
+                lo += (u128)a[j + 4] * b[i - j + 4];
+            } else {
+                cross += (u128)a[j] * b[i - j + 8];
+                hi += (u128)sa[j] * sbb[i - j + 4];
+                lo += (u128)a[j + 4] * sb[i - j + 4];
+            }
+        }
+        hi -= cross;
+        lo += cross;
+        c[i] = (uint64_t)lo & LMASK;
+        c[i + 4] = (uint64_t)hi & LMASK;
+        lo >>= 56;
+        hi >>= 56;
+    }
+    /* src/arch_ref64/f_impl.c:155-165 : the two carry tails */
+    lo += hi;
+    lo += c[4];
+    hi += c[0];
+    c[4] = (uint64_t)lo & LMASK;
+    c[0] = (uint64_t)hi & LMASK;
+    lo >>= 56;
+    hi >>= 56;
+    c[5] += (uint64_t)lo;
+    c[1] += (uint64_t)hi;
+    for (int i = 0; i < 8; i++) cs->limb[i] = c[i];
+}
+
+/* src/arch_ref64/f_impl.c:192-300 : same column sums as gf_mul(a,a) (the
+ * reference only folds the symmetric products), hence identical limbs. */
+void orc_gf_sqr(orc_gf *cs, const orc_gf *as) { orc_gf_mul(cs, as, as); }
+
+/* src/arch_ref64/f_impl.c:168-190 */
+void orc_gf_mulw(orc_gf *cs, const orc_gf *as, uint32_t w) {
+    const uint64_t *a = as->limb;
+    uint64_t c[8];
+    u128 lo = 0, hi = 0;
+    for (int i = 0; i < 4; i++) {
+        lo += (u128)w * a[i];
+        hi += (u128)w * a[i + 4];
+        c[i] = (uint64_t)lo & LMASK;  lo >>= 56;
+        c[i + 4] = (uint64_t)hi & LMASK;  hi >>= 56;
+    }
+    lo += hi + c[4];
+    c[4] = (uint64_t)lo & LMASK;
+    c[5] += (uint64_t)(lo >> 56);
+    hi += c[0];
+    c[0] = (uint64_t)hi & LMASK;
+    c[1] += (uint64_t)(hi >> 56);
+    for (int i = 0; i < 8; i++) cs->limb[i] = c[i];
+}
+
+/* src/include/field.h:57-65 : signed small multiplier */
+static void fe_mulw_signed(orc_gf *c, const orc_gf *a, int32_t w) {
+    if (w > 0) {
+        orc_gf_mulw(c, a, (uint32_t)w);
+    } else {
+        orc_gf_mulw(c, a, (uint32_t)(-w));
+        fe_sub(c, &FE_ZERO, c);
+    }
+}
+
+/* src/f_generic.c:71-105 */
+void orc_gf_strong_reduce(orc_gf *a) {
+    s128 sc = 0;
+    u128 carry = 0;
+    fe_weak(a);
+    for (int i = 0; i < 8; i++) {
+        sc = sc + a->limb[i] - FE_P.limb[i];
+        a->limb[i] = (uint64_t)sc & LMASK;
+        sc >>= 56;
+    }
+    uint64_t addback = (uint64_t)sc; /* 0 if value was >= p, all-ones otherwise */
+    for (int i = 0; i < 8; i++) {
+        carry = carry + a->limb[i] + (addback & FE_P.limb[i]);
+        a->limb[i] = (uint64_t)carry & LMASK;
+        carry >>= 56;
+    }
+}
+
+/* src/f_generic.c:19-38 : 56 bytes little-endian of the canonical value */
+void orc_gf_serialize(uint8_t out[56], const orc_gf *x) {
+    orc_gf r = *x;
+    orc_gf_strong_reduce(&r);
+    for (int i = 0; i < 8; i++)
+        for (int j = 0; j < 7; j++) out[7 * i + j] = (uint8_t)(r.limb[i] >> (8 * j));
+}
+
+/* src/f_generic.c:49-68 : returns all-ones iff the value read is < p.  The top
+ * byte is first masked with ~hi_nmask. */
+mask_t orc_gf_deserialize(orc_gf *x, const uint8_t in[56], uint8_t hi_nmask) {
+    s128 sc = 0;
+    for (int i = 0; i < 8; i++) {
+        uint64_t l = 0;
+        for (int j = 0; j < 7; j++) {
+            uint8_t byte = in[7 * i + j];
+            if (7 * i + j == 55) byte &= (uint8_t)~hi_nmask;
+            l |= (uint64_t)byte << (8 * j);
+        }
+        x->limb[i] = l;
+        sc = (sc + l - FE_P.limb[i]) >> 64;
+    }
+    return ~is_zero64((uint64_t)sc);
+}
+
+/* src/f_generic.c:119-131 */
+mask_t orc_gf_eq(const orc_gf *a, const orc_gf *b) {
+    orc_gf c;
+    uint64_t acc = 0;
+    fe_sub(&c, a, b);
+    orc_gf_strong_reduce(&c);
+    for (int i = 0; i < 8; i++) acc |= c.limb[i];
+    return is_zero64(acc);
+}
+
+/* src/f_generic.c:41-46 */
+mask_t orc_gf_lobit(const orc_gf *a) {
+    orc_gf y = *a;
+    orc_gf_strong_reduce(&y);
+    return (mask_t)0 - (y.limb[0] & 1);
+}
+
+#define fe_mul orc_gf_mul
+#define fe_sqr orc_gf_sqr
+
+static void fe_sqrn(orc_gf *y, const orc_gf *x, int n) { /* src/include/field.h:19-38 */
+    orc_gf t = *x;
+    while (n-- > 0) { orc_gf u; fe_sqr(&u, &t); t = u; }
+    *y = t;
+}
+
+static void fe_mul_ip(orc_gf *y, const orc_gf *a, const orc_gf *b) { /* alias-safe */
+    orc_gf t; fe_mul(&t, a, b); *y = t;
+}
+
+/* src/f_arithmetic.c:14-46 : x^((p-3)/4) through x^(2^k-1),
+ * k = 1,2,3,6,9,18,19,37,74,111,222,223; mask = (out^2 * x == 1). */
+mask_t orc_gf_isr(orc_gf *out, const orc_gf *x) {
+    orc_gf e1 = *x, e2, e3, e6, e9, e18, e19, e37, e74, e111, e222, e223, t, chk;
+    fe_sqr(&t, &e1);          fe_mul(&e2, &e1, &t);      /* 2^2-1 */
+    fe_sqr(&t, &e2);          fe_mul(&e3, &e1, &t);      /* 2^3-1 */
+    fe_sqrn(&t, &e3, 3);      fe_mul(&e6, &e3, &t);      /* 2^6-1 */
+    fe_sqrn(&t, &e6, 3);      fe_mul(&e9, &e3, &t);      /* 2^9-1 */
+    fe_sqrn(&t, &e9, 9);      fe_mul(&e18, &e9, &t);     /* 2^18-1 */
+    fe_sqr(&t, &e18);         fe_mul(&e19, &e1, &t);     /* 2^19-1 */
+    fe_sqrn(&t, &e19, 18);    fe_mul(&e37, &e18, &t);    /* 2^37-1 */
+    fe_sqrn(&t, &e37, 37);    fe_mul(&e74, &e37, &t);    /* 2^74-1 */
+    fe_sqrn(&t, &e74, 37);    fe_mul(&e111, &e37, &t);   /* 2^111-1 */
+    fe_sqrn(&t, &e111, 111);  fe_mul(&e222, &e111, &t);  /* 2^222-1 */
+    fe_sqr(&t, &e222);        fe_mul(&e223, &e1, &t);    /* 2^223-1 */
+    fe_sqrn(&t, &e223, 223);  fe_mul(out, &e222, &t);    /* 2^446-2^222-1 */
+    fe_sqr(&t, out);
+    fe_mul(&chk, &t, x);
+    return orc_gf_eq(&chk, &FE_ONE);
+}
+
+/* src/goldilocks.c:69-80 */
+static void fe_invert(orc_gf *y, const orc_gf *x) {
+    orc_gf t1, t2;
+    fe_sqr(&t1, x);
+    (void)orc_gf_isr(&t2, &t1);
+    fe_sqr(&t1, &t2);
+    fe_mul(&t2, &t1, x);
+    *y = t2;
+}
+
+static void fe_cond_neg(orc_gf *x, mask_t neg) { /* src/include/field.h:72-77 */
+    orc_gf y;
+    fe_sub(&y, &FE_ZERO, x);
+    for (int i = 0; i < 8; i++) x->limb[i] = (x->limb[i] & ~neg) | (y.limb[i] & neg);
+}
+
+static void fe_cond_swap(orc_gf *x, orc_gf *y, mask_t swap) {
+    for (int i = 0; i < 8; i++) {
+        uint64_t d = (x->limb[i] ^ y->limb[i]) & swap;
+        x->limb[i] ^= d;  y->limb[i] ^= d;
+    }
+}
+
+/* =====================================================================
+ * Scalars mod q  (src/scalar.c)
+ * ===================================================================== */
+
+static const uint64_t SC_MONT = 0x3bd440fae918bc5ull;                       /* scalar.c:17 */
+static const orc_scalar SC_Q = {{0x2378c292ab5844f3ull, 0x216cc2728dc58f55ull, 0xc44edb49aed63690ull,
+                                 0xffffffff7cca23e9ull, 0xffffffffffffffffull, 0xffffffffffffffffull,
+                                 0x3fffffffffffffffull}};                   /* scalar.c:18-20 */
+static const orc_scalar SC_R2 = {{0xe3539257049b9b60ull, 0x7af32c4bc1b195d9ull, 0x0d66de2388ea1859ull,
+                                  0xae17cf725ee4d838ull, 0x1a9cc14ba3c47c44ull, 0x2052bcb7e4d070afull,
+                                  0x3402a939f823b729ull}};                  /* scalar.c:20-22 */
+static const orc_scalar SC_ONE = {{1}}, SC_ZERO = {{0}};
+/* goldilocks.c:33-37 : (2^450 - 1) mod q, the signed-window recoding offset */
+static const orc_scalar SC_ADJ = {{0xc873d6d54a7bb0cfull, 0xe933d8d723a70aadull, 0xbb124b65129c96fdull,
+                                   0x00000008335dc163ull, 0, 0, 0}};
+
+/* scalar.c:30-53 : out = {extra,acc} - sub, then + q if that went negative */
+static void sc_subx(orc_scalar *out, const uint64_t acc[7], const orc_scalar *sub, uint64_t extra) {
+    s128 chain = 0;
+    for (int i = 0; i < 7; i++) {
+        chain = (chain + acc[i]) - sub->limb[i];
+        out->limb[i] = (uint64_t)chain;
+        chain >>= 64;
+    }
+    uint64_t borrow = (uint64_t)chain + extra;
+    u128 c2 = 0;
+    for (int i = 0; i < 7; i++) {
+        c2 = (c2 + out->limb[i]) + (SC_Q.limb[i] & borrow);
+        out->limb[i] = (uint64_t)c2;
+        c2 >>= 64;
+    }
+}
+
+/* scalar.c:55-91 : Montgomery product a*b/2^448 mod q */
+static void sc_montmul(orc_scalar *out, const orc_scalar *a, const orc_scalar *b) {
+    uint64_t acc[8] = {0}, hi_carry = 0;
+    for (int i = 0; i < 7; i++) {
+        uint64_t m = a->limb[i];
+        u128 chain = 0;
+        int j;
+        for (j = 0; j < 7; j++) {
+            chain += (u128)m * b->limb[j] + acc[j];
+            acc[j] = (uint64_t)chain;
+            chain >>= 64;
+        }
+        acc[7] = (uint64_t)chain;
+        m = acc[0] * SC_MONT;
+        chain = 0;
+        for (j = 0; j < 7; j++) {
+            chain += (u128)m * SC_Q.limb[j] + acc[j];
+            if (j) acc[j - 1] = (uint64_t)chain;
+            chain >>= 64;
+        }
+        chain += acc[7];
+        chain += hi_carry;
+        acc[6] = (uint64_t)chain;
+        hi_carry = (uint64_t)(chain >> 64);
+    }
+    sc_subx(out, acc, &SC_Q, hi_carry);
+}
+
+void orc_scalar_mul(orc_scalar *o, const orc_scalar *a, const orc_scalar *b) { /* scalar.c:93-100 */
+    orc_scalar t;
+    sc_montmul(&t, a, b);
+    sc_montmul(o, &t, &SC_R2);
+}
+void orc_scalar_sub(orc_scalar *o, const orc_scalar *a, const orc_scalar *b) { /* scalar.c:168-174 */
+    sc_subx(o, a->limb, b, 0);
+}
+void orc_scalar_add(orc_scalar *o, const orc_scalar *a, const orc_scalar *b) { /* scalar.c:176-189 */
+    u128 chain = 0;
+    uint64_t t[7];
+    for (int i = 0; i < 7; i++) {
+        chain = (chain + a->limb[i]) + b->limb[i];
+        t[i] = (uint64_t)chain;
+        chain >>= 64;
+    }
+    sc_subx(o, t, &SC_Q, (uint64_t)chain);
+}
+void orc_scalar_halve(orc_scalar *o, const orc_scalar *a) { /* scalar.c:316-332 */
+    uint64_t mask = 0 - (a->limb[0] & 1), t[7];
+    u128 chain = 0;
+    for (int i = 0; i < 7; i++) {
+        chain = (chain + a->limb[i]) + (SC_Q.limb[i] & mask);
+        t[i] = (uint64_t)chain;
+        chain >>= 64;
+    }
+    for (int i = 0; i < 6; i++) o->limb[i] = t[i] >> 1 | t[i + 1] << 63;
+    o->limb[6] = t[6] >> 1 | (uint64_t)chain << 63;
+}
+static void sc_decode_short(orc_scalar *s, const uint8_t *in, size_t n) { /* scalar.c:219-232 */
+    size_t k = 0;
+    for (int i = 0; i < 7; i++) {
+        uint64_t w = 0;
+        for (int j = 0; j < 8 && k < n; j++, k++) w |= (uint64_t)in[k] << (8 * j);
+        s->limb[i] = w;
+    }
+}
+int orc_scalar_decode(orc_scalar *s, const uint8_t in[56]) { /* scalar.c:234-249 */
+    s128 acc = 0;
+    sc_decode_short(s, in, 56);
+    for (int i = 0; i < 7; i++) acc = (acc + s->limb[i] - SC_Q.limb[i]) >> 64;
+    orc_scalar t = *s;
+    orc_scalar_mul(s, &t, &SC_ONE);
+    return (uint64_t)acc ? ORC_SUCCESS : ORC_FAILURE;
+}
+void orc_scalar_decode_long(orc_scalar *s, const uint8_t *in, size_t len) { /* scalar.c:257-293 */
+    orc_scalar t1, t2;
+    if (len == 0) { *s = SC_ZERO; return; }
+    size_t i = len - (len % 56);
+    if (i == len) i -= 56;
+    sc_decode_short(&t1, in + i, len - i);
+    if (len == sizeof(orc_scalar)) { /* == 56: a single block, reduce by mult with 1 */
+        orc_scalar_mul(s, &t1, &SC_ONE);
+        return;
+    }
+    while (i) {
+        i -= 56;
+        orc_scalar u;
+        sc_montmul(&u, &t1, &SC_R2);
+        (void)orc_scalar_decode(&t2, in + i);
+        orc_scalar_add(&t1, &u, &t2);
+    }
+    *s = t1;
+}
+void orc_scalar_encode(uint8_t out[56], const orc_scalar *s) { /* scalar.c:295-305 */
+    for (int i = 0; i < 7; i++)
+        for (int j = 0; j < 8; j++) out[8 * i + j] = (uint8_t)(s->limb[i] >> (8 * j));
+}
+
+/* =====================================================================
+ * Group: extended twisted Edwards, a = -1, d' = -39082  (src/goldilocks.c)
+ * ===================================================================== */
+
+#define EDWARDS_D (-39081)
+#define TWISTED_D (EDWARDS_D - 1)
+#define EFF_D (-(TWISTED_D))
+
+/* goldilocks.c:41-43 : 1/sqrt(39082/39081 - 1), as 56-bit limbs */
+static const orc_gf FE_FACTOR = {{0x42ef0f45572736ull, 0x7bf6aa20ce5296ull, 0xf4fd6eded26033ull,
+                                  0x968c14ba839a66ull, 0xb8d54b64a2d780ull, 0x6aa0a1f1a7b8a5ull,
+                                  0x683bf68d722fa2ull, 0x22d962fbeb24f7ull}};
+
+static const orc_point PT_IDENTITY = {{{0}}, {{1}}, {{1}}, {{0}}};
+const orc_point *orc_point_identity(void) { return &PT_IDENTITY; }
+
+/* goldilocks.c:205-230 (add) and :178-203 (sub) */
+static void pt_addsub(orc_point *p, const orc_point *q, const orc_point *r, int subtract) {
+    orc_gf a, b, c, d, px, py;
+    fe_sub_nr(&b, &q->y, &q->x);
+    if (subtract) { fe_sub_nr(&d, &r->y, &r->x); fe_add_nr(&c, &r->y, &r->x); }
+    else          { fe_sub_nr(&c, &r->y, &r->x); fe_add_nr(&d, &r->y, &r->x); }
+    fe_mul(&a, &c, &b);
+    fe_add_nr(&b, &q->y, &q->x);
+    fe_mul(&py, &d, &b);
+    fe_mul(&b, &r->t, &q->t);
+    orc_gf_mulw(&px, &b, 2 * EFF_D);
+    fe_add_nr(&b, &a, &py);
+    fe_sub_nr(&c, &py, &a);
+    fe_mul(&a, &q->z, &r->z);
+    fe_add_nr(&a, &a, &a);
+    if (subtract) { fe_sub_nr(&py, &a, &px); fe_add_nr(&a, &a, &px); }
+    else          { fe_add_nr(&py, &a, &px); fe_sub_nr(&a, &a, &px); }
+    fe_mul(&p->z, &a, &py);
+    fe_mul(&p->x, &py, &c);
+    fe_mul(&p->y, &a, &b);
+    fe_mul(&p->t, &b, &c);
+}
+void orc_point_add(orc_point *p, const orc_point *q, const orc_point *r) { pt_addsub(p, q, r, 0); }
+void orc_point_sub(orc_point *p, const orc_point *q, const orc_point *r) { pt_addsub(p, q, r, 1); }
+
+/* goldilocks.c:232-254 */
+static void pt_double(orc_point *p, const orc_point *q, int before_double) {
+    orc_gf a, b, c, d, pt, px, pz;
+    fe_sqr(&c, &q->x);
+    fe_sqr(&a, &q->y);
+    fe_add_nr(&d, &c, &a);
+    fe_add_nr(&pt, &q->y, &q->x);
+    fe_sqr(&b, &pt);
+    fe_sub_nr(&b, &b, &d);
+    fe_sub_nr(&pt, &a, &c);
+    fe_sqr(&px, &q->z);
+    fe_add_nr(&pz, &px, &px);
+    fe_sub_nr(&a, &pz, &pt);
+    fe_mul(&p->x, &a, &b);
+    fe_mul(&p->z, &pt, &a);
+    fe_mul(&p->y, &pt, &d);
+    if (!before_double) fe_mul(&p->t, &b, &d);
+    /* when before_double the reference leaves p->t = pt (A - C); keep that so
+     * raw limbs match too */
+    else p->t = pt;
+}
+void orc_point_double(orc_point *p, const orc_point *q) { pt_double(p, q, 0); }
+
+void orc_point_negate(orc_point *p, const orc_point *q) { /* goldilocks.c:260-268 */
+    fe_sub(&p->x, &FE_ZERO, &q->x);
+    p->y = q->y;
+    p->z = q->z;
+    fe_sub(&p->t, &FE_ZERO, &q->t);
+}
+
+static void niels_cond_neg(orc_niels *n, mask_t neg) { /* goldilocks.c:271-278 */
+    fe_cond_swap(&n->a, &n->b, neg);
+    fe_cond_neg(&n->c, neg);
+}
+static void pt_to_pniels(orc_pniels *b, const orc_point *a) { /* goldilocks.c:280-288 */
+    fe_sub(&b->n.a, &a->y, &a->x);
+    fe_add(&b->n.b, &a->x, &a->y);
+    fe_mulw_signed(&b->n.c, &a->t, 2 * TWISTED_D);
+    fe_add(&b->z, &a->z, &a->z);
+}
+static void pniels_to_pt(orc_point *e, const orc_pniels *d) { /* goldilocks.c:290-301 */
+    orc_gf eu;
+    fe_add(&eu, &d->n.b, &d->n.a);
+    fe_sub(&e->y, &d->n.b, &d->n.a);
+    fe_mul(&e->t, &e->y, &eu);
+    fe_mul(&e->x, &d->z, &e->y);
+    fe_mul_ip(&e->y, &d->z, &eu);
+    fe_sqr(&e->z, &d->z);
+}
+static void niels_to_pt(orc_point *e, const orc_niels *n) { /* goldilocks.c:303-312 */
+    fe_add(&e->y, &n->b, &n->a);
+    fe_sub(&e->x, &n->b, &n->a);
+    fe_mul(&e->t, &e->y, &e->x);
+    e->z = FE_ONE;
+}
+/* goldilocks.c:314-334 (add) and :336-356 (sub) */
+static void pt_addsub_niels(orc_point *d, const orc_niels *e, int before_double, int subtract) {
+    orc_gf a, b, c;
+    const orc_gf *ea = subtract ? &e->b : &e->a, *eb = subtract ? &e->a : &e->b;
+    fe_sub_nr(&b, &d->y, &d->x);
+    fe_mul(&a, ea, &b);
+    fe_add_nr(&b, &d->x, &d->y);
+    fe_mul_ip(&d->y, eb, &b);
+    fe_mul_ip(&d->x, &e->c, &d->t);
+    fe_add_nr(&c, &a, &d->y);
+    fe_sub_nr(&b, &d->y, &a);
+    if (subtract) { fe_add_nr(&d->y, &d->z, &d->x); fe_sub_nr(&a, &d->z, &d->x); }
+    else          { fe_sub_nr(&d->y, &d->z, &d->x); fe_add_nr(&a, &d->x, &d->z); }
+    fe_mul_ip(&d->z, &a, &d->y);
+    fe_mul_ip(&d->x, &d->y, &b);
+    fe_mul_ip(&d->y, &a, &c);
+    if (!before_double) fe_mul_ip(&d->t, &b, &c);
+}
+static void pt_addsub_pniels(orc_point *p, const orc_pniels *pn, int before_double, int subtract) {
+    fe_mul_ip(&p->z, &p->z, &pn->z); /* goldilocks.c:358-380 */
+    pt_addsub_niels(p, &pn->n, before_double, subtract);
+}
+
+int orc_point_eq(const orc_point *p, const orc_point *q) { /* goldilocks.c:644-653 */
+    orc_gf a, b;
+    fe_mul(&a, &p->y, &q->x);
+    fe_mul(&b, &q->y, &p->x);
+    return orc_gf_eq(&a, &b) ? ORC_SUCCESS : ORC_FAILURE;
+}
+int orc_point_valid(const orc_point *p) { /* goldilocks.c:655-673 */
+    orc_gf a, b, c;
+    mask_t ok;
+    fe_mul(&a, &p->x, &p->y);
+    fe_mul(&b, &p->z, &p->t);
+    ok = orc_gf_eq(&a, &b);
+    fe_sqr(&a, &p->x);
+    fe_sqr(&b, &p->y);
+    fe_sub(&a, &b, &a);
+    fe_sqr(&b, &p->t);
+    fe_mulw_signed(&c, &b, TWISTED_D);
+    fe_sqr(&b, &p->z);
+    fe_add(&b, &b, &c);
+    ok &= orc_gf_eq(&a, &b);
+    ok &= ~orc_gf_eq(&p->z, &FE_ZERO);
+    return ok ? ORC_SUCCESS : ORC_FAILURE;
+}
+
+/* goldilocks.c:98-134 (deisogenize with all toggles 0) + :136-140 */
+void orc_point_encode(uint8_t out[56], const orc_point *p) {
+    orc_gf t1, t2, t3, t4, s;
+    fe_add(&t1, &p->x, &p->t);
+    fe_sub(&t2, &p->x, &p->t);
+    fe_mul(&t3, &t1, &t2);                   /* num = (X+T)(X-T) */
+    fe_sqr(&t2, &p->x);
+    fe_mul(&t1, &t2, &t3);
+    fe_mulw_signed(&t2, &t1, -1 - TWISTED_D); /* 39081 * X^2 * num */
+    (void)orc_gf_isr(&t1, &t2);              /* r */
+    fe_mul(&t2, &t1, &t3);                   /* ratio = r*num */
+    fe_mul(&t4, &t2, &FE_FACTOR);
+    mask_t negx = orc_gf_lobit(&t4);
+    fe_cond_neg(&t2, negx);
+    fe_mul(&t3, &t2, &p->z);
+    fe_sub(&t3, &t3, &p->t);
+    fe_mul(&t2, &t3, &p->x);
+    fe_mulw_signed(&t4, &t2, -1 - TWISTED_D);
+    fe_mul(&s, &t4, &t1);
+    fe_cond_neg(&s, orc_gf_lobit(&s));
+    orc_gf_serialize(out, &s);
+}
+
+/* goldilocks.c:142-176 */
+int orc_point_decode(orc_point *p, const uint8_t in[56], int allow_identity) {
+    orc_gf s, s2, num, tmp, tmp2, den, ynum, isr;
+    mask_t ok = orc_gf_deserialize(&s, in, 0);
+    ok &= (allow_identity ? ~(mask_t)0 : 0) | ~orc_gf_eq(&s, &FE_ZERO);
+    ok &= ~orc_gf_lobit(&s);
+    fe_sqr(&s2, &s);
+    fe_sub(&den, &FE_ONE, &s2);
+    fe_add(&ynum, &FE_ONE, &s2);
+    fe_mulw_signed(&num, &s2, -4 * TWISTED_D);
+    fe_sqr(&tmp, &den);
+    fe_add(&num, &tmp, &num);
+    fe_mul(&tmp2, &num, &tmp);
+    ok &= orc_gf_isr(&isr, &tmp2);
+    fe_mul(&tmp, &isr, &den);
+    fe_mul(&p->y, &tmp, &ynum);
+    fe_mul(&tmp2, &tmp, &s);
+    fe_add(&tmp2, &tmp2, &tmp2);
+    fe_mul(&tmp, &tmp2, &isr);
+    fe_mul(&p->x, &tmp, &num);
+    fe_mul(&tmp, &tmp2, &FE_FACTOR);
+    fe_cond_neg(&p->x, orc_gf_lobit(&tmp));
+    p->z = FE_ONE;
+    fe_mul(&p->t, &p->x, &p->y);
+    return ok ? ORC_SUCCESS : ORC_FAILURE;
+}
+
+/* goldilocks.c:905-946 : dual 4-isogeny to Ed448, affine, RFC 8032 encoding */
+void orc_point_encode_like_eddsa(uint8_t out[57], const orc_point *p) {
+    orc_gf x, y, z, t, u;
+    fe_sqr(&x, &p->x);
+    fe_sqr(&t, &p->y);
+    fe_add(&u, &x, &t);
+    fe_add(&z, &p->y, &p->x);
+    fe_sqr(&y, &z);
+    fe_sub(&y, &y, &u);
+    fe_sub(&z, &t, &x);
+    fe_sqr(&x, &p->z);
+    fe_add(&t, &x, &x);
+    fe_sub(&t, &t, &z);
+    fe_mul(&x, &t, &y);
+    fe_mul(&y, &z, &u);
+    fe_mul(&z, &u, &t);
+    fe_invert(&z, &z);
+    fe_mul(&t, &x, &z);
+    fe_mul(&x, &y, &z);
+    out[56] = 0;
+    orc_gf_serialize(out, &x);
+    out[56] |= 0x80 & (uint8_t)orc_gf_lobit(&t);
+}
+
+/* goldilocks.c:949-1004 */
+int orc_point_decode_like_eddsa(orc_point *p, const uint8_t in[57]) {
+    uint8_t enc[57];
+    orc_gf a, b, c, d;
+    memcpy(enc, in, 57);
+    mask_t low = ~is_zero64(enc[56] & 0x80);
+    enc[56] &= 0x7f;
+    mask_t ok = orc_gf_deserialize(&p->y, enc, 0);
+    ok &= is_zero64(enc[56]);
+    fe_sqr(&p->x, &p->y);
+    fe_sub(&p->z, &FE_ONE, &p->x);                  /* 1 - y^2 */
+    fe_mulw_signed(&p->t, &p->x, EDWARDS_D);        /* d y^2 */
+    fe_sub(&p->t, &FE_ONE, &p->t);                  /* 1 - d y^2 */
+    fe_mul(&p->x, &p->z, &p->t);
+    ok &= orc_gf_isr(&p->t, &p->x);
+    fe_mul(&p->x, &p->t, &p->z);
+    fe_cond_neg(&p->x, orc_gf_lobit(&p->x) ^ low);
+    p->z = FE_ONE;
+    /* 4-isogeny onto the twisted curve (note E = 2Z^2 - D, not - T') */
+    fe_sqr(&c, &p->x);
+    fe_sqr(&a, &p->y);
+    fe_add(&d, &c, &a);
+    fe_add(&p->t, &p->y, &p->x);
+    fe_sqr(&b, &p->t);
+    fe_sub(&b, &b, &d);
+    fe_sub(&p->t, &a, &c);
+    fe_sqr(&p->x, &p->z);
+    fe_add(&p->z, &p->x, &p->x);
+    fe_sub(&a, &p->z, &d);
+    fe_mul(&p->x, &a, &b);
+    fe_mul(&p->z, &p->t, &a);
+    fe_mul(&p->y, &p->t, &d);
+    fe_mul_ip(&p->t, &b, &d);
+    return ok ? ORC_SUCCESS : ORC_FAILURE;
+}
+
+/* ---- variable-base scalarmul: goldilocks.c:382-465 ---- */
+
+static void build_odd_multiples(orc_pniels *tab, const orc_point *b, int n) { /* :382-403 */
+    orc_point tmp;
+    orc_pniels twice;
+    pt_double(&tmp, b, 0);
+    pt_to_pniels(&twice, &tmp);
+    pt_to_pniels(&tab[0], b);
+    tmp = *b;
+    for (int i = 1; i < n; i++) {
+        pt_addsub_pniels(&tmp, &twice, 0, 0);
+        pt_to_pniels(&tab[i], &tmp);
+    }
+}
+
+/* constant_time.h:134-183 semantics: table[idx] */
+static void lookup_pniels(orc_pniels *out, const orc_pniels *tab, int n, unsigned idx) {
+    memset(out, 0, sizeof(*out));
+    for (int j = 0; j < n; j++) {
+        mask_t m = is_zero64((uint64_t)j ^ idx);
+        const uint64_t *src = (const uint64_t *)&tab[j];
+        uint64_t *dst = (uint64_t *)out;
+        for (size_t k = 0; k < sizeof(*out) / 8; k++) dst[k] |= src[k] & m;
+    }
+}
+
+static unsigned window5(const orc_scalar *s, int i) { /* goldilocks.c:432-436 */
+    uint64_t bits = s->limb[i / 64] >> (i % 64);
+    if (i % 64 >= 64 - 5 && i / 64 < 6) bits ^= s->limb[i / 64 + 1] << (64 - (i % 64));
+    return (unsigned)(bits & 31);
+}
+
+void orc_point_scalarmul(orc_point *out, const orc_point *base, const orc_scalar *scalar) {
+    orc_scalar s1;
+    orc_pniels pn, tab[16];
+    orc_point tmp;
+    int first = 1;
+    orc_scalar_add(&s1, scalar, &SC_ADJ);
+    orc_scalar_halve(&s1, &s1);
+    build_odd_multiples(tab, base, 16);
+    for (int i = 446 - ((446 - 1) % 5) - 1; i >= 0; i -= 5) {
+        unsigned bits = window5(&s1, i);
+        mask_t inv = (mask_t)(bits >> 4) - 1;
+        bits ^= (unsigned)inv;
+        lookup_pniels(&pn, tab, 16, bits & 15);
+        niels_cond_neg(&pn.n, inv);
+        if (first) {
+            pniels_to_pt(&tmp, &pn);
+            first = 0;
+        } else {
+            for (int j = 0; j < 4; j++) pt_double(&tmp, &tmp, -1);
+            pt_double(&tmp, &tmp, 0);
+            pt_addsub_pniels(&tmp, &pn, i ? -1 : 0, 0);
+        }
+    }
+    *out = tmp;
+}
+
+/* goldilocks.c:467-541 */
+void orc_point_double_scalarmul(orc_point *out, const orc_point *b, const orc_scalar *sb,
+                                const orc_point *c, const orc_scalar *sc) {
+    orc_scalar s1, s2;
+    orc_pniels pn, tab1[16], tab2[16];
+    orc_point tmp;
+    int first = 1;
+    orc_scalar_add(&s1, sb, &SC_ADJ);  orc_scalar_halve(&s1, &s1);
+    orc_scalar_add(&s2, sc, &SC_ADJ);  orc_scalar_halve(&s2, &s2);
+    build_odd_multiples(tab1, b, 16);
+    build_odd_multiples(tab2, c, 16);
+    for (int i = 445; i >= 0; i -= 5) {
+        unsigned b1 = window5(&s1, i), b2 = window5(&s2, i);
+        mask_t inv1 = (mask_t)(b1 >> 4) - 1, inv2 = (mask_t)(b2 >> 4) - 1;
+        b1 ^= (unsigned)inv1;  b2 ^= (unsigned)inv2;
+        lookup_pniels(&pn, tab1, 16, b1 & 15);
+        niels_cond_neg(&pn.n, inv1);
+        if (first) {
+            pniels_to_pt(&tmp, &pn);
+            first = 0;
+        } else {
+            for (int j = 0; j < 4; j++) pt_double(&tmp, &tmp, -1);
+            pt_double(&tmp, &tmp, 0);
+            pt_addsub_pniels(&tmp, &pn, 0, 0);
+        }
+        lookup_pniels(&pn, tab2, 16, b2 & 15);
+        niels_cond_neg(&pn.n, inv2);
+        pt_addsub_pniels(&tmp, &pn, i ? -1 : 0, 0);
+    }
+    *out = tmp;
+}
+
+/* ---- fixed-base comb: goldilocks.c:703-877 ---- */
+
+#define COMBS_N 5
+#define COMBS_T 5
+#define COMBS_S 18
+
+static void fe_batch_invert(orc_gf *out, const orc_gf *in, int n) { /* goldilocks.c:703-726 */
+    orc_gf t1;
+    out[1] = in[0];
+    for (int i = 1; i < n - 1; i++) fe_mul(&out[i + 1], &out[i], &in[i]);
+    fe_mul(&out[0], &out[n - 1], &in[n - 1]);
+    fe_invert(&out[0], &out[0]);
+    for (int i = n - 1; i > 0; i--) {
+        fe_mul(&t1, &out[i], &out[0]);
+        out[i] = t1;
+        fe_mul(&t1, &out[0], &in[i]);
+        out[0] = t1;
+    }
+}
+static void normalize_niels(orc_niels *tab, const orc_gf *zs, orc_gf *zis, int n) { /* :728-753 */
+    orc_gf prod;
+    fe_batch_invert(zis, zs, n);
+    for (int i = 0; i < n; i++) {
+        fe_mul(&prod, &tab[i].a, &zis[i]);  orc_gf_strong_reduce(&prod);  tab[i].a = prod;
+        fe_mul(&prod, &tab[i].b, &zis[i]);  orc_gf_strong_reduce(&prod);  tab[i].b = prod;
+        fe_mul(&prod, &tab[i].c, &zis[i]);  orc_gf_strong_reduce(&prod);  tab[i].c = prod;
+    }
+}
+
+void orc_precompute(orc_precomputed *table, const orc_point *base) { /* goldilocks.c:755-818 */
+    const unsigned n = COMBS_N, t = COMBS_T, s = COMBS_S;
+    orc_point working = *base, start, doubles[COMBS_T - 1];
+    orc_pniels pn;
+    orc_gf zs[80], zis[80];
+    for (unsigned i = 0; i < n; i++) {
+        for (unsigned j = 0; j < t; j++) {
+            if (j) orc_point_add(&start, &start, &working);
+            else start = working;
+            if (j == t - 1 && i == n - 1) break;
+            pt_double(&working, &working, 0);
+            if (j < t - 1) doubles[j] = working;
+            for (unsigned k = 0; k < s - 1; k++) pt_double(&working, &working, k < s - 2);
+        }
+        for (unsigned j = 0;; j++) {
+            int gray = j ^ (j >> 1);
+            int idx = (((i + 1) << (t - 1)) - 1) ^ gray;
+            pt_to_pniels(&pn, &start);
+            table->table[idx] = pn.n;
+            zs[idx] = pn.z;
+            if (j >= (1u << (t - 1)) - 1) break;
+            int delta = (j + 1) ^ ((j + 1) >> 1) ^ gray;
+            unsigned k;
+            for (k = 0; delta > 1; k++) delta >>= 1;
+            if (gray & (1 << k)) orc_point_add(&start, &start, &doubles[k]);
+            else orc_point_sub(&start, &start, &doubles[k]);
+        }
+    }
+    normalize_niels(table->table, zs, zis, 80);
+}
+
+void orc_precomputed_scalarmul(orc_point *out, const orc_precomputed *table, const orc_scalar *scalar) {
+    const unsigned n = COMBS_N, t = COMBS_T, s = COMBS_S; /* goldilocks.c:830-877 */
+    orc_scalar s1;
+    orc_niels ni;
+    orc_scalar_add(&s1, scalar, &SC_ADJ);
+    orc_scalar_halve(&s1, &s1);
+    for (int i = (int)s - 1; i >= 0; i--) {
+        if (i != (int)s - 1) pt_double(out, out, 0);
+        for (unsigned j = 0; j < n; j++) {
+            unsigned tab = 0;
+            for (unsigned k = 0; k < t; k++) {
+                unsigned bit = i + s * (k + j * t);
+                if (bit < 446) tab |= (unsigned)((s1.limb[bit / 64] >> (bit % 64)) & 1) << k;
+            }
+            mask_t invert = (mask_t)(tab >> (t - 1)) - 1;
+            tab ^= (unsigned)invert;
+            tab &= (1u << (t - 1)) - 1;
+            ni = table->table[(j << (t - 1)) + tab];
+            niels_cond_neg(&ni, invert);
+            if (i != (int)s - 1 || j) pt_addsub_niels(out, &ni, j == n - 1 && i, 0);
+            else niels_to_pt(out, &ni);
+        }
+    }
+}
+
+/* ---- variable-time double-base: goldilocks.c:1143-1330 ---- */
+
+struct wnaf_ctl { int power, addend; };
+
+static int recode_wnaf(struct wnaf_ctl *control, const orc_scalar *scalar, unsigned table_bits) {
+    unsigned table_size = 446 / (table_bits + 1) + 3; /* goldilocks.c:1151-1202 */
+    int position = (int)table_size - 1;
+    control[position].power = -1;
+    control[position].addend = 0;
+    position--;
+    uint64_t current = scalar->limb[0] & 0xFFFF;
+    uint32_t mask = (1u << (table_bits + 1)) - 1;
+    for (unsigned w = 1; w < (446 - 1) / 16 + 3; w++) {
+        if (w < (446 - 1) / 16 + 1)
+            current += (uint32_t)((scalar->limb[w / 4] >> (16 * (w % 4))) << 16);
+        while (current & 0xFFFF) {
+            uint32_t pos = (uint32_t)__builtin_ctz((uint32_t)current), odd = (uint32_t)current >> pos;
+            int32_t delta = (int32_t)(odd & mask);
+            if (odd & (1u << (table_bits + 1))) delta -= (int32_t)(1u << (table_bits + 1));
+            current -= (uint64_t)(int64_t)(delta * (int32_t)(1u << pos));
+            control[position].power = (int)(pos + 16 * (w - 1));
+            control[position].addend = delta;
+            position--;
+        }
+        current >>= 16;
+    }
+    position++;
+    unsigned n = table_size - (unsigned)position;
+    for (unsigned i = 0; i < n; i++) control[i] = control[i + position];
+    return (int)n - 1;
+}
+
+static void build_wnaf_table(orc_pniels *out, const orc_point *working, unsigned tbits) { /* :1204-1230 */
+    orc_point tmp;
+    orc_pniels twop;
+    pt_to_pniels(&out[0], working);
+    if (tbits == 0) return;
+    pt_double(&tmp, working, 0);
+    pt_to_pniels(&twop, &tmp);
+    pt_addsub_pniels(&tmp, &out[0], 0, 0);
+    pt_to_pniels(&out[1], &tmp);
+    for (int i = 2; i < 1 << tbits; i++) {
+        pt_addsub_pniels(&tmp, &twop, 0, 0);
+        pt_to_pniels(&out[i], &tmp);
+    }
+}
+
+void orc_precompute_wnafs(orc_niels out[32], const orc_point *base) { /* goldilocks.c:1241-1258 */
+    orc_pniels tmp[32];
+    orc_gf zs[32], zis[32];
+    build_wnaf_table(tmp, base, 5);
+    for (int i = 0; i < 32; i++) { out[i] = tmp[i].n; zs[i] = tmp[i].z; }
+    normalize_niels(out, zs, zis, 32);
+}
+
+void orc_base_double_scalarmul_non_secret(orc_point *combo, const orc_scalar *s1,
+                                          const orc_point *base2, const orc_scalar *s2) {
+    struct wnaf_ctl cvar[446 / 4 + 3], cpre[446 / 6 + 3]; /* goldilocks.c:1260-1330 */
+    const orc_niels *wb = orc_wnaf_base();
+    int contp = 0, contv = 0, i;
+    (void)recode_wnaf(cpre, s1, 5);
+    (void)recode_wnaf(cvar, s2, 3);
+    orc_pniels pvar[8];
+    build_wnaf_table(pvar, base2, 3);
+    i = cvar[0].power;
+    if (i < 0) {
+        *combo = PT_IDENTITY;
+        return;
+    } else if (i > cpre[0].power) {
+        pniels_to_pt(combo, &pvar[cvar[0].addend >> 1]);
+        contv++;
+    } else if (i == cpre[0].power && i >= 0) {
+        pniels_to_pt(combo, &pvar[cvar[0].addend >> 1]);
+        pt_addsub_niels(combo, &wb[cpre[0].addend >> 1], i, 0);
+        contv++;  contp++;
+    } else {
+        i = cpre[0].power;
+        niels_to_pt(combo, &wb[cpre[0].addend >> 1]);
+        contp++;
+    }
+    for (i--; i >= 0; i--) {
+        int cv = (i == cvar[contv].power), cp = (i == cpre[contp].power);
+        pt_double(combo, combo, i && !(cv || cp));
+        if (cv) {
+            if (cvar[contv].addend > 0) pt_addsub_pniels(combo, &pvar[cvar[contv].addend >> 1], i && !cp, 0);
+            else pt_addsub_pniels(combo, &pvar[(-cvar[contv].addend) >> 1], i && !cp, 1);
+            contv++;
+        }
+        if (cp) {
+            if (cpre[contp].addend > 0) pt_addsub_niels(combo, &wb[cpre[contp].addend >> 1], i, 0);
+            else pt_addsub_niels(combo, &wb[(-cpre[contp].addend) >> 1], i, 1);
+            contp++;
+        }
+    }
+}
+
+int orc_direct_scalarmul(uint8_t out[56], const uint8_t base[56], const orc_scalar *s,
+                         int allow_identity, int short_circuit) { /* goldilocks.c:888-903 */
+    orc_point bp;
+    int succ = orc_point_decode(&bp, base, allow_identity);
+    if (short_circuit && succ != ORC_SUCCESS) return succ;
+    if (succ != ORC_SUCCESS) bp = *orc_point_base();
+    orc_point_scalarmul(&bp, &bp, s);
+    orc_point_encode(out, &bp);
+    return succ;
+}
+
+/* ---- constants regenerated by this file's own generator (gen_tables.c:21-23, 59-86) ---- */
+
+static pthread_once_t g_tables_once = PTHREAD_ONCE_INIT;
+static orc_point g_base;
+static orc_precomputed g_comb;
+static orc_niels g_wnaf[32];
+
+static void tables_init(void) {
+    uint8_t ser[56];
+    memset(ser, 0x66, 28);
+    memset(ser + 28, 0x33, 28);
+    (void)orc_point_decode(&g_base, ser, 0);
+    /* the reference stores point_base as canonical FIELD_LITERALs (gen_tables.c:40-57, 95-100) */
+    orc_gf_strong_reduce(&g_base.x);  orc_gf_strong_reduce(&g_base.y);
+    orc_gf_strong_reduce(&g_base.z);  orc_gf_strong_reduce(&g_base.t);
+    orc_precompute(&g_comb, &g_base);
+    orc_precompute_wnafs(g_wnaf, &g_base);
+}
+const orc_point *orc_point_base(void) { pthread_once(&g_tables_once, tables_init); return &g_base; }
+const orc_precomputed *orc_precomputed_base(void) { pthread_once(&g_tables_once, tables_init); return &g_comb; }
+const orc_niels *orc_wnaf_base(void) { pthread_once(&g_tables_once, tables_init); return g_wnaf; }
+
+/* =====================================================================
+ * SHAKE256  (src/shake.c:60-162, 211-213: rate 136, pad 0x1f / 0x80)
+ * ===================================================================== */
+
+static inline uint64_t rotl64(uint64_t x, int s) { return s ? (x << s) | (x >> (64 - s)) : x; }
+
+static void keccak_f1600(uint64_t st[25]) {
+    static const uint64_t RC[24] = {
+        0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
+        0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+        0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+        0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
+        0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+        0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    static const int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43,
+                                25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    for (int round = 0; round < 24; round++) {
+        uint64_t C[5], B[25];
+        for (int x = 0; x < 5; x++) C[x] = st[x] ^ st[x + 5] ^ st[x + 10] ^ st[x + 15] ^ st[x + 20];
+        for (int x = 0; x < 5; x++) {
+            uint64_t D = C[(x + 4) % 5] ^ rotl64(C[(x + 1) % 5], 1);
+            for (int y = 0; y < 25; y += 5) st[y + x] ^= D;
+        }
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++)
+                B[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(st[x + 5 * y], RHO[x + 5 * y]);
+        for (int y = 0; y < 25; y += 5)
+            for (int x = 0; x < 5; x++) st[y + x] = B[y + x] ^ (~B[y + (x + 1) % 5] & B[y + (x + 2) % 5]);
+        st[0] ^= RC[round];
+    }
+}
+
+typedef struct { uint64_t st[25]; unsigned pos; } shake_ctx;
+#define SHAKE256_RATE 136
+
+static void shake_init(shake_ctx *c) { memset(c, 0, sizeof(*c)); }
+static void shake_absorb(shake_ctx *c, const uint8_t *in, size_t len) {
+    for (size_t i = 0; i < len; i++) {
+        c->st[c->pos / 8] ^= (uint64_t)in[i] << (8 * (c->pos % 8));
+        if (++c->pos == SHAKE256_RATE) { keccak_f1600(c->st); c->pos = 0; }
+    }
+}
+static void shake_squeeze(shake_ctx *c, uint8_t *out, size_t len) { /* call once, after absorb */
+    c->st[c->pos / 8] ^= (uint64_t)0x1f << (8 * (c->pos % 8));
+    c->st[(SHAKE256_RATE - 1) / 8] ^= (uint64_t)0x80 << (8 * ((SHAKE256_RATE - 1) % 8));
+    keccak_f1600(c->st);
+    c->pos = 0;
+    for (size_t i = 0; i < len; i++) {
+        if (c->pos == SHAKE256_RATE) { keccak_f1600(c->st); c->pos = 0; }
+        out[i] = (uint8_t)(c->st[c->pos / 8] >> (8 * (c->pos % 8)));
+        c->pos++;
+    }
+}
+void orc_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen) {
+    shake_ctx c;
+    shake_init(&c);
+    shake_absorb(&c, in, inlen);
+    shake_squeeze(&c, out, outlen);
+}
+
+/* =====================================================================
+ * EdDSA-Ed448 (src/eddsa.c)
+ * ===================================================================== */
+
+static void ed_clamp(uint8_t s[57]) { /* eddsa.c:34-48 */
+    s[0] &= 0xFC;
+    s[56] = 0;
+    s[55] |= 0x80;
+}
+static void ed_dom(shake_ctx *h, uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen) { /* eddsa.c:51-74 */
+    /* dom[0] = 2 + word_is_zero(prehashed) + word_is_zero(for_prehash=0) with all-ones
+     * masks, i.e. 2 - [prehashed==0] - 1  (mod 256)  =  prehashed ? 1 : 0 */
+    uint8_t dom[2] = {(uint8_t)(prehashed ? 1 : 0), ctxlen};
+    shake_init(h);
+    shake_absorb(h, (const uint8_t *)"SigEd448", 8);
+    shake_absorb(h, dom, 2);
+    shake_absorb(h, ctx, ctxlen);
+}
+static void ed_secret_scalar(orc_scalar *s, const uint8_t sk[57]) { /* eddsa.c:98-129 */
+    uint8_t ser[57];
+    orc_shake256(ser, 57, sk, 57);
+    ed_clamp(ser);
+    orc_scalar_decode_long(s, ser, 57);
+    for (unsigned c = 1; c < 4; c <<= 1) orc_scalar_halve(s, s);
+}
+void orc_ed448_derive_public_key(uint8_t pk[57], const uint8_t sk[57]) { /* eddsa.c:131-147 */
+    orc_scalar s;
+    orc_point p;
+    ed_secret_scalar(&s, sk);
+    orc_precomputed_scalarmul(&p, orc_precomputed_base(), &s);
+    orc_point_encode_like_eddsa(pk, &p);
+}
+void orc_ed448_sign(uint8_t sig[114], const uint8_t sk[57], const uint8_t pk[57], const uint8_t *msg,
+                    size_t msglen, uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen) {
+    orc_scalar secret, nonce, challenge, n2; /* eddsa.c:149-230 */
+    uint8_t expanded[114], nonce_ser[114], rpoint[57], chal[114];
+    shake_ctx h;
+    orc_point p;
+    orc_shake256(expanded, 114, sk, 57);
+    ed_clamp(expanded);
+    orc_scalar_decode_long(&secret, expanded, 57);
+    ed_dom(&h, prehashed, ctx, ctxlen);
+    shake_absorb(&h, expanded + 57, 57);
+    shake_absorb(&h, msg, msglen);
+    shake_squeeze(&h, nonce_ser, 114);
+    orc_scalar_decode_long(&nonce, nonce_ser, 114);
+    orc_scalar_halve(&n2, &nonce);
+    for (unsigned c = 2; c < 4; c <<= 1) orc_scalar_halve(&n2, &n2);
+    orc_precomputed_scalarmul(&p, orc_precomputed_base(), &n2);
+    orc_point_encode_like_eddsa(rpoint, &p);
+    ed_dom(&h, prehashed, ctx, ctxlen);
+    shake_absorb(&h, rpoint, 57);
+    shake_absorb(&h, pk, 57);
+    shake_absorb(&h, msg, msglen);
+    shake_squeeze(&h, chal, 114);
+    orc_scalar_decode_long(&challenge, chal, 114);
+    orc_scalar_mul(&challenge, &challenge, &secret);
+    orc_scalar_add(&challenge, &challenge, &nonce);
+    memset(sig, 0, 114);
+    memcpy(sig, rpoint, 57);
+    orc_scalar_encode(sig + 57, &challenge);
+}
+int orc_ed448_verify(const uint8_t sig[114], const uint8_t pk[57], const uint8_t *msg, size_t msglen,
+                     uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen) { /* eddsa.c:253-306 */
+    orc_point pkp, rp;
+    orc_scalar challenge, response;
+    uint8_t chal[114];
+    shake_ctx h;
+    if (orc_point_decode_like_eddsa(&pkp, pk) != ORC_SUCCESS) return ORC_FAILURE;
+    if (orc_point_decode_like_eddsa(&rp, sig) != ORC_SUCCESS) return ORC_FAILURE;
+    ed_dom(&h, prehashed, ctx, ctxlen);
+    shake_absorb(&h, sig, 57);
+    shake_absorb(&h, pk, 57);
+    shake_absorb(&h, msg, msglen);
+    shake_squeeze(&h, chal, 114);
+    orc_scalar_decode_long(&challenge, chal, 114);
+    orc_scalar_sub(&challenge, &SC_ZERO, &challenge);
+    orc_scalar_decode_long(&response, sig + 57, 57);
+    orc_base_double_scalarmul_non_secret(&pkp, &response, &pkp, &challenge);
+    return orc_point_eq(&pkp, &rp);
+}
+
+/* =====================================================================
+ * Threaded batch drivers (cpu_baseline timing, bulk checks)
+ * ===================================================================== */
+
+typedef void (*range_fn)(void *arg, size_t lo, size_t hi);
+struct range_job { range_fn fn; void *arg; size_t lo, hi; };
+static void *range_tramp(void *p) {
+    struct range_job *j = (struct range_job *)p;
+    j->fn(j->arg, j->lo, j->hi);
+    return NULL;
+}
+static void run_ranges(range_fn fn, void *arg, size_t n, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    if (nthreads > 256) nthreads = 256;
+    if ((size_t)nthreads > n) nthreads = n ? (int)n : 1;
+    pthread_t th[256];
+    struct range_job jobs[256];
+    for (int t = 0; t < nthreads; t++) {
+        jobs[t] = (struct range_job){fn, arg, n * t / nthreads, n * (t + 1) / nthreads};
+        if (t) pthread_create(&th[t], NULL, range_tramp, &jobs[t]);
+    }
+    range_tramp(&jobs[0]);
+    for (int t = 1; t < nthreads; t++) pthread_join(th[t], NULL);
+}
+
+struct sm_args { orc_point *out; const orc_point *base; const orc_precomputed *tab; const orc_scalar *s; };
+static void sm_range(void *a, size_t lo, size_t hi) {
+    struct sm_args *x = (struct sm_args *)a;
+    for (size_t i = lo; i < hi; i++) orc_point_scalarmul(&x->out[i], &x->base[i], &x->s[i]);
+}
+static void psm_range(void *a, size_t lo, size_t hi) {
+    struct sm_args *x = (struct sm_args *)a;
+    for (size_t i = lo; i < hi; i++) orc_precomputed_scalarmul(&x->out[i], x->tab, &x->s[i]);
+}
+void orc_point_scalarmul_batch(orc_point *out, const orc_point *base, const orc_scalar *s, size_t n, int nt) {
+    struct sm_args a = {out, base, NULL, s};
+    run_ranges(sm_range, &a, n, nt);
+}
+void orc_precomputed_scalarmul_batch(orc_point *out, const orc_precomputed *tab, const orc_scalar *s,
+                                     size_t n, int nt) {
+    struct sm_args a = {out, NULL, tab, s};
+    (void)orc_point_base();
+    run_ranges(psm_range, &a, n, nt);
+}
+
+struct enc_args { uint8_t *out; const orc_point *p; };
+static void enc_range(void *a, size_t lo, size_t hi) {
+    struct enc_args *x = (struct enc_args *)a;
+    for (size_t i = lo; i < hi; i++) orc_point_encode(x->out + 56 * i, &x->p[i]);
+}
+void orc_point_encode_batch(uint8_t *out56, const orc_point *p, size_t n, int nt) {
+    struct enc_args a = {out56, p};
+    run_ranges(enc_range, &a, n, nt);
+}
+
+struct ed_args {
+    int32_t *status; uint8_t *sig_out; uint8_t *pk_out;
+    const uint8_t *sig, *pk, *sk, *msgs; size_t msglen; uint8_t prehashed; const uint8_t *ctx; uint8_t ctxlen;
+};
+static void ver_range(void *a, size_t lo, size_t hi) {
+    struct ed_args *x = (struct ed_args *)a;
+    for (size_t i = lo; i < hi; i++)
+        x->status[i] = orc_ed448_verify(x->sig + 114 * i, x->pk + 57 * i, x->msgs + x->msglen * i, x->msglen,
+                                        x->prehashed, x->ctx, x->ctxlen);
+}
+static void sign_range(void *a, size_t lo, size_t hi) {
+    struct ed_args *x = (struct ed_args *)a;
+    for (size_t i = lo; i < hi; i++)
+        orc_ed448_sign(x->sig_out + 114 * i, x->sk + 57 * i, x->pk + 57 * i, x->msgs + x->msglen * i,
+                       x->msglen, x->prehashed, x->ctx, x->ctxlen);
+}
+static void pk_range(void *a, size_t lo, size_t hi) {
+    struct ed_args *x = (struct ed_args *)a;
+    for (size_t i = lo; i < hi; i++) orc_ed448_derive_public_key(x->pk_out + 57 * i, x->sk + 57 * i);
+}
+void orc_ed448_verify_batch(int32_t *status, const uint8_t *sig, const uint8_t *pk, const uint8_t *msgs,
+                            size_t msglen, uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, size_t n,
+                            int nt) {
+    struct ed_args a = {status, NULL, NULL, sig, pk, NULL, msgs, msglen, prehashed, ctx, ctxlen};
+    (void)orc_point_base();
+    run_ranges(ver_range, &a, n, nt);
+}
+void orc_ed448_sign_batch(uint8_t *sig, const uint8_t *sk, const uint8_t *pk, const uint8_t *msgs,
+                          size_t msglen, uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, size_t n,
+                          int nt) {
+    struct ed_args a = {NULL, sig, NULL, NULL, pk, sk, msgs, msglen, prehashed, ctx, ctxlen};
+    (void)orc_point_base();
+    run_ranges(sign_range, &a, n, nt);
+}
+void orc_ed448_derive_public_key_batch(uint8_t *pk, const uint8_t *sk, size_t n, int nt) {
+    struct ed_args a = {NULL, NULL, pk, NULL, NULL, sk, NULL, 0, 0, NULL, 0};
+    (void)orc_point_base();
+    run_ranges(pk_range, &a, n, nt);
+}
