@@ -1,0 +1,238 @@
+// eddsa.hpp -- per-lane Ed448 verification (RFC 8032), restating
+//   goldilocks_ed448_verify                  src/eddsa.c:253-306
+//   hash_init_with_dom ("SigEd448" dom2)     src/eddsa.c:51-74
+//   SHAKE256 (rate 136, pad 0x1f .. 0x80)    src/shake.c:60-162, 211-213
+//   scalar_decode_long                       src/scalar.c:257-293
+// The reference finishes with the variable-time wNAF double-base multiply
+// (src/goldilocks.c:1260-1330); only accept/reject is observable, so the lanes run
+// the lane-uniform fixed-window double-base ladder instead (no divergence).
+#pragma once
+#include "scalarmul.hpp"
+
+namespace gd {
+
+// ------------------------------------------------------------------ Keccak-f[1600]
+// State words are only ever indexed with compile-time constants so they stay in VGPRs.
+
+GD_FN uint64_t rotl64(uint64_t x, int s) { return s ? (x << s) | (x >> (64 - s)) : x; }
+
+GD_CONST uint64_t KECCAK_RC[24] = {
+    0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808aull, 0x8000000080008000ull,
+    0x000000000000808bull, 0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull,
+    0x000000000000008aull, 0x0000000000000088ull, 0x0000000080008009ull, 0x000000008000000aull,
+    0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
+    0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
+    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+
+GD_FN void keccak_round(uint64_t (&a)[25], uint64_t rc) {
+    constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43,
+                             25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    uint64_t c[5], b[25];
+#pragma unroll
+    for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        uint64_t d = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) a[y + x] ^= d;
+    }
+#pragma unroll
+    for (int x = 0; x < 5; x++)
+#pragma unroll
+        for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rotl64(a[x + 5 * y], RHO[x + 5 * y]);
+#pragma unroll
+    for (int y = 0; y < 25; y += 5)
+#pragma unroll
+        for (int x = 0; x < 5; x++) a[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
+    a[0] ^= rc;
+}
+GD_FN void keccak_f1600(uint64_t (&a)[25]) {
+#pragma unroll 1
+    for (int r = 0; r < 24; r++) keccak_round(a, KECCAK_RC[r]);
+}
+
+constexpr int SHAKE256_RATE = 136;
+
+// Host-side convenience sponge (tests only; dynamic indexing would spill on the GPU).
+#if !defined(__HIPCC__)
+struct shake256 {
+    uint64_t st[25];
+    unsigned pos;
+    void init() {
+        for (int i = 0; i < 25; i++) st[i] = 0;
+        pos = 0;
+    }
+    void absorb(const uint8_t *in, size_t len) {
+        for (size_t i = 0; i < len; i++) {
+            st[pos / 8] ^= (uint64_t)in[i] << (8 * (pos % 8));
+            if (++pos == SHAKE256_RATE) { keccak_f1600(st); pos = 0; }
+        }
+    }
+    void finish() {
+        st[pos / 8] ^= (uint64_t)0x1f << (8 * (pos % 8));
+        st[16] ^= 0x8000000000000000ull;
+        keccak_f1600(st);
+        pos = 0;
+    }
+    void squeeze(uint8_t *out, size_t len) {
+        for (size_t i = 0; i < len; i++) {
+            if (pos == SHAKE256_RATE) { keccak_f1600(st); pos = 0; }
+            out[i] = (uint8_t)(st[pos / 8] >> (8 * (pos % 8)));
+            pos++;
+        }
+    }
+};
+#endif
+
+// ------------------------------------------------------------------ challenge hash
+// The hashed string is  "SigEd448" | ph | ctxlen | ctx | R(57) | A(57) | msg.
+// MSG policy: src.byte(j) returns byte j of that virtual string (j < total).
+// STAGE policy: a per-lane 136-byte scratch: stage.put(i, byte), stage.get64(k).
+// Returns the first 114 output bytes as 29 words (top 2 bytes of word 28 zero).
+template <class MSG, class STAGE>
+GD_FN void shake256_114(uint32_t out[29], const MSG &src, uint32_t total, STAGE &stage) {
+    uint64_t st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    const uint32_t nblocks = total / SHAKE256_RATE + 1;  // padding always adds >= 1 byte
+#pragma unroll 1
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+        const uint32_t base = blk * SHAKE256_RATE;
+#pragma unroll 1
+        for (uint32_t i = 0; i < SHAKE256_RATE; i++) {
+            const uint32_t j = base + i;
+            uint32_t b = j < total ? src.byte(j) : (j == total ? 0x1fu : 0u);
+            if (i == SHAKE256_RATE - 1 && blk == nblocks - 1) b ^= 0x80u;
+            stage.put(i, b);
+        }
+#pragma unroll
+        for (int k = 0; k < SHAKE256_RATE / 8; k++) st[k] ^= stage.get64(k);
+        keccak_f1600(st);
+    }
+#pragma unroll
+    for (int k = 0; k < 14; k++) {
+        out[2 * k] = (uint32_t)st[k];
+        out[2 * k + 1] = (uint32_t)(st[k] >> 32);
+    }
+    out[28] = (uint32_t)st[14] & 0xffffu;
+}
+
+// ------------------------------------------------------------------ scalar_decode_long
+// NBYTES-byte little-endian integer (packed in words, unused high bytes zero) mod q,
+// folded 56 bytes at a time from the top (src/scalar.c:257-293).
+template <int NBYTES>
+GD_FN sc sc_decode_long_words(const uint32_t *w) {
+    static_assert(NBYTES > 56 && NBYTES % 56 != 0, "only the shapes verify needs");
+    constexpr int FULL = NBYTES / 56;
+    sc t1 = sc_zero();
+#pragma unroll
+    for (int i = 0; i < 14 && 14 * FULL + i < (NBYTES + 3) / 4; i++) t1.w[i] = w[14 * FULL + i];
+#pragma unroll
+    for (int blk = FULL - 1; blk >= 0; blk--) {
+        t1 = sc_montmul(t1, sc_const(SC_R2));
+        sc t2;
+#pragma unroll
+        for (int i = 0; i < 14; i++) t2.w[i] = w[14 * blk + i];
+        t1 = sc_add(t1, sc_reduce(t2));
+    }
+    return t1;
+}
+
+#if !defined(__HIPCC__)
+static inline sc sc_decode_long_bytes(const uint8_t *in, size_t len) {  // host tests, generic length
+    uint32_t w[64] = {0};
+    for (size_t i = 0; i < len && i < 256; i++) w[i / 4] |= (uint32_t)in[i] << (8 * (i % 4));
+    if (len == 114) return sc_decode_long_words<114>(w);
+    if (len == 57) return sc_decode_long_words<57>(w);
+    if (len == 72) return sc_decode_long_words<72>(w);
+    return sc_zero();
+}
+#endif
+
+// ------------------------------------------------------------------ verify
+struct Ed448Msg {  // the virtual challenge string
+    const uint8_t *sig, *pk, *msg, *ctx;
+    uint32_t msglen, ctxlen;
+    uint32_t ph;
+    GD_MFN uint32_t total() const { return 10 + ctxlen + 114 + msglen; }
+    GD_MFN uint32_t byte(uint32_t j) const {
+        // "SigEd448" as two little-endian words
+        if (j < 8) return ((j < 4 ? 0x45676953u : 0x38343464u) >> (8 * (j & 3))) & 0xffu;
+        if (j == 8) return ph;
+        if (j == 9) return ctxlen;
+        j -= 10;
+        if (j < ctxlen) return ctx[j];
+        j -= ctxlen;
+        if (j < 57) return sig[j];
+        j -= 57;
+        if (j < 57) return pk[j];
+        return msg[j - 57];
+    }
+};
+
+GD_FN void load_bytes_as_words(uint32_t *w, const uint8_t *p, int nbytes, int nwords) {
+    for (int i = 0; i < nwords; i++) {
+        uint32_t x = 0;
+        for (int b = 0; b < 4; b++)
+            if (4 * i + b < nbytes) x |= (uint32_t)p[4 * i + b] << (8 * b);
+        w[i] = x;
+    }
+}
+
+// BT: window table of the base point (shared, read-only).  AT: this lane's table,
+// filled here.  STAGE/BITS: see above; `mkbits(sc)` turns a recoded scalar into a
+// BITS reader (LDS-backed on the device).
+template <class BT, class AT, class STAGE, class MKBITS>
+GD_FN bool ed448_verify_core(const Ed448Msg &m, const BT &base_tab, AT &a_tab, STAGE &stage, MKBITS &mkbits) {
+    uint32_t w[29];
+    pt A, R;
+    load_bytes_as_words(w, m.pk, 57, 15);
+    bool ok = pt_decode_eddsa_words(A, w);
+    load_bytes_as_words(w, m.sig, 57, 15);
+    ok = pt_decode_eddsa_words(R, w) && ok;   // (both decoded: lanes stay uniform)
+
+    shake256_114(w, m, m.total(), stage);
+    sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));   // -h mod q
+    load_bytes_as_words(w, m.sig + 57, 57, 15);
+    sc response = sc_decode_long_words<57>(w);                        // S mod q, no range check
+
+    build_window_table(a_tab, A);
+    auto bits_s = mkbits(sc_recode_signed(response), 0);
+    auto bits_c = mkbits(sc_recode_signed(challenge), 1);
+    pt P = ladder_double(bits_s, base_tab, bits_c, a_tab);            // S*B - h*A
+    return ok && pt_eq(P, R);
+}
+
+#if !defined(__HIPCC__)
+struct HostStage {
+    uint8_t b[136];
+    void put(uint32_t i, uint32_t v) { b[i] = (uint8_t)v; }
+    uint64_t get64(int k) const {
+        uint64_t x = 0;
+        for (int i = 0; i < 8; i++) x |= (uint64_t)b[8 * k + i] << (8 * i);
+        return x;
+    }
+};
+struct HostBitsV {
+    uint32_t w[15];
+    uint32_t word(int k) const { return w[k]; }
+};
+struct HostMkBits {
+    HostBitsV operator()(const sc &s, int) const {
+        HostBitsV b;
+        for (int i = 0; i < 14; i++) b.w[i] = s.w[i];
+        b.w[14] = 0;
+        return b;
+    }
+};
+template <class BT, class AT>
+static inline bool ed448_verify_lane(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen,
+                                     uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const BT &bt, AT &at) {
+    Ed448Msg m{sig, pk, msg, ctx, (uint32_t)msglen, ctxlen, prehashed ? 1u : 0u};
+    HostStage stage;
+    HostMkBits mk;
+    return ed448_verify_core(m, bt, at, stage, mk);
+}
+#endif
+
+}  // namespace gd

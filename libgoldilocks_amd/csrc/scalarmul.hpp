@@ -1,0 +1,128 @@
+// scalarmul.hpp -- the scalar-multiplication ladders, one operation per lane.
+//
+// The loop structure restates the reference's three scalarmuls:
+//   variable base, signed 5-bit fixed windows   src/goldilocks.c:405-465
+//   fixed base, 5x5x18 signed comb              src/goldilocks.c:830-877
+//   double base a*P + b*Q, interleaved windows  src/goldilocks.c:467-541
+// All three walk the recoded scalar s' = (s + 2^450 - 1)/2 mod q, whose 5-bit digit
+// w in [0,32) stands for the odd signed digit 2w - 31.
+//
+// The ladders are templates over two small policies so that the same code is
+// (a) instantiated by the HIP kernels with HBM/LDS-backed storage and (b) run on
+// the host by tests/hostsim with plain arrays (checker only, never shipped):
+//   BITS  : bits.word(k) -> k-th 32-bit word of s' (k < 15, word 14 is zero)
+//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table
+#pragma once
+#include "point.hpp"
+#include "sc14.hpp"
+
+namespace gd {
+
+// 5-bit window of s' whose least significant bit is bit `pos` (pos <= 445).
+template <class BITS>
+GD_FN uint32_t window5(const BITS &bits, int pos) {
+    const int k = pos >> 5, sh = pos & 31;
+    uint32_t lo = bits.word(k) >> sh;
+    uint32_t hi = sh > 27 ? bits.word(k + 1) << (32 - sh) : 0u;  // sh > 27: window straddles
+    return (lo | hi) & 31u;
+}
+
+// digit w -> (table index, negate): index (w^inv)&15 with inv = (w>>4)-1; entry
+// holds (2*idx+1)*B; negate iff w < 16  (src/goldilocks.c:437-442).
+GD_FN void signed_digit(uint32_t w, uint32_t &idx, bool &neg) {
+    neg = w < 16;
+    idx = (neg ? ~w : w) & 15u;
+}
+
+// multiples[k] = (2k+1)*B, k < 16, as projective niels (src/goldilocks.c:382-403).
+template <class TABLE>
+GD_FN void build_window_table(TABLE &table, const pt &b) {
+    pt twice = b;
+    pt_double(twice, true);
+    pniels step = pt_to_pniels(twice);
+    table.store(0, pt_to_pniels(b));
+    pt acc = b;
+#pragma unroll 1
+    for (int k = 1; k < 16; k++) {
+        pt_add_pniels(acc, step, false, true);
+        table.store(k, pt_to_pniels(acc));
+    }
+}
+
+// out = s * B with the window table already built and s' readable through `bits`.
+template <class BITS, class TABLE>
+GD_FN pt ladder_varbase(const BITS &bits, const TABLE &table) {
+    uint32_t idx;
+    bool neg;
+    signed_digit(window5(bits, 445), idx, neg);
+    pt acc = pniels_to_pt(table.load(idx), neg);
+#pragma unroll 1
+    for (int pos = 440; pos >= 0; pos -= 5) {
+        signed_digit(window5(bits, pos), idx, neg);
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) pt_double(acc, j == 4);
+        pniels e = table.load(idx);
+        // T is only needed by a following addition, i.e. never after the last window's
+        // add -- except that the caller wants a complete extended point at pos == 0.
+        pt_add_pniels(acc, e, neg, pos == 0);
+    }
+    return acc;
+}
+
+// Comb: 18 rounds; round i adds, for each of the 5 combs j, the entry selected by
+// bits i + 18*(k + 5j), k < 5, of s'  (src/goldilocks.c:846-873).
+// COMB: comb.load(j, idx) -> affine niels entry 16*j + idx (our sign convention).
+template <class BITS>
+GD_FN uint32_t comb_teeth(const BITS &bits, int i, int j) {
+    uint32_t tab = 0;
+#pragma unroll
+    for (int k = 0; k < 5; k++) {
+        const int bit = i + 18 * (k + 5 * j);
+        if (bit < 446) tab |= ((bits.word(bit >> 5) >> (bit & 31)) & 1u) << k;
+    }
+    return tab;
+}
+
+template <class BITS, class COMB>
+GD_FN pt ladder_comb(const BITS &bits, const COMB &comb) {
+    uint32_t idx;
+    bool neg;
+    signed_digit(comb_teeth(bits, 17, 0), idx, neg);
+    pt acc = niels_to_pt(comb.load(0, idx), neg);
+#pragma unroll 1
+    for (int i = 17; i >= 0; i--) {
+        if (i != 17) pt_double(acc, true);
+#pragma unroll 1
+        for (int j = (i == 17 ? 1 : 0); j < 5; j++) {
+            signed_digit(comb_teeth(bits, i, j), idx, neg);
+            niels e = comb.load(j, idx);
+            // T feeds the next addition; the last add of a round is followed by a
+            // doubling (which ignores T) unless it is the very last one.
+            pt_add_niels(acc, e, neg, !(j == 4 && i));
+        }
+    }
+    return acc;
+}
+
+// out = s1*P1 + s2*P2, both through 16-entry window tables (src/goldilocks.c:467-541).
+template <class BITS, class TABLE1, class TABLE2>
+GD_FN pt ladder_double(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2) {
+    uint32_t idx;
+    bool neg;
+    signed_digit(window5(bits1, 445), idx, neg);
+    pt acc = pniels_to_pt(t1.load(idx), neg);
+    signed_digit(window5(bits2, 445), idx, neg);
+    pt_add_pniels(acc, t2.load(idx), neg, false);
+#pragma unroll 1
+    for (int pos = 440; pos >= 0; pos -= 5) {
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) pt_double(acc, j == 4);
+        signed_digit(window5(bits1, pos), idx, neg);
+        pt_add_pniels(acc, t1.load(idx), neg, true);
+        signed_digit(window5(bits2, pos), idx, neg);
+        pt_add_pniels(acc, t2.load(idx), neg, pos == 0);
+    }
+    return acc;
+}
+
+}  // namespace gd

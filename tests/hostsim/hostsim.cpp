@@ -1,0 +1,172 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Compiles the device headers (gf28/point/scalarmul/...) as plain C++ with the
+// GF_CHECKED accumulator (traps on any 64-bit accumulator overflow/underflow and on
+// violated subtraction-bias preconditions) so the lane arithmetic and its
+// magnitude contract can be exercised in the CPU-only container against the
+// oracle.  It is never loaded by the product; the product path has no CPU mode.
+#define GF_CHECKED 1
+#include "../../libgoldilocks_amd/csrc/abi.hpp"
+#include "../../libgoldilocks_amd/csrc/scalarmul.hpp"
+#include "../../libgoldilocks_amd/csrc/eddsa.hpp"
+
+#include <string.h>
+
+using namespace gd;
+
+namespace {
+struct HostBits {
+    uint32_t w[15];
+    uint32_t word(int k) const { return w[k]; }
+};
+HostBits make_bits(const sc &s) {
+    sc r = sc_recode_signed(s);
+    HostBits b;
+    for (int i = 0; i < 14; i++) b.w[i] = r.w[i];
+    b.w[14] = 0;
+    return b;
+}
+struct HostTable {
+    pniels e[16];
+    void store(int k, const pniels &p) { e[k] = p; }
+    pniels load(uint32_t k) const { return e[k]; }
+};
+struct HostComb {
+    niels e[80];
+    niels load(int j, uint32_t idx) const { return e[16 * j + idx]; }
+};
+void words_to_bytes(uint8_t *out, const uint32_t *w, int nbytes) {
+    for (int i = 0; i < nbytes; i++) out[i] = (uint8_t)(w[i / 4] >> (8 * (i % 4)));
+}
+void bytes_to_words(uint32_t *w, const uint8_t *in, int nbytes, int nwords) {
+    for (int i = 0; i < nwords; i++) w[i] = 0;
+    for (int i = 0; i < nbytes; i++) w[i / 4] |= (uint32_t)in[i] << (8 * (i % 4));
+}
+}  // namespace
+
+extern "C" {
+
+void hs_fe_mul(uint64_t *o, const uint64_t *a, const uint64_t *b) {
+    fe_to_limbs56(o, fe_mul(fe_weak(fe_from_limbs56(a)), fe_weak(fe_from_limbs56(b))));
+}
+void hs_fe_sqr(uint64_t *o, const uint64_t *a) { fe_to_limbs56(o, fe_sqr(fe_weak(fe_from_limbs56(a)))); }
+void hs_fe_mulw(uint64_t *o, const uint64_t *a, uint32_t w) {
+    fe_to_limbs56(o, fe_mulw(fe_weak(fe_from_limbs56(a)), w));
+}
+int hs_fe_isr(uint64_t *o, const uint64_t *a) {
+    bool ok;
+    fe_to_limbs56(o, fe_isr(fe_weak(fe_from_limbs56(a)), &ok));
+    return ok ? -1 : 0;
+}
+void hs_fe_serialize(uint8_t *out, const uint64_t *a) {
+    uint32_t w[14];
+    fe_serialize_words(w, fe_from_limbs56(a));
+    words_to_bytes(out, w, 56);
+}
+int hs_fe_deserialize(uint64_t *o, const uint8_t *in) {
+    uint32_t w[14];
+    bytes_to_words(w, in, 56, 14);
+    fe x;
+    bool ok = fe_deserialize_words(x, w);
+    fe_to_limbs56(o, x);
+    return ok ? -1 : 0;
+}
+// stress mul at the documented magnitude limits: a*(ma), b*(mb) limb-wise scaled
+void hs_fe_mul_mag(uint64_t *o, const uint64_t *a, const uint64_t *b, int ma, int mb) {
+    fe x = fe_weak(fe_from_limbs56(a)), y = fe_weak(fe_from_limbs56(b)), xs = fe_zero(), ys = fe_zero();
+    for (int i = 0; i < ma; i++) xs = fe_add(xs, x);
+    for (int i = 0; i < mb; i++) ys = fe_add(ys, y);
+    fe_to_limbs56(o, fe_mul(xs, ys));
+}
+void hs_fe_sqr_mag(uint64_t *o, const uint64_t *a, int ma) {
+    fe x = fe_weak(fe_from_limbs56(a)), xs = fe_zero();
+    for (int i = 0; i < ma; i++) xs = fe_add(xs, x);
+    fe_to_limbs56(o, fe_sqr(xs));
+}
+
+void hs_sc_recode(uint64_t *o, const uint64_t *s) { sc_to_abi(o, sc_recode_signed(sc_from_abi(s))); }
+void hs_sc_mul(uint64_t *o, const uint64_t *a, const uint64_t *b) {
+    sc_to_abi(o, sc_mul(sc_from_abi(a), sc_from_abi(b)));
+}
+void hs_sc_add(uint64_t *o, const uint64_t *a, const uint64_t *b) {
+    sc_to_abi(o, sc_add(sc_from_abi(a), sc_from_abi(b)));
+}
+void hs_sc_sub(uint64_t *o, const uint64_t *a, const uint64_t *b) {
+    sc_to_abi(o, sc_sub(sc_from_abi(a), sc_from_abi(b)));
+}
+void hs_sc_decode_long(uint64_t *o, const uint8_t *in, size_t len) {
+    sc_to_abi(o, sc_decode_long_bytes(in, len));
+}
+
+void hs_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *scalar) {
+    HostBits bits = make_bits(sc_from_abi(scalar));
+    HostTable tab;
+    build_window_table(tab, pt_from_abi(base));
+    pt_to_abi(out, ladder_varbase(bits, tab));
+}
+void hs_precomputed_scalarmul(uint64_t *out, const uint64_t *table /*80*24 limbs*/, const uint64_t *scalar) {
+    HostBits bits = make_bits(sc_from_abi(scalar));
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(table + 24 * i);
+    pt_to_abi(out, ladder_comb(bits, comb));
+}
+void hs_point_double_scalarmul(uint64_t *out, const uint64_t *b, const uint64_t *sb, const uint64_t *c,
+                               const uint64_t *scc) {
+    HostBits b1 = make_bits(sc_from_abi(sb)), b2 = make_bits(sc_from_abi(scc));
+    HostTable t1, t2;
+    build_window_table(t1, pt_from_abi(b));
+    build_window_table(t2, pt_from_abi(c));
+    pt_to_abi(out, ladder_double(b1, t1, b2, t2));
+}
+void hs_point_add(uint64_t *out, const uint64_t *a, const uint64_t *b, int subtract) {
+    pt_to_abi(out, pt_add(pt_from_abi(a), pt_from_abi(b), subtract != 0));
+}
+void hs_point_double(uint64_t *out, const uint64_t *a) {
+    pt p = pt_from_abi(a);
+    pt_double(p, true);
+    pt_to_abi(out, p);
+}
+int hs_point_eq(const uint64_t *a, const uint64_t *b) { return pt_eq(pt_from_abi(a), pt_from_abi(b)) ? -1 : 0; }
+int hs_point_valid(const uint64_t *a) { return pt_valid(pt_from_abi(a)) ? -1 : 0; }
+void hs_point_encode(uint8_t *out, const uint64_t *a) {
+    uint32_t w[14];
+    pt_encode_words(w, pt_from_abi(a));
+    words_to_bytes(out, w, 56);
+}
+int hs_point_decode(uint64_t *out, const uint8_t *in, int allow_identity) {
+    uint32_t w[14];
+    bytes_to_words(w, in, 56, 14);
+    pt p;
+    bool ok = pt_decode_words(p, w, allow_identity != 0);
+    pt_to_abi(out, p);
+    return ok ? -1 : 0;
+}
+void hs_point_encode_eddsa(uint8_t *out, const uint64_t *a) {
+    uint32_t w[15];
+    pt_encode_eddsa_words(w, pt_from_abi(a));
+    words_to_bytes(out, w, 57);
+}
+int hs_point_decode_eddsa(uint64_t *out, const uint8_t *in) {
+    uint32_t w[15];
+    bytes_to_words(w, in, 57, 15);
+    pt p;
+    bool ok = pt_decode_eddsa_words(p, w);
+    pt_to_abi(out, p);
+    return ok ? -1 : 0;
+}
+void hs_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen) {
+    shake256 h;
+    h.init();
+    h.absorb(in, inlen);
+    h.finish();
+    h.squeeze(out, outlen);
+}
+int hs_ed448_verify(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen, uint8_t prehashed,
+                    const uint8_t *ctx, uint8_t ctxlen, const uint64_t *base_point) {
+    HostTable tb;  // fixed-base window table built on the fly (the device keeps it staged)
+    build_window_table(tb, pt_from_abi(base_point));
+    HostTable ta;
+    return ed448_verify_lane(sig, pk, msg, msglen, prehashed, ctx, ctxlen, tb, ta) ? -1 : 0;
+}
+
+}  // extern "C"
