@@ -1,0 +1,233 @@
+/*
+ * goldilocks_amd.h -- C ABI of libgoldilocks_amd.so: the MI355X (gfx950) backend for
+ * the batched Ed448-Goldilocks scalar-multiplication hot path of otrv4/libgoldilocks.
+ *
+ * Three groups of entry points, all `extern "C"`, plain pointers and sizes:
+ *
+ *  (1) DROP-IN single-operation functions with the reference's exact names, argument
+ *      meaning and error behaviour, so that eddsa.c / elligator.c / the C++ wrappers /
+ *      python/edgold link against this library instead of the arch_* CPU backend.
+ *      Each one runs the HIP path with a batch of one (there is NO CPU fallback: if no
+ *      gfx950 device can be opened the call aborts with a message on stderr, because
+ *      the reference's void functions have no way to report failure).
+ *
+ *  (2) *_batch functions over HOST arrays (AoS, the reference's struct layouts): one
+ *      H2D copy, one kernel, one D2H copy.  New; the reference has no batch API.
+ *
+ *  (3) goldilocks_amd_*_dev functions over DEVICE arrays on a caller-supplied HIP
+ *      stream (what bench.py times; what a host written in another language binds
+ *      through cgo/JNI/ctypes -- see INTEGRATION.md).
+ *
+ * "ref:" comments cite the reference declaration each function replaces, relative to
+ * the reference tree (src/public_include/goldilocks/...).
+ *
+ * Type layouts are the reference's (ref: point_448.h:33-35, 66-70, 82-86): a field
+ * element is 8 x uint64 limbs of 56 bits, 32-byte aligned; a point is {x,y,z,t}; a
+ * scalar is 7 x uint64 little-endian, fully reduced mod q.  Points produced by this
+ * library are weakly reduced like the reference's (limbs < 2^56 + small); as in the
+ * reference, raw limbs are not a canonical form -- compare encodings.
+ */
+#ifndef GOLDILOCKS_AMD_H
+#define GOLDILOCKS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GOLDILOCKS_AMD_API __attribute__((visibility("default")))
+
+/* ------------------------------------------------------------------ ABI types */
+
+#define GOLDILOCKS_448_SER_BYTES 56            /* ref: point_448.h:40 */
+#define GOLDILOCKS_448_SCALAR_BYTES 56         /* ref: point_448.h:48 */
+#define GOLDILOCKS_448_SCALAR_LIMBS 7          /* ref: point_448.h:23 */
+#define GOLDILOCKS_EDDSA_448_PUBLIC_BYTES 57   /* ref: ed448.h:24 */
+#define GOLDILOCKS_EDDSA_448_PRIVATE_BYTES 57  /* ref: ed448.h:27 */
+#define GOLDILOCKS_EDDSA_448_SIGNATURE_BYTES 114 /* ref: ed448.h:30 */
+
+typedef uint64_t goldilocks_word_t;  /* ref: common.h:60 */
+typedef uint64_t goldilocks_bool_t;  /* all-ones / zero mask; ref: common.h:62 */
+typedef enum {                       /* ref: common.h:82-85 */
+    GOLDILOCKS_SUCCESS = -1,
+    GOLDILOCKS_FAILURE = 0
+} goldilocks_error_t;
+
+typedef struct gf_448_s {            /* ref: point_448.h:33-35 */
+    goldilocks_word_t limb[8];
+} __attribute__((aligned(32))) gf_448_s, gf_448_p[1];
+
+typedef struct goldilocks_448_point_s {   /* ref: point_448.h:66-70 */
+    gf_448_p x, y, z, t;
+} goldilocks_448_point_s, goldilocks_448_point_p[1];
+
+typedef struct goldilocks_448_scalar_s {  /* ref: point_448.h:82-86 */
+    goldilocks_word_t limb[GOLDILOCKS_448_SCALAR_LIMBS];
+} goldilocks_448_scalar_s, goldilocks_448_scalar_p[1];
+
+/* Opaque, caller-allocated, goldilocks_448_sizeof_precomputed_s bytes (15360),
+ * goldilocks_448_alignof_precomputed_s alignment.  ref: point_448.h:73-79.
+ * Contents are bit-compatible with the reference's (80 affine niels, canonical limbs). */
+struct goldilocks_448_precomputed_s;
+typedef struct goldilocks_448_precomputed_s goldilocks_448_precomputed_s;
+
+/* ------------------------------------------------------------------ exported constants */
+
+GOLDILOCKS_AMD_API extern const size_t goldilocks_448_sizeof_precomputed_s;   /* ref: point_448.h:79 */
+GOLDILOCKS_AMD_API extern const size_t goldilocks_448_alignof_precomputed_s;  /* ref: point_448.h:79 */
+GOLDILOCKS_AMD_API extern const goldilocks_448_scalar_p goldilocks_448_scalar_one;   /* ref: point_448.h:89 */
+GOLDILOCKS_AMD_API extern const goldilocks_448_scalar_p goldilocks_448_scalar_zero;  /* ref: point_448.h:92 */
+GOLDILOCKS_AMD_API extern const goldilocks_448_point_p goldilocks_448_point_identity; /* ref: point_448.h:95 */
+GOLDILOCKS_AMD_API extern const goldilocks_448_point_p goldilocks_448_point_base;     /* ref: point_448.h:98 */
+GOLDILOCKS_AMD_API extern const goldilocks_448_precomputed_s *goldilocks_448_precomputed_base; /* ref: point_448.h:101 */
+
+/* ------------------------------------------------------------------ (1) drop-in single ops */
+
+/* scaled = scalar * base.  Output may alias input.  ref: point_448.h:355-359, src/goldilocks.c:405-465 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_scalarmul(goldilocks_448_point_p scaled,
+        const goldilocks_448_point_p base, const goldilocks_448_scalar_p scalar);
+
+/* Decode base, multiply, encode.  On a decoding failure: with short_circuit the error is
+ * returned and `scaled` is untouched, otherwise the multiply runs on the base point and the
+ * error is returned afterwards.  ref: point_448.h:378-384, src/goldilocks.c:888-903 */
+GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_448_direct_scalarmul(uint8_t scaled[GOLDILOCKS_448_SER_BYTES],
+        const uint8_t base[GOLDILOCKS_448_SER_BYTES], const goldilocks_448_scalar_p scalar,
+        goldilocks_bool_t allow_identity, goldilocks_bool_t short_circuit);
+
+/* Build the 5x5x18 comb table for `base`.  ref: point_448.h:461-464, src/goldilocks.c:755-818 */
+GOLDILOCKS_AMD_API void goldilocks_448_precompute(goldilocks_448_precomputed_s *table,
+        const goldilocks_448_point_p base);
+
+/* scaled = scalar * (table's point).  ref: point_448.h:477-481, src/goldilocks.c:830-877 */
+GOLDILOCKS_AMD_API void goldilocks_448_precomputed_scalarmul(goldilocks_448_point_p scaled,
+        const goldilocks_448_precomputed_s *table, const goldilocks_448_scalar_p scalar);
+
+/* combo = scalar1*base1 + scalar2*base2.  ref: point_448.h:496-502, src/goldilocks.c:467-541 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_double_scalarmul(goldilocks_448_point_p combo,
+        const goldilocks_448_point_p base1, const goldilocks_448_scalar_p scalar1,
+        const goldilocks_448_point_p base2, const goldilocks_448_scalar_p scalar2);
+
+/* combo = scalar1*point_base + scalar2*base2 ("non_secret": the reference is variable-time
+ * here; this backend runs a lane-uniform ladder).  ref: point_448.h:542-547, src/goldilocks.c:1260-1330 */
+GOLDILOCKS_AMD_API void goldilocks_448_base_double_scalarmul_non_secret(goldilocks_448_point_p combo,
+        const goldilocks_448_scalar_p scalar1, const goldilocks_448_point_p base2,
+        const goldilocks_448_scalar_p scalar2);
+
+/* Canonical 56-byte decaf encoding.  ref: point_448.h:241-244, src/goldilocks.c:136-140 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_encode(uint8_t ser[GOLDILOCKS_448_SER_BYTES],
+        const goldilocks_448_point_p pt);
+/* FAILURE for non-canonical / negative / (unless allowed) identity encodings; output undefined
+ * then.  ref: point_448.h:258-264, src/goldilocks.c:142-176 */
+GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_448_point_decode(goldilocks_448_point_p pt,
+        const uint8_t ser[GOLDILOCKS_448_SER_BYTES], goldilocks_bool_t allow_identity);
+
+/* RFC 8032 57-byte encoding of 4*p / decoding (no cofactor multiply on decode: ratio 4/4).
+ * ref: ed448.h:213-232, src/goldilocks.c:905-1004 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa(
+        uint8_t enc[GOLDILOCKS_EDDSA_448_PUBLIC_BYTES], const goldilocks_448_point_p p);
+GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio(
+        goldilocks_448_point_p p, const uint8_t enc[GOLDILOCKS_EDDSA_448_PUBLIC_BYTES]);
+
+/* Group law and predicates.  ref: point_448.h:274-337, src/goldilocks.c:178-268, 644-673 */
+GOLDILOCKS_AMD_API goldilocks_bool_t goldilocks_448_point_eq(const goldilocks_448_point_p a,
+        const goldilocks_448_point_p b);
+GOLDILOCKS_AMD_API goldilocks_bool_t goldilocks_448_point_valid(const goldilocks_448_point_p a);
+GOLDILOCKS_AMD_API void goldilocks_448_point_add(goldilocks_448_point_p sum,
+        const goldilocks_448_point_p a, const goldilocks_448_point_p b);
+GOLDILOCKS_AMD_API void goldilocks_448_point_sub(goldilocks_448_point_p diff,
+        const goldilocks_448_point_p a, const goldilocks_448_point_p b);
+GOLDILOCKS_AMD_API void goldilocks_448_point_double(goldilocks_448_point_p two_a,
+        const goldilocks_448_point_p a);
+
+/* RFC 8032 Ed448 verification.  ref: ed448.h:157-165, src/eddsa.c:253-306 */
+GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_ed448_verify(
+        const uint8_t signature[GOLDILOCKS_EDDSA_448_SIGNATURE_BYTES],
+        const uint8_t pubkey[GOLDILOCKS_EDDSA_448_PUBLIC_BYTES],
+        const uint8_t *message, size_t message_len, uint8_t prehashed,
+        const uint8_t *context, uint8_t context_len);
+
+/* ------------------------------------------------------------------ (2) host-array batches
+ * All return 0 on success, nonzero on a runtime (HIP) error -- see goldilocks_amd_last_error().
+ * Arrays are dense AoS of the reference structs; outputs may alias inputs of the same type. */
+
+GOLDILOCKS_AMD_API int goldilocks_448_point_scalarmul_batch(goldilocks_448_point_s *scaled,
+        const goldilocks_448_point_s *base, const goldilocks_448_scalar_s *scalar, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_448_precomputed_scalarmul_batch(goldilocks_448_point_s *scaled,
+        const goldilocks_448_precomputed_s *table, const goldilocks_448_scalar_s *scalar, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_448_point_double_scalarmul_batch(goldilocks_448_point_s *combo,
+        const goldilocks_448_point_s *base1, const goldilocks_448_scalar_s *scalar1,
+        const goldilocks_448_point_s *base2, const goldilocks_448_scalar_s *scalar2, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_448_point_encode_batch(uint8_t *ser /* n*56 */,
+        const goldilocks_448_point_s *pt, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_448_point_decode_batch(goldilocks_448_point_s *pt,
+        goldilocks_error_t *status, const uint8_t *ser /* n*56 */, goldilocks_bool_t allow_identity, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa_batch(uint8_t *enc /* n*57 */,
+        const goldilocks_448_point_s *pt, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio_batch(goldilocks_448_point_s *pt,
+        goldilocks_error_t *status, const uint8_t *enc /* n*57 */, size_t n);
+/* status[i] = verify(sig[i], pk[i], msg[i], len[i], prehashed, ctx, ctxlen) */
+GOLDILOCKS_AMD_API int goldilocks_ed448_verify_batch(goldilocks_error_t *status,
+        const uint8_t *sig /* n*114 */, const uint8_t *pk /* n*57 */,
+        const uint8_t *const *message, const size_t *message_len, uint8_t prehashed,
+        const uint8_t *context, uint8_t context_len, size_t n);
+
+/* ------------------------------------------------------------------ (3) device-array API
+ * Pointers are device pointers (hipMalloc / torch.Tensor.data_ptr()); `stream` is a
+ * hipStream_t (NULL = default stream).  Calls are asynchronous on that stream and use a
+ * per-device workspace owned by the library: issue them from one stream at a time per device. */
+
+/* Bind this process to a device and build the device-resident tables.  Optional (every
+ * entry point initialises lazily on the current HIP device).  Returns 0 on success. */
+GOLDILOCKS_AMD_API int goldilocks_amd_init(int device);
+GOLDILOCKS_AMD_API void goldilocks_amd_shutdown(void);
+GOLDILOCKS_AMD_API const char *goldilocks_amd_last_error(void);
+/* "gfx950", number of CUs, workspace bytes currently held */
+GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
+        size_t *workspace_bytes);
+
+GOLDILOCKS_AMD_API int goldilocks_amd_point_scalarmul_dev(void *scaled /* point_s[n] */,
+        const void *base /* point_s[n] */, const void *scalar /* scalar_s[n] */, size_t n, void *stream);
+/* table == NULL selects the built-in base-point comb; otherwise a DEVICE copy of a precomputed_s */
+GOLDILOCKS_AMD_API int goldilocks_amd_precomputed_scalarmul_dev(void *scaled, const void *table,
+        const void *scalar, size_t n, void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_point_double_scalarmul_dev(void *combo, const void *base1,
+        const void *scalar1, const void *base2, const void *scalar2, size_t n, void *stream);
+/* base1 == point_base for every lane (verify's shape) */
+GOLDILOCKS_AMD_API int goldilocks_amd_base_double_scalarmul_dev(void *combo, const void *scalar1,
+        const void *base2, const void *scalar2, size_t n, void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_point_encode_dev(void *ser /* n*56 B */, const void *pt, size_t n,
+        void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_point_decode_dev(void *pt, void *status /* int32[n] */,
+        const void *ser, int allow_identity, size_t n, void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_point_encode_eddsa_dev(void *enc /* n*57 B */, const void *pt, size_t n,
+        void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_point_decode_eddsa_dev(void *pt, void *status /* int32[n] */,
+        const void *enc, size_t n, void *stream);
+/* op: 0 add, 1 sub, 2 double (b ignored); out/a/b: point_s[n] */
+GOLDILOCKS_AMD_API int goldilocks_amd_point_op_dev(void *out, const void *a, const void *b, int op, size_t n,
+        void *stream);
+/* op: 0 eq(a,b), 1 valid(a); status: int32[n] (-1 / 0) */
+GOLDILOCKS_AMD_API int goldilocks_amd_point_pred_dev(void *status, const void *a, const void *b, int op,
+        size_t n, void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_precompute_dev(void *table /* precomputed_s[n] */, const void *base,
+        size_t n, void *stream);
+/* Messages: if msg_offsets != NULL, message i is msgs[msg_offsets[i] .. msg_offsets[i+1])
+ * (uint64 offsets, n+1 entries, device memory); otherwise every message is msg_len bytes at
+ * msgs + i*msg_len.  ctx: device pointer to ctx_len bytes (may be NULL when ctx_len == 0).
+ * status: int32[n], -1 = GOLDILOCKS_SUCCESS, 0 = GOLDILOCKS_FAILURE. */
+GOLDILOCKS_AMD_API int goldilocks_amd_ed448_verify_dev(void *status, const void *sig, const void *pk,
+        const void *msgs, const void *msg_offsets, size_t msg_len, uint8_t prehashed,
+        const void *ctx, uint8_t ctx_len, size_t n, void *stream);
+
+/* Field-level test hook (parity tests for gf_mul / gf_sqr / gf_isr, ref: src/f_field.h:76-79):
+ * op 0: out = a*b, 1: out = a^2, 2: out = isr(a) (status = mask), 3: out = strong_reduce(a).
+ * a, b, out: gf_448_s[n] in the ABI limb form. */
+GOLDILOCKS_AMD_API int goldilocks_amd_field_op_dev(void *out, void *status, const void *a, const void *b,
+        int op, size_t n, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GOLDILOCKS_AMD_H */

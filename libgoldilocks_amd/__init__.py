@@ -1,0 +1,287 @@
+"""libgoldilocks_amd -- ctypes binding of the MI355X Ed448-Goldilocks batch engine.
+
+This is the Python host-side mirror of the reference's own Python binding
+(reference: python/edgold/ed448.py, a ctypes caller of libgoldilocks.so) extended with
+the batch entry points of include/goldilocks_amd.h.  It contains no arithmetic: every
+call goes through the C ABI of the in-tree ``libgoldilocks_amd.so`` (HIP, gfx950).  If
+that library is missing the import fails loudly -- there is no fallback.
+
+Array conventions (numpy, C-contiguous):
+  points   uint64 [n, 32]   = goldilocks_448_point_s  (x,y,z,t, 8 x 56-bit limbs each)
+  scalars  uint64 [n, 7]    = goldilocks_448_scalar_s (little-endian words, < q)
+  tables   uint64 [1920]    = goldilocks_448_precomputed_s
+  bytes    uint8  [n, 56|57|114]
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgoldilocks_amd.so")
+
+GOLDILOCKS_SUCCESS = -1
+GOLDILOCKS_FAILURE = 0
+SER_BYTES = 56
+EDDSA_448_PUBLIC_BYTES = 57
+EDDSA_448_SIGNATURE_BYTES = 114
+
+# Every symbol include/goldilocks_amd.h declares (checked by tests/test_abi.py).
+FUNCTIONS = {
+    # (1) drop-in single ops
+    "goldilocks_448_point_scalarmul": (None, "ppp"),
+    "goldilocks_448_direct_scalarmul": (C.c_int, "pppQQ"),
+    "goldilocks_448_precompute": (None, "pp"),
+    "goldilocks_448_precomputed_scalarmul": (None, "ppp"),
+    "goldilocks_448_point_double_scalarmul": (None, "ppppp"),
+    "goldilocks_448_base_double_scalarmul_non_secret": (None, "pppp"),
+    "goldilocks_448_point_encode": (None, "pp"),
+    "goldilocks_448_point_decode": (C.c_int, "ppQ"),
+    "goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa": (None, "pp"),
+    "goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio": (C.c_int, "pp"),
+    "goldilocks_448_point_eq": (C.c_uint64, "pp"),
+    "goldilocks_448_point_valid": (C.c_uint64, "p"),
+    "goldilocks_448_point_add": (None, "ppp"),
+    "goldilocks_448_point_sub": (None, "ppp"),
+    "goldilocks_448_point_double": (None, "pp"),
+    "goldilocks_ed448_verify": (C.c_int, "pppzBpB"),
+    # (2) host-array batches
+    "goldilocks_448_point_scalarmul_batch": (C.c_int, "pppz"),
+    "goldilocks_448_precomputed_scalarmul_batch": (C.c_int, "pppz"),
+    "goldilocks_448_point_double_scalarmul_batch": (C.c_int, "pppppz"),
+    "goldilocks_448_point_encode_batch": (C.c_int, "ppz"),
+    "goldilocks_448_point_decode_batch": (C.c_int, "pppQz"),
+    "goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa_batch": (C.c_int, "ppz"),
+    "goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio_batch": (C.c_int, "pppz"),
+    "goldilocks_ed448_verify_batch": (C.c_int, "pppppBpBz"),
+    # (3) device-array API
+    "goldilocks_amd_init": (C.c_int, "i"),
+    "goldilocks_amd_shutdown": (None, ""),
+    "goldilocks_amd_last_error": (C.c_char_p, ""),
+    "goldilocks_amd_device_info": (C.c_int, "pzpp"),
+    "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
+    "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
+    "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
+    "goldilocks_amd_base_double_scalarmul_dev": (C.c_int, "ppppzp"),
+    "goldilocks_amd_point_encode_dev": (C.c_int, "ppzp"),
+    "goldilocks_amd_point_decode_dev": (C.c_int, "pppizp"),
+    "goldilocks_amd_point_encode_eddsa_dev": (C.c_int, "ppzp"),
+    "goldilocks_amd_point_decode_eddsa_dev": (C.c_int, "pppzp"),
+    "goldilocks_amd_point_op_dev": (C.c_int, "pppizp"),
+    "goldilocks_amd_point_pred_dev": (C.c_int, "pppizp"),
+    "goldilocks_amd_precompute_dev": (C.c_int, "ppzp"),
+    "goldilocks_amd_ed448_verify_dev": (C.c_int, "pppppzBpBzp"),
+    "goldilocks_amd_field_op_dev": (C.c_int, "ppppizp"),
+}
+DATA_SYMBOLS = [
+    "goldilocks_448_sizeof_precomputed_s", "goldilocks_448_alignof_precomputed_s",
+    "goldilocks_448_scalar_one", "goldilocks_448_scalar_zero", "goldilocks_448_point_identity",
+    "goldilocks_448_point_base", "goldilocks_448_precomputed_base",
+]
+_CT = {"p": C.c_void_p, "z": C.c_size_t, "Q": C.c_uint64, "B": C.c_uint8, "i": C.c_int}
+
+_lib = None
+
+
+class GoldilocksAmdError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded libgoldilocks_amd.so (raises ImportError if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, sig) in FUNCTIONS.items():
+            f = getattr(L, name)
+            f.restype = res
+            f.argtypes = [_CT[ch] for ch in sig]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc:
+        raise GoldilocksAmdError(lib().goldilocks_amd_last_error().decode())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _u64(a, cols):
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    assert a.shape[1] == cols, a.shape
+    return a
+
+
+def _u8(a, cols):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.ndim == 1:
+        a = a.reshape(1, -1)
+    assert a.shape[1] == cols, a.shape
+    return a
+
+
+# ----------------------------------------------------------------------------- constants
+
+
+def point_base():
+    return np.ctypeslib.as_array((C.c_uint64 * 32).in_dll(lib(), "goldilocks_448_point_base")).copy()
+
+
+def point_identity():
+    return np.ctypeslib.as_array((C.c_uint64 * 32).in_dll(lib(), "goldilocks_448_point_identity")).copy()
+
+
+def precomputed_base():
+    """The built-in base-point comb table (copy of the 15360 bytes the exported pointer refers to)."""
+    p = C.c_void_p.in_dll(lib(), "goldilocks_448_precomputed_base")
+    return np.frombuffer(C.string_at(p.value, 15360), dtype=np.uint64).copy()
+
+
+# ----------------------------------------------------------------------------- host-array batches
+
+
+def point_scalarmul_batch(bases, scalars):
+    bases, scalars = _u64(bases, 32), _u64(scalars, 7)
+    n = len(scalars)
+    assert len(bases) == n
+    out = np.empty((n, 32), dtype=np.uint64)
+    _check(lib().goldilocks_448_point_scalarmul_batch(_ptr(out), _ptr(bases), _ptr(scalars), n))
+    return out
+
+
+def precomputed_scalarmul_batch(scalars, table=None):
+    scalars = _u64(scalars, 7)
+    n = len(scalars)
+    out = np.empty((n, 32), dtype=np.uint64)
+    if table is None:
+        tab = C.c_void_p.in_dll(lib(), "goldilocks_448_precomputed_base")
+    else:
+        table = np.ascontiguousarray(table, dtype=np.uint64).reshape(1920)
+        tab = _ptr(table)
+    _check(lib().goldilocks_448_precomputed_scalarmul_batch(_ptr(out), tab, _ptr(scalars), n))
+    return out
+
+
+def point_double_scalarmul_batch(bases1, scalars1, bases2, scalars2):
+    """scalars1*bases1 + scalars2*bases2; bases1=None means the base point for every lane."""
+    scalars1, bases2, scalars2 = _u64(scalars1, 7), _u64(bases2, 32), _u64(scalars2, 7)
+    n = len(scalars1)
+    out = np.empty((n, 32), dtype=np.uint64)
+    b1 = None if bases1 is None else _ptr(_u64(bases1, 32))
+    _check(lib().goldilocks_448_point_double_scalarmul_batch(_ptr(out), b1, _ptr(scalars1), _ptr(bases2),
+                                                             _ptr(scalars2), n))
+    return out
+
+
+def point_encode_batch(points):
+    points = _u64(points, 32)
+    out = np.empty((len(points), 56), dtype=np.uint8)
+    _check(lib().goldilocks_448_point_encode_batch(_ptr(out), _ptr(points), len(points)))
+    return out
+
+
+def point_decode_batch(ser, allow_identity=False):
+    ser = _u8(ser, 56)
+    n = len(ser)
+    pts = np.empty((n, 32), dtype=np.uint64)
+    st = np.empty(n, dtype=np.int32)
+    _check(lib().goldilocks_448_point_decode_batch(_ptr(pts), _ptr(st), _ptr(ser),
+                                                   2**64 - 1 if allow_identity else 0, n))
+    return pts, st
+
+
+def point_encode_like_eddsa_batch(points):
+    points = _u64(points, 32)
+    out = np.empty((len(points), 57), dtype=np.uint8)
+    _check(lib().goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa_batch(_ptr(out), _ptr(points),
+                                                                               len(points)))
+    return out
+
+
+def point_decode_like_eddsa_batch(enc):
+    enc = _u8(enc, 57)
+    n = len(enc)
+    pts = np.empty((n, 32), dtype=np.uint64)
+    st = np.empty(n, dtype=np.int32)
+    _check(lib().goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio_batch(_ptr(pts), _ptr(st), _ptr(enc), n))
+    return pts, st
+
+
+def ed448_verify_batch(sigs, pks, messages, prehashed=False, context=b""):
+    """status[i] in {-1 (valid), 0 (invalid)} for each (sig, pk, message)."""
+    sigs, pks = _u8(sigs, 114), _u8(pks, 57)
+    n = len(sigs)
+    assert len(pks) == n and len(messages) == n
+    bufs = [C.create_string_buffer(bytes(m), max(len(m), 1)) for m in messages]
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    lens = (C.c_size_t * n)(*[len(m) for m in messages])
+    ctx = C.create_string_buffer(bytes(context), max(len(context), 1))
+    st = np.empty(n, dtype=np.int32)
+    _check(lib().goldilocks_ed448_verify_batch(_ptr(st), _ptr(sigs), _ptr(pks), C.addressof(ptrs),
+                                               C.addressof(lens), 1 if prehashed else 0, C.addressof(ctx),
+                                               len(context), n))
+    return st
+
+
+# ----------------------------------------------------------------------------- single ops (drop-in names)
+
+
+def point_scalarmul(base, scalar):
+    base, scalar = _u64(base, 32), _u64(scalar, 7)
+    out = np.empty((1, 32), dtype=np.uint64)
+    lib().goldilocks_448_point_scalarmul(_ptr(out), _ptr(base), _ptr(scalar))
+    return out[0]
+
+
+def precompute(base):
+    base = _u64(base, 32)
+    tab = np.empty(1920, dtype=np.uint64)
+    lib().goldilocks_448_precompute(_ptr(tab), _ptr(base))
+    return tab
+
+
+def ed448_verify(sig, pk, msg, context=b"", prehashed=False):
+    sig, pk = _u8(np.frombuffer(bytes(sig), np.uint8), 114), _u8(np.frombuffer(bytes(pk), np.uint8), 57)
+    m = C.create_string_buffer(bytes(msg), max(len(msg), 1))
+    ctx = C.create_string_buffer(bytes(context), max(len(context), 1))
+    return lib().goldilocks_ed448_verify(_ptr(sig), _ptr(pk), C.addressof(m), len(msg), 1 if prehashed else 0,
+                                         C.addressof(ctx), len(context)) == GOLDILOCKS_SUCCESS
+
+
+class EDDSA448(object):
+    """Verify-only mirror of the reference binding's class (python/edgold/ed448.py:109-201)."""
+
+    def __init__(self, pub):
+        if len(pub) != EDDSA_448_PUBLIC_BYTES:
+            raise ValueError("public key must be 57 bytes")
+        self._pub = bytes(pub)
+
+    def verify(self, sig, msg, ctx=None):
+        """Raises ValueError if sig is not valid for msg (same behaviour as the reference)."""
+        if not ed448_verify(sig, self._pub, msg, context=ctx or b""):
+            raise ValueError("signature is not valid")
+
+
+# ----------------------------------------------------------------------------- device-array API (torch / raw pointers)
+
+
+def dev(name, *args):
+    """Call goldilocks_amd_<name>_dev with raw device pointers (ints) / sizes; raises on error."""
+    _check(getattr(lib(), "goldilocks_amd_%s_dev" % name)(*args))
+
+
+def device_info():
+    arch = C.create_string_buffer(64)
+    cus = C.c_int()
+    ws = C.c_size_t()
+    _check(lib().goldilocks_amd_device_info(C.addressof(arch), 64, C.addressof(cus), C.addressof(ws)))
+    return {"arch": arch.value.decode(), "compute_units": cus.value, "workspace_bytes": ws.value}

@@ -1,0 +1,282 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Bar: bit-exact on canonical encodings / status words (integer arithmetic)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _gen
+from _libs import Q, P
+
+pytestmark = pytest.mark.gpu
+
+EDGE_SCALARS = [0, 1, 2, Q - 1, Q - 2, 2**445, 2**445 - 1, (Q + 1) // 2, 31, 32, 2**224, 2**440 + 12345]
+
+
+def enc(ga, pts):
+    return ga.point_encode_batch(pts)
+
+
+def test_device_is_gfx950(ga):
+    info = ga.device_info()
+    assert info["arch"].startswith("gfx950") and info["compute_units"] > 0
+
+
+def test_field_ops_vs_oracle(ga, O):
+    import torch
+    n = 4096
+    rng = np.random.default_rng(1)
+    a = rng.integers(0, 2**56, size=(n, 8), dtype=np.uint64)
+    b = rng.integers(0, 2**56, size=(n, 8), dtype=np.uint64)
+    # weakly reduced / unreduced-limb inputs and special values
+    a[0] = 0; b[0] = 0
+    a[1] = 2**56 - 1; b[1] = 2**56 - 1
+    a[2] = 2**56 + 255; b[2] = 2**56 + 255
+    a[3] = [1, 0, 0, 0, 0, 0, 0, 0]
+    a[4] = [2**56 - 1] * 4 + [2**56 - 2] + [2**56 - 1] * 3          # p itself
+    da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    out = torch.empty_like(da)
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    from _libs import Gf
+    def ser(limbs):
+        g = Gf(); g.limb[:] = [int(x) for x in limbs]
+        buf = (C.c_uint8 * 56)(); O.orc_gf_serialize(buf, C.byref(g)); return bytes(buf)
+    for op in (0, 1, 2, 3):
+        ga.dev("field_op", out.data_ptr(), st.data_ptr(), da.data_ptr(), db.data_ptr(), op, n, None)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(np.uint64)
+        status = st.cpu().numpy()
+        for i in list(range(8)) + list(range(8, n, 37)):
+            ga_, gb_, go = Gf(), Gf(), Gf()
+            ga_.limb[:] = [int(x) for x in a[i]]; gb_.limb[:] = [int(x) for x in b[i]]
+            if op == 0: O.orc_gf_mul(C.byref(go), C.byref(ga_), C.byref(gb_))
+            elif op == 1: O.orc_gf_sqr(C.byref(go), C.byref(ga_))
+            elif op == 2:
+                m = O.orc_gf_isr(C.byref(go), C.byref(ga_))
+                assert (m != 0) == (status[i] != 0), (op, i)
+            else:
+                go = ga_; O.orc_gf_strong_reduce(C.byref(go))
+                assert [int(x) for x in got[i]] == list(go.limb), ("strong", i)
+            assert ser(got[i]) == ser(go.limb), (op, i)
+
+
+def test_fixed_base_vs_oracle(ga, O):
+    n = 2048
+    s = _gen.random_scalars(n, b"t-fixed")
+    s[:len(EDGE_SCALARS)] = _gen.scalars_from_ints(EDGE_SCALARS)
+    got = enc(ga, ga.precomputed_scalarmul_batch(s))
+    want = _gen.oracle_encode(_gen.oracle_fixed(O, s))
+    assert (got == want).all()
+
+
+def test_variable_base_vs_oracle(ga, O):
+    n = 1024
+    s = _gen.random_scalars(n, b"t-var-s")
+    bases = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-var-b"))
+    s[:len(EDGE_SCALARS)] = _gen.scalars_from_ints(EDGE_SCALARS)
+    bases[20] = ga.point_identity()
+    bases[21] = ga.point_base()
+    got = ga.point_scalarmul_batch(bases, s)
+    want = _gen.oracle_varbase(O, bases, s)
+    assert (enc(ga, got) == _gen.oracle_encode(want)).all()
+    # outputs must be complete extended points (XY = ZT, on curve)
+    import torch
+    d = torch.from_numpy(got.view(np.int64)).cuda()
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    ga.dev("point_pred", st.data_ptr(), d.data_ptr(), None, 1, n, None)
+    assert (st.cpu().numpy() == -1).all()
+
+
+def test_ragged_and_empty_batches(ga, O):
+    assert ga.point_scalarmul_batch(np.empty((0, 32), np.uint64), np.empty((0, 7), np.uint64)).shape == (0, 32)
+    for n in (1, 63, 65, 257, 1000):
+        s = _gen.random_scalars(n, b"t-ragged%d" % n)
+        bases = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-ragged-b%d" % n))
+        got = enc(ga, ga.point_scalarmul_batch(bases, s))
+        assert (got == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all(), n
+
+
+def test_output_may_alias_input_single_op(ga, O):
+    s = _gen.random_scalars(1, b"t-alias")
+    base = _gen.oracle_fixed(O, _gen.random_scalars(1, b"t-alias-b"))
+    buf = base.copy()
+    ga.lib().goldilocks_448_point_scalarmul(buf.ctypes.data, buf.ctypes.data, s.ctypes.data)
+    assert (enc(ga, buf) == _gen.oracle_encode(_gen.oracle_varbase(O, base, s))).all()
+
+
+def test_double_scalarmul_vs_oracle(ga, O):
+    from _libs import Point, Scalar
+    n = 256
+    s1, s2 = _gen.random_scalars(n, b"t-d1"), _gen.random_scalars(n, b"t-d2")
+    b1 = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-db1"))
+    b2 = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-db2"))
+    got = enc(ga, ga.point_double_scalarmul_batch(b1, s1, b2, s2))
+    gotb = enc(ga, ga.point_double_scalarmul_batch(None, s1, b2, s2))
+    want = np.empty((n, 32), np.uint64); wantb = np.empty((n, 32), np.uint64)
+    for i in range(n):
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        O.orc_point_double_scalarmul(C.cast(p(want[i]), C.POINTER(Point)), C.cast(p(b1[i]), C.POINTER(Point)),
+                                     C.cast(p(s1[i]), C.POINTER(Scalar)), C.cast(p(b2[i]), C.POINTER(Point)),
+                                     C.cast(p(s2[i]), C.POINTER(Scalar)))
+        O.orc_base_double_scalarmul_non_secret(C.cast(p(wantb[i]), C.POINTER(Point)),
+                                               C.cast(p(s1[i]), C.POINTER(Scalar)),
+                                               C.cast(p(b2[i]), C.POINTER(Point)),
+                                               C.cast(p(s2[i]), C.POINTER(Scalar)))
+    assert (got == _gen.oracle_encode(want)).all()
+    assert (gotb == _gen.oracle_encode(wantb)).all()
+
+
+def test_decode_encode_and_rejects(ga, O):
+    from _libs import Point
+    n = 512
+    pts = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-enc"))
+    ser = enc(ga, pts)
+    assert (ser == _gen.oracle_encode(pts)).all()
+    dec, st = ga.point_decode_batch(ser)
+    assert (st == -1).all() and (enc(ga, dec) == ser).all()
+    # random strings: accept/reject must match the oracle
+    rnd = np.frombuffer(_gen.stream(b"t-dec-rnd", 56 * n), dtype=np.uint8).reshape(n, 56).copy()
+    rnd[0] = 0                       # identity encoding
+    rnd[1] = 0xff                    # >= p
+    rnd[2] = ser[2]; rnd[2, 0] |= 1  # "negative" s
+    _, st0 = ga.point_decode_batch(rnd, allow_identity=False)
+    _, st1 = ga.point_decode_batch(rnd, allow_identity=True)
+    for i in range(n):
+        p = Point()
+        buf = (C.c_uint8 * 56).from_buffer_copy(rnd[i].tobytes())
+        assert O.orc_point_decode(C.byref(p), buf, 0) == st0[i], i
+        assert O.orc_point_decode(C.byref(p), buf, 1) == st1[i], i
+    assert st0[0] == 0 and st1[0] == -1 and st0[1] == 0
+
+
+def test_eddsa_encode_decode(ga, O):
+    from _libs import Point
+    n = 256
+    pts = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-eddsa"))
+    e = ga.point_encode_like_eddsa_batch(pts)
+    for i in range(0, n, 5):
+        buf = (C.c_uint8 * 57)()
+        O.orc_point_encode_like_eddsa(buf, C.cast(pts[i].ctypes.data_as(C.c_void_p), C.POINTER(Point)))
+        assert bytes(buf) == e[i].tobytes()
+    dec, st = ga.point_decode_like_eddsa_batch(e)
+    assert (st == -1).all()
+    # decode(encode(P)) = 4P
+    four = _gen.oracle_varbase(O, pts, _gen.scalars_from_ints([4] * n))
+    assert (enc(ga, dec) == _gen.oracle_encode(four)).all()
+    bad = e.copy(); bad[:, 56] |= 0x01          # byte 56 must be 0x00 / 0x80
+    _, st = ga.point_decode_like_eddsa_batch(bad)
+    assert (st == 0).all()
+    rnd = np.frombuffer(_gen.stream(b"t-eddsa-rnd", 57 * n), dtype=np.uint8).reshape(n, 57).copy()
+    rnd[:, 56] &= 0x80
+    _, st = ga.point_decode_like_eddsa_batch(rnd)
+    for i in range(n):
+        p = Point()
+        assert O.orc_point_decode_like_eddsa(C.byref(p), (C.c_uint8 * 57).from_buffer_copy(rnd[i].tobytes())) == st[i]
+
+
+def test_group_ops(ga, O):
+    import torch
+    n = 256
+    a = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-ga"))
+    sa, sb = _gen.random_scalars(n, b"t-ga"), _gen.random_scalars(n, b"t-gb")
+    b = _gen.oracle_fixed(O, sb)
+    da, db = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(b.view(np.int64)).cuda()
+    out = torch.empty_like(da)
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    tot = lambda f: _gen.scalars_from_ints([f(int.from_bytes(x.tobytes(), "little"), int.from_bytes(y.tobytes(), "little"))
+                                            for x, y in zip(sa, sb)])
+    for op, f in ((0, lambda x, y: x + y), (1, lambda x, y: x - y), (2, lambda x, y: 2 * x)):
+        ga.dev("point_op", out.data_ptr(), da.data_ptr(), db.data_ptr(), op, n, None)
+        got = out.cpu().numpy().view(np.uint64)
+        assert (enc(ga, got) == _gen.oracle_encode(_gen.oracle_fixed(O, tot(f)))).all(), op
+    ga.dev("point_pred", st.data_ptr(), da.data_ptr(), da.data_ptr(), 0, n, None)
+    assert (st.cpu().numpy() == -1).all()
+    ga.dev("point_pred", st.data_ptr(), da.data_ptr(), db.data_ptr(), 0, n, None)
+    assert (st.cpu().numpy() == 0).all()
+    junk = a.copy(); junk[:, 3] ^= np.uint64(5)
+    dj = torch.from_numpy(junk.view(np.int64)).cuda()
+    ga.dev("point_pred", st.data_ptr(), dj.data_ptr(), None, 1, n, None)
+    assert (st.cpu().numpy() == 0).all()
+
+
+def test_precompute_matches_oracle_table(ga, O):
+    from _libs import Point, Precomputed
+    base = ga.point_base()
+    tab = ga.precompute(base)
+    assert (tab == ga.precomputed_base()).all()           # canonical limbs, bit for bit
+    pt = _gen.oracle_fixed(O, _gen.random_scalars(1, b"t-pre"))[0]
+    tab = ga.precompute(pt)
+    want = Precomputed()
+    O.orc_precompute(C.byref(want), C.cast(pt.ctypes.data_as(C.c_void_p), C.POINTER(Point)))
+    assert tab.tobytes() == bytes(want)
+    s = _gen.random_scalars(64, b"t-pre-s")
+    got = enc(ga, ga.precomputed_scalarmul_batch(s, table=tab))
+    assert (got == _gen.oracle_encode(_gen.oracle_varbase(O, np.tile(pt, (64, 1)), s))).all()
+
+
+def test_verify_vs_oracle(ga, O):
+    for msglen, ctx, ph in ((0, b"", False), (32, b"", False), (1, b"abc", False), (125, b"", False),
+                            (126, b"", False), (200, b"x" * 255, False), (64, b"ctx", True), (300, b"", False)):
+        n = 64
+        sigs, pks, msgs = _gen.signatures(O, n, msglen=msglen, seed=b"t-ver%d" % msglen, nkeys=8,
+                                          context=ctx, prehashed=ph)
+        # corruptions: R, S, pk, message; non-canonical encodings; S >= q
+        sigs[1, 3] ^= 0x10
+        sigs[2, 60] ^= 0x01
+        pks[3, 10] ^= 0x80
+        if msglen:
+            msgs[4] = bytes([msgs[4][0] ^ 1]) + msgs[4][1:]
+        sigs[5, 56] |= 0x01
+        pks[6, 56] |= 0x40
+        sigs[7, 0:57] = 0xff
+        s_val = int.from_bytes(sigs[8, 57:114].tobytes(), "little") + Q      # S + q: accepted after reduction
+        sigs[8, 57:114] = np.frombuffer(s_val.to_bytes(57, "little"), np.uint8)
+        got = ga.ed448_verify_batch(sigs, pks, msgs, prehashed=ph, context=ctx)
+        want = _gen.oracle_verify(O, sigs, pks, msgs, context=ctx, prehashed=ph)
+        assert (got == want).all(), (msglen, got, want)
+        assert got[0] == -1 and got[1] == 0 and got[2] == 0 and got[8] == -1
+
+
+def test_verify_single_and_class(ga, O):
+    sigs, pks, msgs = _gen.signatures(O, 2, msglen=17, seed=b"t-single")
+    assert ga.ed448_verify(sigs[0].tobytes(), pks[0].tobytes(), msgs[0])
+    assert not ga.ed448_verify(sigs[0].tobytes(), pks[0].tobytes(), msgs[1])
+    ga.EDDSA448(pks[1].tobytes()).verify(sigs[1].tobytes(), msgs[1])
+    with pytest.raises(ValueError):
+        ga.EDDSA448(pks[1].tobytes()).verify(sigs[0].tobytes(), msgs[1])
+
+
+def test_full_size_linearity(ga, O):
+    """Size-independent property at the benchmark batch (2^20): (s1+s2)*P == s1*P + s2*P, and a sample
+    of lanes against the oracle."""
+    import torch
+    n = 1 << 20
+    rng = np.random.default_rng(7)
+    k = 1 << 10
+    base_k = ga.precomputed_scalarmul_batch(_gen.random_scalars(k, b"t-full-b"))
+    bases = np.ascontiguousarray(base_k[rng.integers(0, k, n)])
+    s1 = _gen.random_scalars(k, b"t-full-1")[rng.integers(0, k, n)]
+    s2 = _gen.random_scalars(k, b"t-full-2")[rng.integers(0, k, n)]
+    ssum = _gen.scalars_from_ints([int.from_bytes(a.tobytes(), "little") + int.from_bytes(b.tobytes(), "little")
+                                   for a, b in zip(s1[:4096], s2[:4096])])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    db, d1, d2 = d(bases), d(s1), d(s2)
+    o1, o2 = torch.empty_like(db), torch.empty_like(db)
+    ga.dev("point_scalarmul", o1.data_ptr(), db.data_ptr(), d1.data_ptr(), n, None)
+    ga.dev("point_scalarmul", o2.data_ptr(), db.data_ptr(), d2.data_ptr(), n, None)
+    osum = torch.empty_like(db)
+    ga.dev("point_op", osum.data_ptr(), o1.data_ptr(), o2.data_ptr(), 0, n, None)
+    m = 4096
+    dsum = d(ssum)
+    o3 = torch.empty((m, 32), dtype=torch.int64, device="cuda")
+    ga.dev("point_scalarmul", o3.data_ptr(), db.data_ptr(), dsum.data_ptr(), m, None)
+    st = torch.empty(m, dtype=torch.int32, device="cuda")
+    ga.dev("point_pred", st.data_ptr(), o3.data_ptr(), osum.data_ptr(), 0, m, None)
+    assert (st.cpu().numpy() == -1).all()
+    # every output is a valid point
+    stv = torch.empty(n, dtype=torch.int32, device="cuda")
+    ga.dev("point_pred", stv.data_ptr(), o1.data_ptr(), None, 1, n, None)
+    assert int((stv == -1).sum()) == n
+    idx = rng.integers(0, n, 256)
+    got = o1.cpu().numpy().view(np.uint64)[idx]
+    assert (enc(ga, got) == _gen.oracle_encode(_gen.oracle_varbase(O, bases[idx], s1[idx]))).all()

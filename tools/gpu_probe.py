@@ -1,0 +1,39 @@
+"""First-contact probe for the GPU box: time the three batch kernels device-resident."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import libgoldilocks_amd as ga, _gen
+from _libs import oracle
+O = oracle()
+print(ga.device_info(), flush=True)
+d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+k = 1024
+sk = _gen.random_scalars(k, b"probe-s"); bk = ga.precomputed_scalarmul_batch(_gen.random_scalars(k, b"probe-b"))
+chk = ga.point_encode_batch(ga.point_scalarmul_batch(bk[:128], sk[:128]))
+assert (chk == _gen.oracle_encode(_gen.oracle_varbase(O, bk[:128], sk[:128]))).all(); print("parity ok", flush=True)
+rng = np.random.default_rng(0)
+def timeit(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+for logn in (14, 16, 17, 18, 20):
+    n = 1 << logn
+    bases = d(bk[rng.integers(0, k, n)]); scal = d(sk[rng.integers(0, k, n)]); out = torch.empty_like(bases)
+    ms = timeit(lambda: ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), scal.data_ptr(), n, None))
+    print("varbase  n=2^%d  %.2f ms  %.3f M/s" % (logn, ms, n / ms / 1e3), flush=True)
+    ms = timeit(lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scal.data_ptr(), n, None))
+    print("fixed    n=2^%d  %.2f ms  %.3f M/s" % (logn, ms, n / ms / 1e3), flush=True)
+sigs, pks, msgs = _gen.signatures(O, 4096, msglen=32, seed=b"probe-sig", nkeys=64)
+for logn in (14, 17, 20):
+    n = 1 << logn
+    idx = rng.integers(0, 4096, n)
+    ds, dp = torch.from_numpy(sigs[idx]).cuda(), torch.from_numpy(pks[idx]).cuda()
+    dm = torch.from_numpy(np.frombuffer(b"".join(msgs), np.uint8).reshape(4096, 32)[idx].copy()).cuda()
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    ms = timeit(lambda: ga.dev("ed448_verify", st.data_ptr(), ds.data_ptr(), dp.data_ptr(), dm.data_ptr(), None, 32, 0, None, 0, n, None))
+    assert int((st == -1).sum()) == n
+    print("verify   n=2^%d  %.2f ms  %.3f M/s" % (logn, ms, n / ms / 1e3), flush=True)
