@@ -95,6 +95,13 @@ def lib():
             raise ImportError(
                 "%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64; when torch is
+        # going to be used for device memory it must be the first to load it, otherwise the two
+        # runtimes fight over the device ("No HIP GPUs are available").  Plumbing only.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, sig) in FUNCTIONS.items():
             f = getattr(L, name)

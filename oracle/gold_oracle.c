@@ -1187,3 +1187,18 @@ void orc_ed448_derive_public_key_batch(uint8_t *pk, const uint8_t *sk, size_t n,
     (void)orc_point_base();
     run_ranges(pk_range, &a, n, nt);
 }
+
+/* Generic threaded driver: run fn(out[i], base[i], scalar[i]) over a batch.  bench.py's
+ * cpu_baseline leg passes the REAL reference's goldilocks_448_point_scalarmul (from
+ * oracle/_ref) here so that the reference itself is what gets timed on the host cores. */
+typedef void (*ext_scalarmul_fn)(void *out, const void *base, const void *scalar);
+struct ext_args { ext_scalarmul_fn fn; orc_point *out; const orc_point *base; const orc_scalar *s; };
+static void ext_range(void *a, size_t lo, size_t hi) {
+    struct ext_args *x = (struct ext_args *)a;
+    for (size_t i = lo; i < hi; i++) x->fn(&x->out[i], &x->base[i], &x->s[i]);
+}
+void orc_extern_scalarmul_batch(ext_scalarmul_fn fn, orc_point *out, const orc_point *base, const orc_scalar *s,
+                                size_t n, int nt) {
+    struct ext_args a = {fn, out, base, s};
+    run_ranges(ext_range, &a, n, nt);
+}

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libgoldilocks_ref64.so")
+REF_X86_SO = os.path.join(ORACLE_DIR, "_ref", "libgoldilocks_x86_64.so")
 
 P = 2**448 - 2**224 - 1
 Q = 2**446 - 0x8335DC163BB124B65129C96FDE933D8D723A70AADC873D6D54A7BB0D
@@ -125,6 +126,7 @@ def oracle():
         "orc_point_scalarmul_batch": (None, [vp, vp, vp, C.c_size_t, C.c_int]),
         "orc_precomputed_scalarmul_batch": (None, [vp, vp, vp, C.c_size_t, C.c_int]),
         "orc_point_encode_batch": (None, [vp, vp, C.c_size_t, C.c_int]),
+        "orc_extern_scalarmul_batch": (None, [vp, vp, vp, vp, C.c_size_t, C.c_int]),
         "orc_ed448_verify_batch": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8,
                                           C.c_size_t, C.c_int]),
         "orc_ed448_sign_batch": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8,
