@@ -28,6 +28,15 @@ def random_scalars(n, seed=b"scalars"):
     return out
 
 
+def stream_scalars(n, label):
+    """n scalars below 2^446 straight from the SHAKE256 stream (56 bytes each, top word masked to 62
+    bits; the chance of landing in [q, 2^446) is 2^-222).  This is the benchmark input stream
+    (labels bench_varbase_v1/<rank> ...), cheap enough for 2^20 and reproducible bit for bit."""
+    s = np.frombuffer(stream(label, 56 * n), dtype=np.uint64).reshape(n, 7).copy()
+    s[:, 6] &= np.uint64(2**62 - 1)
+    return s
+
+
 def scalars_from_ints(vals):
     out = np.empty((len(vals), 7), dtype=np.uint64)
     for i, v in enumerate(vals):

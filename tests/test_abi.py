@@ -1,0 +1,87 @@
+"""CPU tests of the drop-in boundary: the C-ABI shared library loads without a GPU and exports every
+symbol include/goldilocks_amd.h declares (no compute calls here)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "goldilocks_amd.h")
+
+
+def declared_symbols():
+    text = re.sub(r"/\*.*?\*/", "", open(HEADER).read(), flags=re.S)
+    funcs = re.findall(r"GOLDILOCKS_AMD_API\s+[\w\s\*]+?\b(goldilocks_\w+)\s*\(", text)
+    data = re.findall(r"GOLDILOCKS_AMD_API\s+extern\s+const\s+[\w\s\*]+?\b(goldilocks_\w+)\s*;", text)
+    return sorted(set(funcs)), sorted(set(data))
+
+
+@pytest.fixture(scope="module")
+def L():
+    import libgoldilocks_amd as ga
+    if not os.path.exists(ga.LIB_PATH):
+        import __graft_entry__ as g
+        g.build_lib()
+    return ga.lib()
+
+
+def test_header_and_binding_agree():
+    import libgoldilocks_amd as ga
+    funcs, data = declared_symbols()
+    assert len(funcs) >= 40 and len(data) == 7
+    assert sorted(ga.FUNCTIONS) == funcs
+    assert sorted(ga.DATA_SYMBOLS) == data
+
+
+def test_library_exports_every_declared_symbol(L):
+    funcs, data = declared_symbols()
+    for name in funcs:
+        assert getattr(L, name) is not None
+    for name in data:
+        C.c_char.in_dll(L, name)
+
+
+def test_exported_constants_match_the_reference(L):
+    import json
+    import numpy as np
+    import libgoldilocks_amd as ga
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "f5_constants.json")))
+    assert C.c_size_t.in_dll(L, "goldilocks_448_sizeof_precomputed_s").value == k["sizeof_precomputed_s"]
+    assert C.c_size_t.in_dll(L, "goldilocks_448_alignof_precomputed_s").value == k["alignof_precomputed_s"]
+    assert [int(x) for x in ga.point_base()] == k["point_base_limbs"]
+    import hashlib
+    assert hashlib.sha256(ga.precomputed_base().tobytes()).hexdigest() == k["precomputed_base_sha256"]
+    assert list(ga.point_identity()) == [0] * 8 + [1] + [0] * 7 + [1] + [0] * 7 + [0] * 8
+    one = (C.c_uint64 * 7).in_dll(L, "goldilocks_448_scalar_one")
+    assert list(one) == [1, 0, 0, 0, 0, 0, 0]
+
+
+def test_no_cpu_fallback_without_gpu(L):
+    """Without a device the library reports an error (batch API) -- it never computes on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import numpy as np
+    import libgoldilocks_amd as ga
+    with pytest.raises(ga.GoldilocksAmdError):
+        ga.point_scalarmul_batch(np.zeros((1, 32), np.uint64), np.zeros((1, 7), np.uint64))
+    assert b"hip" in L.goldilocks_amd_last_error().lower()
+
+
+def test_code_object_is_gfx950_only(L):
+    import libgoldilocks_amd as ga
+    out = subprocess.run(["strings", "-a", ga.LIB_PATH], capture_output=True, text=True).stdout
+    archs = set(re.findall(r"amdgcn-amd-amdhsa--(gfx\w+)", out))
+    assert archs == {"gfx950"}, archs
+
+
+def test_product_sources_do_not_reference_the_oracle():
+    pkg = os.path.join(ROOT, "libgoldilocks_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "gold_oracle" not in text and "liboracle" not in text and "hostsim" not in text.replace(
+                    "tests/hostsim", ""), f

@@ -280,3 +280,82 @@ def test_full_size_linearity(ga, O):
     idx = rng.integers(0, n, 256)
     got = o1.cpu().numpy().view(np.uint64)[idx]
     assert (enc(ga, got) == _gen.oracle_encode(_gen.oracle_varbase(O, bases[idx], s1[idx]))).all()
+
+
+# ----------------------------------------------------------------------------- golden fixtures / KATs
+
+import hashlib
+import json
+import os
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_golden_f1_variable_base(ga):
+    """BASELINE config 1: 1024 variable-base scalarmuls captured from the arch_ref64 build."""
+    d = np.load(os.path.join(GOLD, "f1_varbase.npz"))
+    bases, st = ga.point_decode_batch(d["base"], allow_identity=True)
+    assert (st == -1).all()
+    assert (enc(ga, ga.point_scalarmul_batch(bases, d["scalar"])) == d["out"]).all()
+
+
+def test_golden_f2_fixed_base(ga):
+    d = np.load(os.path.join(GOLD, "f2_fixed.npz"))
+    assert (enc(ga, ga.precomputed_scalarmul_batch(d["scalar"])) == d["out"]).all()
+    assert (enc(ga, ga.precomputed_scalarmul_batch(d["scalar2"], table=d["table"])) == d["out2"]).all()
+    pt, st = ga.point_decode_batch(d["point"].reshape(1, 56))
+    assert st[0] == -1
+    assert (enc(ga, ga.precomputed_scalarmul_batch(d["scalar2"], table=ga.precompute(pt[0]))) == d["out2"]).all()
+
+
+def test_golden_f3_verify(ga):
+    cases = json.load(open(os.path.join(GOLD, "f3_verify.json")))["cases"]
+    groups = {}
+    for c in cases:
+        groups.setdefault((c["ctx"], c["prehashed"]), []).append(c)
+    checked = 0
+    for (ctx, ph), cs in groups.items():
+        sigs = np.array([np.frombuffer(bytes.fromhex(c["sig"]), np.uint8) for c in cs])
+        pks = np.array([np.frombuffer(bytes.fromhex(c["pk"]), np.uint8) for c in cs])
+        msgs = [bytes.fromhex(c["msg"]) for c in cs]
+        got = ga.ed448_verify_batch(sigs, pks, msgs, prehashed=bool(ph), context=bytes.fromhex(ctx))
+        assert list(got) == [c["verdict"] for c in cs], [c["kind"] for c in cs]
+        checked += len(cs)
+    assert checked == 256
+
+
+def test_rfc8032_vectors_through_the_abi(ga):
+    kats = json.load(open(os.path.join(GOLD, "kats.json")))
+    for c in kats["rfc8032_ed448"]:
+        msg = bytes.fromhex(c["message"])
+        if c["prehashed"]:
+            msg = hashlib.shake_256(msg).digest(64)
+        ok = ga.ed448_verify(bytes.fromhex(c["sig"]), bytes.fromhex(c["pk"]), msg,
+                             context=bytes.fromhex(c["context"]), prehashed=c["prehashed"])
+        assert ok
+        assert not ga.ed448_verify(bytes.fromhex(c["sig"]), bytes.fromhex(c["pk"]), msg + b"x",
+                                   context=bytes.fromhex(c["context"]), prehashed=c["prehashed"])
+    # k*B for k < 16 (the reference's test_dalek_vectors)
+    want = np.array([np.frombuffer(bytes.fromhex(h), np.uint8) for h in kats["base_multiples"]])
+    ks = _gen.scalars_from_ints(list(range(16)))
+    assert (enc(ga, ga.precomputed_scalarmul_batch(ks)) == want).all()
+    assert (enc(ga, ga.point_scalarmul_batch(np.tile(ga.point_base(), (16, 1)), ks)) == want).all()
+
+
+def test_golden_f6_full_batch_digest(ga):
+    """The whole 2^20 benchmark batch, pinned by 32 bytes computed with the real reference."""
+    import torch
+    dig = json.load(open(os.path.join(GOLD, "f6_bench_digest.json")))["digest_shake256_32"]
+    n = 1 << 20
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    k = d(_gen.stream_scalars(n, b"bench_varbase_v1/0/base"))
+    s = d(_gen.stream_scalars(n, b"bench_varbase_v1/0/scalar"))
+    bases = torch.empty((n, 32), dtype=torch.int64, device="cuda")
+    out = torch.empty_like(bases)
+    ser = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+    ga.dev("precomputed_scalarmul", bases.data_ptr(), None, k.data_ptr(), n, None)
+    ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None)
+    ga.dev("point_encode", ser.data_ptr(), out.data_ptr(), n, None)
+    enc_all = ser.cpu().numpy()
+    for lg in (10, 16, 20):
+        assert hashlib.shake_256(enc_all[:1 << lg].tobytes()).hexdigest(32) == dig[str(lg)], lg

@@ -1,0 +1,117 @@
+"""CPU tests: the device lane arithmetic (libgoldilocks_amd/csrc/*.hpp) compiled for the host with
+the GF_CHECKED accumulator -- which traps on any 64-bit accumulator overflow and on violated
+subtraction-bias preconditions -- against the oracle.  This exercises the magnitude contract of
+gf28.hpp; it is a checker build, never a product path."""
+import ctypes as C
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+import _gen
+from _libs import Gf, Point, Scalar, P, Q, buf
+
+HS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+
+
+@pytest.fixture(scope="module")
+def H():
+    subprocess.check_call(["make", "-s", "-C", HS_DIR])
+    return C.CDLL(os.path.join(HS_DIR, "libhostsim.so"))
+
+
+def _ser(O, g):
+    b = (C.c_uint8 * 56)(); O.orc_gf_serialize(b, C.byref(g)); return bytes(b)
+
+
+def _enc(O, p):
+    b = (C.c_uint8 * 56)(); O.orc_point_encode(b, C.byref(p)); return bytes(b)
+
+
+def test_field_and_magnitude_contract(H, O):
+    rnd = random.Random(2)
+    allones = Gf()
+    for i in range(8):
+        allones.limb[i] = (1 << 56) - 1
+    cases = [Gf.from_int(rnd.getrandbits(448) % P) for _ in range(150)] + [allones, Gf.from_int(0), Gf.from_int(P - 1)]
+    for a in cases:
+        b = cases[rnd.randrange(len(cases))]
+        o1, o2 = Gf(), Gf()
+        O.orc_gf_mul(C.byref(o1), C.byref(a), C.byref(b)); H.hs_fe_mul(C.byref(o2), C.byref(a), C.byref(b))
+        assert _ser(O, o1) == _ser(O, o2)
+        O.orc_gf_sqr(C.byref(o1), C.byref(a)); H.hs_fe_sqr(C.byref(o2), C.byref(a))
+        assert _ser(O, o1) == _ser(O, o2)
+        w = rnd.getrandbits(18)
+        O.orc_gf_mulw(C.byref(o1), C.byref(a), w); H.hs_fe_mulw(C.byref(o2), C.byref(a), w)
+        assert _ser(O, o1) == _ser(O, o2)
+        for ma, mb in ((2, 2), (5, 1), (1, 5), (4, 1), (3, 1), (1, 4)):      # documented magnitude limits
+            H.hs_fe_mul_mag(C.byref(o2), C.byref(a), C.byref(b), ma, mb)
+            assert o2.value() == a.value() * b.value() * ma * mb % P
+        H.hs_fe_sqr_mag(C.byref(o2), C.byref(a), 2)
+        assert o2.value() == 4 * a.value() ** 2 % P
+    H.hs_fe_isr.restype = C.c_int
+    for a in cases[:12]:
+        o1, o2 = Gf(), Gf()
+        m1 = O.orc_gf_isr(C.byref(o1), C.byref(a)); m2 = H.hs_fe_isr(C.byref(o2), C.byref(a))
+        assert (m1 != 0) == (m2 != 0) and _ser(O, o1) == _ser(O, o2)
+        bs = (C.c_uint8 * 56)(); H.hs_fe_serialize(bs, C.byref(a)); assert bytes(bs) == _ser(O, a)
+
+
+def test_scalars(H, O):
+    rnd = random.Random(3)
+    for it in range(100):
+        a, b = Scalar.from_int(rnd.getrandbits(446) % Q), Scalar.from_int(rnd.getrandbits(446) % Q)
+        o1, o2 = Scalar(), Scalar()
+        O.orc_scalar_mul(C.byref(o1), C.byref(a), C.byref(b)); H.hs_sc_mul(C.byref(o2), C.byref(a), C.byref(b))
+        assert bytes(o1) == bytes(o2)
+        O.orc_scalar_sub(C.byref(o1), C.byref(a), C.byref(b)); H.hs_sc_sub(C.byref(o2), C.byref(a), C.byref(b))
+        assert bytes(o1) == bytes(o2)
+        for n in (57, 72, 114):
+            x = bytes(rnd.getrandbits(8) for _ in range(n)) if it else b"\xff" * n
+            O.orc_scalar_decode_long(C.byref(o1), buf(x), n); H.hs_sc_decode_long(C.byref(o2), buf(x), C.c_size_t(n))
+            assert bytes(o1) == bytes(o2)
+
+
+def test_ladders_and_codecs(H, O):
+    rnd = random.Random(4)
+    edge = [0, 1, Q - 1, 2**445]
+    for it in range(24):
+        k = Scalar.from_int(rnd.getrandbits(446) % Q)
+        pt = Point(); O.orc_precomputed_scalarmul(C.byref(pt), O.orc_precomputed_base(), C.byref(k))
+        s = Scalar.from_int(edge[it] if it < len(edge) else rnd.getrandbits(446) % Q)
+        a, b = Point(), Point()
+        O.orc_point_scalarmul(C.byref(a), C.byref(pt), C.byref(s)); H.hs_point_scalarmul(C.byref(b), C.byref(pt), C.byref(s))
+        assert _enc(O, a) == _enc(O, b) and H.hs_point_valid(C.byref(b)) == -1
+        O.orc_precomputed_scalarmul(C.byref(a), O.orc_precomputed_base(), C.byref(s))
+        H.hs_precomputed_scalarmul(C.byref(b), O.orc_precomputed_base(), C.byref(s))
+        assert _enc(O, a) == _enc(O, b)
+        e = (C.c_uint8 * 56)(); H.hs_point_encode(e, C.byref(a)); assert bytes(e) == _enc(O, a)
+        d = Point(); assert H.hs_point_decode(C.byref(d), e, 1) == -1 and _enc(O, d) == bytes(e)
+        e2, e3 = (C.c_uint8 * 57)(), (C.c_uint8 * 57)()
+        O.orc_point_encode_like_eddsa(e2, C.byref(a)); H.hs_point_encode_eddsa(e3, C.byref(a))
+        assert bytes(e2) == bytes(e3)
+        d2 = Point()
+        assert O.orc_point_decode_like_eddsa(C.byref(d2), e2) == H.hs_point_decode_eddsa(C.byref(d), e2)
+        t = Scalar.from_int(rnd.getrandbits(446) % Q)
+        O.orc_point_double_scalarmul(C.byref(a), C.byref(pt), C.byref(s), C.byref(d2), C.byref(t))
+        H.hs_point_double_scalarmul(C.byref(b), C.byref(pt), C.byref(s), C.byref(d2), C.byref(t))
+        assert _enc(O, a) == _enc(O, b)
+
+
+def test_verify(H, O):
+    base = O.orc_point_base().contents
+    rnd = random.Random(5)
+    for it, mlen in enumerate((0, 1, 32, 125, 126, 136, 300)):
+        ctx = bytes(rnd.getrandbits(8) for _ in range((0, 3, 255)[it % 3]))
+        sigs, pks, msgs = _gen.signatures(O, 2, msglen=mlen, seed=b"hs%d" % it, context=ctx, prehashed=bool(it & 1))
+        for j in range(2):
+            sig = bytearray(sigs[j].tobytes())
+            if j: sig[rnd.randrange(114)] ^= 1 << rnd.randrange(8)
+            m = buf(msgs[j]) if msgs[j] else None
+            c = buf(ctx) if ctx else None
+            want = O.orc_ed448_verify(buf(sig), buf(pks[j].tobytes()), m, mlen, it & 1, c, len(ctx))
+            got = H.hs_ed448_verify(buf(sig), buf(pks[j].tobytes()), m, C.c_size_t(mlen), C.c_uint8(it & 1), c,
+                                    C.c_uint8(len(ctx)), C.byref(base))
+            assert got == want and (j or got == -1)

@@ -1,0 +1,82 @@
+"""CPU tests, build container only: live differential run of the oracle against the REAL reference
+(oracle/_ref, arch_ref64).  Raw limbs must agree, not just encodings.  Skipped where the reference
+build is absent (the GPU box has the prebuilt .so; a bare checkout has not)."""
+import ctypes as C
+import random
+
+import pytest
+
+from _libs import Point, Scalar, buf, have_ref, ref
+
+pytestmark = pytest.mark.skipif(not have_ref(), reason="oracle/_ref not built (make -C oracle ref)")
+
+
+def test_tables_identical(O):
+    R = ref()
+    assert bytes(O.orc_point_base().contents) == bytes(R.point_base)
+    assert bytes(O.orc_precomputed_base().contents) == C.string_at(R.precomputed_base.value, 15360)
+
+
+def test_differential(O):
+    R = ref()
+    rnd = random.Random(11)
+    rb = lambda n: bytes(rnd.getrandbits(8) for _ in range(n))
+    for it in range(60):
+        p1, p2, s, t, s2 = Point(), Point(), Scalar(), Scalar(), Scalar()
+        R.goldilocks_448_point_from_hash_uniform(C.byref(p1), buf(rb(112)))
+        R.goldilocks_448_point_from_hash_uniform(C.byref(p2), buf(rb(112)))
+        raw = rb(72)
+        R.goldilocks_448_scalar_decode_long(C.byref(s), buf(raw), 72)
+        O.orc_scalar_decode_long(C.byref(s2), buf(raw), 72)
+        assert bytes(s) == bytes(s2)
+        R.goldilocks_448_scalar_decode_long(C.byref(t), buf(rb(72)), 72)
+        a, b = Point(), Point()
+        R.goldilocks_448_point_scalarmul(C.byref(a), C.byref(p1), C.byref(s))
+        O.orc_point_scalarmul(C.byref(b), C.byref(p1), C.byref(s))
+        assert bytes(a) == bytes(b)
+        R.goldilocks_448_precomputed_scalarmul(C.byref(a), R.precomputed_base, C.byref(s))
+        O.orc_precomputed_scalarmul(C.byref(b), O.orc_precomputed_base(), C.byref(s))
+        assert bytes(a) == bytes(b)
+        R.goldilocks_448_point_double_scalarmul(C.byref(a), C.byref(p1), C.byref(s), C.byref(p2), C.byref(t))
+        O.orc_point_double_scalarmul(C.byref(b), C.byref(p1), C.byref(s), C.byref(p2), C.byref(t))
+        assert bytes(a) == bytes(b)
+        R.goldilocks_448_base_double_scalarmul_non_secret(C.byref(a), C.byref(s), C.byref(p2), C.byref(t))
+        O.orc_base_double_scalarmul_non_secret(C.byref(b), C.byref(s), C.byref(p2), C.byref(t))
+        assert bytes(a) == bytes(b)
+        e1, e2 = (C.c_uint8 * 56)(), (C.c_uint8 * 56)()
+        R.goldilocks_448_point_encode(e1, C.byref(a)); O.orc_point_encode(e2, C.byref(a))
+        assert bytes(e1) == bytes(e2)
+        d1, d2 = Point(), Point()
+        assert R.goldilocks_448_point_decode(C.byref(d1), e1, 0) == O.orc_point_decode(C.byref(d2), e1, 0) == -1
+        assert bytes(d1) == bytes(d2)
+        g = rb(56)
+        assert R.goldilocks_448_point_decode(C.byref(d1), buf(g), 0) == O.orc_point_decode(C.byref(d2), buf(g), 0)
+        f1, f2 = (C.c_uint8 * 57)(), (C.c_uint8 * 57)()
+        R.goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa(f1, C.byref(a)); O.orc_point_encode_like_eddsa(f2, C.byref(a))
+        assert bytes(f1) == bytes(f2)
+        r1 = R.goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio(C.byref(d1), f1)
+        assert r1 == O.orc_point_decode_like_eddsa(C.byref(d2), f1) and bytes(d1) == bytes(d2)
+        sk, msg, ctx = rb(57), rb(it * 3), rb(it % 7)
+        pk1, pk2, s1, s2_ = (C.c_uint8 * 57)(), (C.c_uint8 * 57)(), (C.c_uint8 * 114)(), (C.c_uint8 * 114)()
+        R.goldilocks_ed448_derive_public_key(pk1, buf(sk)); O.orc_ed448_derive_public_key(pk2, buf(sk))
+        assert bytes(pk1) == bytes(pk2)
+        m, c = (buf(msg) if msg else None), (buf(ctx) if ctx else None)
+        R.goldilocks_ed448_sign(s1, buf(sk), pk1, m, len(msg), it & 1, c, len(ctx))
+        O.orc_ed448_sign(s2_, buf(sk), pk1, m, len(msg), it & 1, c, len(ctx))
+        assert bytes(s1) == bytes(s2_)
+        assert R.goldilocks_ed448_verify(s1, pk1, m, len(msg), it & 1, c, len(ctx)) == -1
+        assert O.orc_ed448_verify(s1, pk1, m, len(msg), it & 1, c, len(ctx)) == -1
+        bad = bytearray(s1); bad[rnd.randrange(114)] ^= 1 << rnd.randrange(8)
+        assert R.goldilocks_ed448_verify(buf(bad), pk1, m, len(msg), it & 1, c, len(ctx)) == \
+            O.orc_ed448_verify(buf(bad), pk1, m, len(msg), it & 1, c, len(ctx))
+
+
+def test_precompute_matches_reference(O):
+    from _libs import Precomputed
+    R = ref()
+    p = Point()
+    R.goldilocks_448_point_from_hash_uniform(C.byref(p), buf(bytes(range(112))))
+    t1, t2 = (C.c_uint8 * 15360)(), Precomputed()
+    R.goldilocks_448_precompute(t1, C.byref(p))
+    O.orc_precompute(C.byref(t2), C.byref(p))
+    assert bytes(t1) == bytes(t2)
