@@ -21,7 +21,10 @@
 namespace gd {
 
 constexpr int BLOCK = 256;          // 4 waves: one per SIMD
-constexpr int WAVES_PER_SIMD = 2;   // 2 blocks per CU -> 256-VGPR budget per lane
+#ifndef GD_WAVES_PER_SIMD
+#define GD_WAVES_PER_SIMD 2
+#endif
+constexpr int WAVES_PER_SIMD = GD_WAVES_PER_SIMD;   // 2 blocks per CU -> 256-VGPR budget per lane
 constexpr int TABLE_U4 = 256;       // uint4 per lane window table (16 entries x 4 fe x 4 uint4)
 constexpr int PRECOMP_U4 = 80 * 20 + 64;  // uint4 per lane for k_precompute: 80 x 5 fe + 4 doubled teeth
 
@@ -139,6 +142,46 @@ struct SharedComb {  // 80 affine niels, 12 uint4 each, our limb/sign convention
         return e;
     }
 };
+// The comb staged in LDS and gathered with wavefront shuffles.  Entry e occupies words
+// [49e, 49e+48) (stride 49 keeps the fill reads below conflict-free).  For comb j every lane
+// first reads 12 words with a LANE-dependent, index-INDEPENDENT address: lane l takes words
+// 4q + (l>>4), q < 12, of entry 16j + (l&15), so the wave's registers hold the whole 16-entry
+// sub-table once.  Word 4q+c of the entry a lane wants then comes from lane idx + 16c through
+// ds_bpermute_b32: the crossbar has no bank conflicts, so neither the addresses issued nor the
+// time taken depend on the (possibly secret) digit.
+constexpr int COMB_LDS_STRIDE = 49;
+constexpr int COMB_LDS_WORDS = 80 * COMB_LDS_STRIDE;
+struct LdsShuffleComb {
+    const uint32_t *lds;
+    uint32_t lane;  // lane within the wave
+    __device__ __forceinline__ niels load(int j, uint32_t idx) const {
+        const uint32_t *src = lds + (16 * j + (lane & 15)) * COMB_LDS_STRIDE + (lane >> 4);
+        uint32_t r[12];
+#pragma unroll
+        for (int q = 0; q < 12; q++) r[q] = src[4 * q];
+        const int a0 = (int)(idx << 2);  // bpermute takes a byte address: 4 * source lane
+        niels e;
+        uint32_t w[48];
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) w[4 * q + c] = (uint32_t)__builtin_amdgcn_ds_bpermute(a0 + 64 * c, (int)r[q]);
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            e.a.v[i] = w[i];
+            e.b.v[i] = w[16 + i];
+            e.cn.v[i] = w[32 + i];
+        }
+        return e;
+    }
+};
+__device__ __forceinline__ void stage_comb_lds(uint32_t *lds, const uint4 *comb) {
+    const uint32_t *g = reinterpret_cast<const uint32_t *>(comb);
+    for (int i = threadIdx.x; i < 80 * 48; i += BLOCK) lds[(i / 48) * COMB_LDS_STRIDE + (i % 48)] = g[i];
+    __syncthreads();
+}
+
 struct LdsStage {  // 136-byte sponge block per lane, word-interleaved across lanes
     uint32_t *p;   // &stage[threadIdx.x]
     __device__ __forceinline__ void put(uint32_t i, uint32_t b) const {
@@ -179,13 +222,20 @@ GD_KERNEL k_point_scalarmul(uint64_t *__restrict__ out, const uint64_t *__restri
 GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ comb,
                                   const uint64_t *__restrict__ scalar, uint32_t n) {
     __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint32_t s_comb[COMB_LDS_WORDS];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
-    SharedComb tab{comb};
-    for (uint32_t i = lane; i < n; i += stride) {
+    stage_comb_lds(s_comb, comb);
+    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
+    // every lane of a wave must take part in the shuffles: iterate wave-uniformly and clamp
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i_raw = lane + r * stride;
+        const bool live = i_raw < n;
+        const uint32_t i = live ? i_raw : n - 1;
         LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(scalar + 7 * (size_t)i)));
-        pt r = ladder_comb(bits, tab);
-        pt_store_abi(out + 32 * (size_t)i, r);
+        pt res = ladder_comb(bits, tab);
+        if (live) pt_store_abi(out + 32 * (size_t)i, res);
     }
 }
 
