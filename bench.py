@@ -15,7 +15,8 @@ Extra objects on the line:
                 56 B scalar in, 256 B point out) / average launch duration measured
                 with HIP events on the launch stream, against 8 TB/s.  The path is integer-VALU
                 bound, so this fraction is tiny by construction; "valu" carries the honest
-                ceiling (achieved 32x32->64 MAC/s vs the measured v_mad_u64_u32 peak).
+                ceiling: achieved VALU wave-instructions/s vs the measured issue peak of the
+                ladder's instruction mix, and 32x32->64 MAC/s vs the measured v_mad_u64_u32 peak.
   cpu_baseline  the REAL reference (arch_x86_64 path, oracle/_ref, built for generic x86-64) --
                 or the oracle port if that .so did not travel -- timed on the host cores over a
                 bounded sample of the same workload.
@@ -35,7 +36,9 @@ LOG2_BATCH = 20
 BYTES_PER_OP = 568          # algorithmic: 256 (point in) + 56 (scalar in) + 256 (point out)
 MACS_PER_OP = 630_604       # 2279 M x 192 + 1785 S x 108 + 16 mulw x 16 MACs per op
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_MAC_PEAK = 34.0e12     # measured: 531 G v_mad_u64_u32 wave-instr/s x 64 lanes (profiles/r01/ubench.txt)
+VALU_MAC_PEAK = 36.0e12     # measured: 560-576 G v_mad_u64_u32 wave-instr/s x 64 lanes (profiles/r01/ubench.txt)
+VALU_INSTR_PER_OP = 1.215e6 # VALU instructions per op and lane (ISA histogram x trip counts)
+VALU_ISSUE_PEAK = 600e9     # measured: wave-instr/s of a 1:1 MAC:simple mix at 2+ waves/SIMD (ubench mix_mac_add)
 
 
 def parse():
@@ -219,8 +222,12 @@ def main():
         }
         if args.workload == "varbase":
             macs = MACS_PER_OP * n / (avg_ms * 1e-3)
-            line["valu"] = {"bound": "v_mad_u64_u32 issue", "achieved": macs / 1e12, "peak": VALU_MAC_PEAK / 1e12,
-                            "unit": "T MAC/s", "frac": macs / VALU_MAC_PEAK}
+            issue = VALU_INSTR_PER_OP * n / 64 / (avg_ms * 1e-3)
+            line["valu"] = {"bound": "VALU issue (every VALU op costs ~4 SIMD-cycles once interleaved with MACs)",
+                            "achieved": issue / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s",
+                            "frac": issue / VALU_ISSUE_PEAK,
+                            "mac": {"achieved": macs / 1e12, "peak": VALU_MAC_PEAK / 1e12, "unit": "T MAC/s",
+                                    "frac": macs / VALU_MAC_PEAK}}
         line.update(extra)
         print(json.dumps(line), flush=True)
         if not ok:

@@ -3,8 +3,9 @@
 // The Ed448 ladder is VALU-bound on 32x32->64 multiply-accumulates, not HBM- or MFMA-bound
 // (SURVEY.md section 8d), so the honest ceiling is the measured issue rate of
 // v_mad_u64_u32 and of the carry-handling instructions around it.  This tool measures,
-// per instruction, SIMD cycles per wave-instruction at 1/2/4 waves per SIMD with 1 or 8
-// independent dependency chains, from s_memtime and from wall clock.
+// per instruction, SIMD cycles per wave-instruction at 1/2/4/8 waves per SIMD with 1 or 8
+// independent dependency chains, from wall clock (nominal 2.4 GHz) -- plus three instruction
+// mixes shaped like the ladder's inner loops.
 //
 //   hipcc -O3 --offload-arch=gfx950 -o ubench ubench.hip && ./ubench
 #include <hip/hip_runtime.h>
@@ -23,74 +24,90 @@
     } while (0)
 
 constexpr int ITERS = 2048;
-constexpr int UNROLL = 32;  // instructions per loop iteration
+constexpr int UNROLL = 32;  // instructions per loop iteration (REPT x 8)
 
-// Each kernel: K independent chains, UNROLL instructions per iteration round-robin over chains.
-#define DEF_KERNEL64(NAME, ASM)                                                                    \
+// Each kernel: one asm statement per loop iteration (hipcc pads every asm statement with an
+// s_nop, which would steal issue slots), containing REPT x 8 instructions on 8 independent
+// registers (K = 8) or on one register (K = 1, a dependent chain).
+#define REPT 4  // 4 x 8 = 32 instructions per iteration
+#define STR2(x) #x
+#define STR(x) STR2(x)
+
+#define DEF_KERNEL(NAME, TYPE, I0, I1, I2, I3, I4, I5, I6, I7)                                     \
     template <int K>                                                                               \
     __global__ void __launch_bounds__(256) NAME(uint64_t *out, uint32_t a0, uint32_t b0,           \
                                                 unsigned long long *cyc) {                         \
-        uint64_t acc[8];                                                                           \
+        TYPE r0, r1, r2, r3, r4, r5, r6, r7;                                                       \
         uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x;                                       \
-        for (int i = 0; i < 8; i++) acc[i] = a * (i + 1);                                          \
+        r0 = a; r1 = a * 2; r2 = a * 3; r3 = a * 4; r4 = a * 5; r5 = a * 6; r6 = a * 7; r7 = a * 8; \
         unsigned long long t0 = __builtin_readcyclecounter();                                      \
         for (int it = 0; it < ITERS; it++) {                                                       \
-            _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {                                   \
-                asm volatile(ASM : "+v"(acc[u % K]) : "v"(a), "v"(b) : "vcc");                     \
-            }                                                                                      \
+            if (K == 8)                                                                            \
+                asm volatile(".rept " STR(REPT) "\n" I0 "\n" I1 "\n" I2 "\n" I3 "\n" I4 "\n" I5 "\n" I6 "\n" I7 "\n.endr" \
+                             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) \
+                             : "v"(a), "v"(b) : "vcc");                                            \
+            else                                                                                   \
+                asm volatile(".rept " STR(REPT) "\n" I0 "\n" I0 "\n" I0 "\n" I0 "\n" I0 "\n" I0 "\n" I0 "\n" I0 "\n.endr" \
+                             : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) \
+                             : "v"(a), "v"(b) : "vcc");                                            \
         }                                                                                          \
         unsigned long long t1 = __builtin_readcyclecounter();                                      \
-        uint64_t r = 0;                                                                            \
-        for (int i = 0; i < 8; i++) r ^= acc[i];                                                   \
+        uint64_t r = (uint64_t)r0 ^ (uint64_t)r1 ^ (uint64_t)r2 ^ (uint64_t)r3 ^ (uint64_t)r4 ^ (uint64_t)r5 ^ \
+                     (uint64_t)r6 ^ (uint64_t)r7;                                                  \
         out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                            \
         if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                           \
     }
+// same instruction on 8 registers; operands: %0..%7 accumulators, %8 = a, %9 = b
+#define ALL8(NAME, TYPE, PRE, POST)                                                                \
+    DEF_KERNEL(NAME, TYPE, PRE "%0" POST("%0"), PRE "%1" POST("%1"), PRE "%2" POST("%2"), PRE "%3" POST("%3"), \
+               PRE "%4" POST("%4"), PRE "%5" POST("%5"), PRE "%6" POST("%6"), PRE "%7" POST("%7"))
 
-#define DEF_KERNEL32(NAME, ASM)                                                                    \
-    template <int K>                                                                               \
-    __global__ void __launch_bounds__(256) NAME(uint64_t *out, uint32_t a0, uint32_t b0,           \
-                                                unsigned long long *cyc) {                         \
-        uint32_t acc[8];                                                                           \
-        uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x;                                       \
-        for (int i = 0; i < 8; i++) acc[i] = a * (i + 1);                                          \
-        unsigned long long t0 = __builtin_readcyclecounter();                                      \
-        for (int it = 0; it < ITERS; it++) {                                                       \
-            _Pragma("unroll") for (int u = 0; u < UNROLL; u++) {                                   \
-                asm volatile(ASM : "+v"(acc[u % K]) : "v"(a), "v"(b) : "vcc");                     \
-            }                                                                                      \
-        }                                                                                          \
-        unsigned long long t1 = __builtin_readcyclecounter();                                      \
-        uint64_t r = 0;                                                                            \
-        for (int i = 0; i < 8; i++) r ^= acc[i];                                                   \
-        out[blockIdx.x * blockDim.x + threadIdx.x] = r;                                            \
-        if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                           \
-    }
+#define P_MAD(r) ", vcc, %8, %9, " r
+#define P_AB_ACC(r) ", %8, %9, " r
+#define P_A_ACC(r) ", %8, " r
+#define P_ACC_ONLY1(r) ", 1, " r
+#define P_LSHLADD(r) ", " r ", 0, " r
+#define P_FMA(r) ", " r ", " r ", " r
+#define P_ALIGN(r) ", %8, " r ", 28"
+#define P_ANDOR(r) ", " r ", %8, %9"
+#define P_BFE(r) ", " r ", 4, 28"
+#define P_ADDC(r) ", vcc, %8, " r ", vcc"
+#define P_ADDCO(r) ", vcc, %8, " r
+#define P_MOV(r) ", %8"
 
-DEF_KERNEL64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
-DEF_KERNEL64(k_mad_i64_i32, "v_mad_i64_i32 %0, vcc, %1, %2, %0")
-DEF_KERNEL64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 0, %0")
-DEF_KERNEL64(k_lshrrev_b64, "v_lshrrev_b64 %0, 1, %0")
-DEF_KERNEL64(k_fma_f64, "v_fma_f64 %0, %0, %0, %0")
-DEF_KERNEL64(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %0, %0")
-DEF_KERNEL32(k_mul_lo_u32, "v_mul_lo_u32 %0, %1, %0")
-DEF_KERNEL32(k_mul_hi_u32, "v_mul_hi_u32 %0, %1, %0")
-DEF_KERNEL32(k_mad_u32_u24, "v_mad_u32_u24 %0, %1, %2, %0")
-DEF_KERNEL32(k_mul_u32_u24, "v_mul_u32_u24_e32 %0, %1, %0")
-DEF_KERNEL32(k_mul_hi_u32_u24, "v_mul_hi_u32_u24_e32 %0, %1, %0")
-DEF_KERNEL32(k_add_u32, "v_add_u32_e32 %0, %1, %0")
-DEF_KERNEL32(k_add3_u32, "v_add3_u32 %0, %1, %2, %0")
-DEF_KERNEL32(k_and_b32, "v_and_b32_e32 %0, %1, %0")
-DEF_KERNEL32(k_and_or_b32, "v_and_or_b32 %0, %0, %1, %2")
-DEF_KERNEL32(k_lshrrev_b32, "v_lshrrev_b32_e32 %0, 1, %0")
-DEF_KERNEL32(k_alignbit_b32, "v_alignbit_b32 %0, %1, %0, 28")
-DEF_KERNEL32(k_add_co_u32, "v_add_co_u32_e32 %0, vcc, %1, %0")
-DEF_KERNEL32(k_addc_co_u32, "v_addc_co_u32_e32 %0, vcc, %1, %0, vcc")
-DEF_KERNEL32(k_cndmask_b32, "v_cndmask_b32_e32 %0, %1, %0, vcc")
-DEF_KERNEL32(k_fma_f32, "v_fma_f32 %0, %0, %0, %0")
-DEF_KERNEL32(k_mad_u16, "v_mad_u16 %0, %1, %2, %0")
-DEF_KERNEL32(k_dot4_u32_u8, "v_dot4_u32_u8 %0, %1, %2, %0")
-DEF_KERNEL32(k_bfe_u32, "v_bfe_u32 %0, %0, 4, 28")
-DEF_KERNEL32(k_mov_b32, "v_mov_b32_e32 %0, %1")
+ALL8(k_mad_u64_u32, uint64_t, "v_mad_u64_u32 ", P_MAD)
+ALL8(k_mad_i64_i32, uint64_t, "v_mad_i64_i32 ", P_MAD)
+ALL8(k_lshl_add_u64, uint64_t, "v_lshl_add_u64 ", P_LSHLADD)
+ALL8(k_lshrrev_b64, uint64_t, "v_lshrrev_b64 ", P_ACC_ONLY1)
+ALL8(k_fma_f64, uint64_t, "v_fma_f64 ", P_FMA)
+ALL8(k_pk_fma_f32, uint64_t, "v_pk_fma_f32 ", P_FMA)
+ALL8(k_mul_lo_u32, uint32_t, "v_mul_lo_u32 ", P_A_ACC)
+ALL8(k_mul_hi_u32, uint32_t, "v_mul_hi_u32 ", P_A_ACC)
+ALL8(k_mad_u32_u24, uint32_t, "v_mad_u32_u24 ", P_AB_ACC)
+ALL8(k_mul_u32_u24, uint32_t, "v_mul_u32_u24_e32 ", P_A_ACC)
+ALL8(k_add_u32, uint32_t, "v_add_u32_e32 ", P_A_ACC)
+ALL8(k_sub_u32, uint32_t, "v_sub_u32_e32 ", P_A_ACC)
+ALL8(k_add3_u32, uint32_t, "v_add3_u32 ", P_AB_ACC)
+ALL8(k_and_b32, uint32_t, "v_and_b32_e32 ", P_A_ACC)
+ALL8(k_and_or_b32, uint32_t, "v_and_or_b32 ", P_ANDOR)
+ALL8(k_lshrrev_b32, uint32_t, "v_lshrrev_b32_e32 ", P_ACC_ONLY1)
+ALL8(k_alignbit_b32, uint32_t, "v_alignbit_b32 ", P_ALIGN)
+ALL8(k_bfe_u32, uint32_t, "v_bfe_u32 ", P_BFE)
+ALL8(k_add_co_u32, uint32_t, "v_add_co_u32_e32 ", P_ADDCO)
+ALL8(k_addc_co_u32, uint32_t, "v_addc_co_u32_e32 ", P_ADDC)
+ALL8(k_fma_f32, uint32_t, "v_fma_f32 ", P_FMA)
+ALL8(k_mov_b32, uint32_t, "v_mov_b32_e32 ", P_MOV)
+
+// instruction mixes of the Ed448 ladder: MAC:simple = 1:1 and the doubling's measured histogram
+DEF_KERNEL(k_mix_mac_add, uint64_t, "v_mad_u64_u32 %0, vcc, %8, %9, %0", "v_add_u32_e32 %8, %9, %8",
+           "v_mad_u64_u32 %1, vcc, %8, %9, %1", "v_and_b32_e32 %9, %8, %9", "v_mad_u64_u32 %2, vcc, %8, %9, %2",
+           "v_add_u32_e32 %8, %9, %8", "v_mad_u64_u32 %3, vcc, %8, %9, %3", "v_and_b32_e32 %9, %8, %9")
+DEF_KERNEL(k_mix_mac3_add, uint64_t, "v_mad_u64_u32 %0, vcc, %8, %9, %0", "v_mad_u64_u32 %1, vcc, %8, %9, %1",
+           "v_mad_u64_u32 %2, vcc, %8, %9, %2", "v_add_u32_e32 %8, %9, %8", "v_mad_u64_u32 %3, vcc, %8, %9, %3",
+           "v_mad_u64_u32 %4, vcc, %8, %9, %4", "v_mad_u64_u32 %5, vcc, %8, %9, %5", "v_and_b32_e32 %9, %8, %9")
+DEF_KERNEL(k_mix_mac_lshladd, uint64_t, "v_mad_u64_u32 %0, vcc, %8, %9, %0", "v_lshl_add_u64 %4, %4, 0, %5",
+           "v_mad_u64_u32 %1, vcc, %8, %9, %1", "v_lshl_add_u64 %5, %5, 0, %6", "v_mad_u64_u32 %2, vcc, %8, %9, %2",
+           "v_lshl_add_u64 %6, %6, 0, %7", "v_mad_u64_u32 %3, vcc, %8, %9, %3", "v_lshl_add_u64 %7, %7, 0, %4")
 
 typedef void (*kern_t)(uint64_t *, uint32_t, uint32_t, unsigned long long *);
 
@@ -106,11 +123,11 @@ int main(int argc, char **argv) {
     int cus = prop.multiProcessorCount;
     printf("device %s, %d CUs, clock %d kHz\n", prop.gcnArchName, cus, prop.clockRate);
     Entry ents[] = {ENT(k_mad_u64_u32), ENT(k_mad_i64_i32), ENT(k_mul_lo_u32), ENT(k_mul_hi_u32),
-                    ENT(k_mad_u32_u24), ENT(k_mul_u32_u24), ENT(k_mul_hi_u32_u24), ENT(k_mad_u16),
-                    ENT(k_dot4_u32_u8), ENT(k_add_u32), ENT(k_add3_u32), ENT(k_and_b32), ENT(k_and_or_b32),
-                    ENT(k_bfe_u32), ENT(k_lshrrev_b32), ENT(k_alignbit_b32), ENT(k_add_co_u32),
-                    ENT(k_addc_co_u32), ENT(k_cndmask_b32), ENT(k_mov_b32), ENT(k_lshl_add_u64),
-                    ENT(k_lshrrev_b64), ENT(k_fma_f32), ENT(k_pk_fma_f32), ENT(k_fma_f64)};
+                    ENT(k_mad_u32_u24), ENT(k_mul_u32_u24), ENT(k_add_u32), ENT(k_sub_u32), ENT(k_add3_u32),
+                    ENT(k_and_b32), ENT(k_and_or_b32), ENT(k_bfe_u32), ENT(k_lshrrev_b32), ENT(k_alignbit_b32),
+                    ENT(k_add_co_u32), ENT(k_addc_co_u32), ENT(k_mov_b32), ENT(k_lshl_add_u64), ENT(k_lshrrev_b64),
+                    ENT(k_fma_f32), ENT(k_pk_fma_f32), ENT(k_fma_f64), ENT(k_mix_mac_add), ENT(k_mix_mac3_add),
+                    ENT(k_mix_mac_lshladd)};
     uint64_t *out;
     unsigned long long *cyc;
     const int max_blocks = cus * 8;
