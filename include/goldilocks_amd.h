@@ -148,6 +148,21 @@ GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_ed448_verify(
         const uint8_t *message, size_t message_len, uint8_t prehashed,
         const uint8_t *context, uint8_t context_len);
 
+/* --- "next" rows of SURVEY.md section 8(f): key derivation and signing (fixed-base comb + SHAKE256) --- */
+
+/* pubkey = RFC 8032 public key of privkey.  ref: ed448.h:73-76, src/eddsa.c:131-147 */
+GOLDILOCKS_AMD_API void goldilocks_ed448_derive_public_key(
+        uint8_t pubkey[GOLDILOCKS_EDDSA_448_PUBLIC_BYTES],
+        const uint8_t privkey[GOLDILOCKS_EDDSA_448_PRIVATE_BYTES]);
+/* RFC 8032 Ed448 / Ed448ph signature (prehashed != 0: message is the 64-byte prehash).
+ * ref: ed448.h:95-104, src/eddsa.c:149-230 */
+GOLDILOCKS_AMD_API void goldilocks_ed448_sign(
+        uint8_t signature[GOLDILOCKS_EDDSA_448_SIGNATURE_BYTES],
+        const uint8_t privkey[GOLDILOCKS_EDDSA_448_PRIVATE_BYTES],
+        const uint8_t pubkey[GOLDILOCKS_EDDSA_448_PUBLIC_BYTES],
+        const uint8_t *message, size_t message_len, uint8_t prehashed,
+        const uint8_t *context, uint8_t context_len);
+
 /* ------------------------------------------------------------------ (2) host-array batches
  * All return 0 on success, nonzero on a runtime (HIP) error -- see goldilocks_amd_last_error().
  * Arrays are dense AoS of the reference structs; outputs may alias inputs of the same type. */
@@ -172,6 +187,18 @@ GOLDILOCKS_AMD_API int goldilocks_ed448_verify_batch(goldilocks_error_t *status,
         const uint8_t *sig /* n*114 */, const uint8_t *pk /* n*57 */,
         const uint8_t *const *message, const size_t *message_len, uint8_t prehashed,
         const uint8_t *context, uint8_t context_len, size_t n);
+
+GOLDILOCKS_AMD_API int goldilocks_ed448_derive_public_key_batch(uint8_t *pubkey /* n*57 */,
+        const uint8_t *privkey /* n*57 */, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_ed448_sign_batch(uint8_t *signature /* n*114 */,
+        const uint8_t *privkey /* n*57 */, const uint8_t *pubkey /* n*57 */,
+        const uint8_t *const *message, const size_t *message_len, uint8_t prehashed,
+        const uint8_t *context, uint8_t context_len, size_t n);
+/* status[i] as goldilocks_448_direct_scalarmul(scaled[i], base[i], scalar[i], ...); with short_circuit a
+ * failing lane leaves scaled[i] untouched.  ref: point_448.h:378-384 */
+GOLDILOCKS_AMD_API int goldilocks_448_direct_scalarmul_batch(uint8_t *scaled /* n*56 */,
+        goldilocks_error_t *status, const uint8_t *base /* n*56 */, const goldilocks_448_scalar_s *scalar,
+        goldilocks_bool_t allow_identity, goldilocks_bool_t short_circuit, size_t n);
 
 /* ------------------------------------------------------------------ (3) device-array API
  * Pointers are device pointers (hipMalloc / torch.Tensor.data_ptr()); `stream` is a
@@ -220,6 +247,17 @@ GOLDILOCKS_AMD_API int goldilocks_amd_precompute_dev(void *table /* precomputed_
 GOLDILOCKS_AMD_API int goldilocks_amd_ed448_verify_dev(void *status, const void *sig, const void *pk,
         const void *msgs, const void *msg_offsets, size_t msg_len, uint8_t prehashed,
         const void *ctx, uint8_t ctx_len, size_t n, void *stream);
+
+GOLDILOCKS_AMD_API int goldilocks_amd_ed448_derive_public_key_dev(void *pubkey /* n*57 */,
+        const void *privkey /* n*57 */, size_t n, void *stream);
+/* message layout as for goldilocks_amd_ed448_verify_dev */
+GOLDILOCKS_AMD_API int goldilocks_amd_ed448_sign_dev(void *signature /* n*114 */, const void *privkey,
+        const void *pubkey, const void *msgs, const void *msg_offsets, size_t msg_len, uint8_t prehashed,
+        const void *ctx, uint8_t ctx_len, size_t n, void *stream);
+/* status: int32[n] */
+GOLDILOCKS_AMD_API int goldilocks_amd_direct_scalarmul_dev(void *scaled /* n*56 */, void *status,
+        const void *base /* n*56 */, const void *scalar, int allow_identity, int short_circuit, size_t n,
+        void *stream);
 
 /* Field-level test hook (parity tests for gf_mul / gf_sqr / gf_isr, ref: src/f_field.h:76-79):
  * op 0: out = a*b, 1: out = a^2, 2: out = isr(a) (status = mask), 3: out = strong_reduce(a).

@@ -46,6 +46,8 @@ FUNCTIONS = {
     "goldilocks_448_point_sub": (None, "ppp"),
     "goldilocks_448_point_double": (None, "pp"),
     "goldilocks_ed448_verify": (C.c_int, "pppzBpB"),
+    "goldilocks_ed448_derive_public_key": (None, "pp"),
+    "goldilocks_ed448_sign": (None, "ppppzBpB"),
     # (2) host-array batches
     "goldilocks_448_point_scalarmul_batch": (C.c_int, "pppz"),
     "goldilocks_448_precomputed_scalarmul_batch": (C.c_int, "pppz"),
@@ -55,6 +57,9 @@ FUNCTIONS = {
     "goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa_batch": (C.c_int, "ppz"),
     "goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio_batch": (C.c_int, "pppz"),
     "goldilocks_ed448_verify_batch": (C.c_int, "pppppBpBz"),
+    "goldilocks_ed448_derive_public_key_batch": (C.c_int, "ppz"),
+    "goldilocks_ed448_sign_batch": (C.c_int, "pppppBpBz"),
+    "goldilocks_448_direct_scalarmul_batch": (C.c_int, "ppppQQz"),
     # (3) device-array API
     "goldilocks_amd_init": (C.c_int, "i"),
     "goldilocks_amd_shutdown": (None, ""),
@@ -73,6 +78,9 @@ FUNCTIONS = {
     "goldilocks_amd_precompute_dev": (C.c_int, "ppzp"),
     "goldilocks_amd_ed448_verify_dev": (C.c_int, "pppppzBpBzp"),
     "goldilocks_amd_field_op_dev": (C.c_int, "ppppizp"),
+    "goldilocks_amd_ed448_derive_public_key_dev": (C.c_int, "ppzp"),
+    "goldilocks_amd_ed448_sign_dev": (C.c_int, "pppppzBpBzp"),
+    "goldilocks_amd_direct_scalarmul_dev": (C.c_int, "ppppiizp"),
 }
 DATA_SYMBOLS = [
     "goldilocks_448_sizeof_precomputed_s", "goldilocks_448_alignof_precomputed_s",
@@ -238,6 +246,45 @@ def ed448_verify_batch(sigs, pks, messages, prehashed=False, context=b""):
                                                C.addressof(lens), 1 if prehashed else 0, C.addressof(ctx),
                                                len(context), n))
     return st
+
+
+def _msg_tables(messages):
+    n = len(messages)
+    bufs = [C.create_string_buffer(bytes(m), max(len(m), 1)) for m in messages]
+    ptrs = (C.c_void_p * n)(*[C.addressof(b) for b in bufs])
+    lens = (C.c_size_t * n)(*[len(m) for m in messages])
+    return bufs, ptrs, lens
+
+
+def ed448_derive_public_key_batch(sks):
+    sks = _u8(sks, 57)
+    out = np.empty((len(sks), 57), dtype=np.uint8)
+    _check(lib().goldilocks_ed448_derive_public_key_batch(_ptr(out), _ptr(sks), len(sks)))
+    return out
+
+
+def ed448_sign_batch(sks, pks, messages, prehashed=False, context=b""):
+    sks, pks = _u8(sks, 57), _u8(pks, 57)
+    n = len(sks)
+    assert len(pks) == n and len(messages) == n
+    bufs, ptrs, lens = _msg_tables(messages)
+    ctx = C.create_string_buffer(bytes(context), max(len(context), 1))
+    out = np.empty((n, 114), dtype=np.uint8)
+    _check(lib().goldilocks_ed448_sign_batch(_ptr(out), _ptr(sks), _ptr(pks), C.addressof(ptrs), C.addressof(lens),
+                                             1 if prehashed else 0, C.addressof(ctx), len(context), n))
+    return out
+
+
+def direct_scalarmul_batch(bases56, scalars, allow_identity=False, short_circuit=False):
+    """Wire-format scalarmul: 56-byte encodings in, 56-byte encodings + status out."""
+    bases56, scalars = _u8(bases56, 56), _u64(scalars, 7)
+    n = len(scalars)
+    out = np.zeros((n, 56), dtype=np.uint8)
+    st = np.empty(n, dtype=np.int32)
+    _check(lib().goldilocks_448_direct_scalarmul_batch(_ptr(out), _ptr(st), _ptr(bases56), _ptr(scalars),
+                                                       2**64 - 1 if allow_identity else 0,
+                                                       2**64 - 1 if short_circuit else 0, n))
+    return out, st
 
 
 # ----------------------------------------------------------------------------- single ops (drop-in names)

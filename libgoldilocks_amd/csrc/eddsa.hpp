@@ -149,26 +149,40 @@ static inline sc sc_decode_long_bytes(const uint8_t *in, size_t len) {  // host 
 }
 #endif
 
-// ------------------------------------------------------------------ verify
-struct Ed448Msg {  // the virtual challenge string
-    const uint8_t *sig, *pk, *msg, *ctx;
-    uint32_t msglen, ctxlen;
+// ------------------------------------------------------------------ hashed strings
+// Every string EdDSA hashes is  [dom] | A | B | msg  with
+//   dom = "SigEd448" | ph | ctxlen | ctx   (src/eddsa.c:51-74; absent for key expansion)
+// verify:     dom | R(57) | pk(57) | msg          sign (challenge): the same
+// sign nonce: dom | seed(57) | msg                key expansion:    sk(57)
+struct Ed448Msg {
+    const uint8_t *a, *b, *msg, *ctx;
+    uint32_t alen, blen, msglen, ctxlen;
     uint32_t ph;
-    GD_MFN uint32_t total() const { return 10 + ctxlen + 114 + msglen; }
+    bool dom;
+    GD_MFN uint32_t total() const { return (dom ? 10 + ctxlen : 0) + alen + blen + msglen; }
     GD_MFN uint32_t byte(uint32_t j) const {
-        // "SigEd448" as two little-endian words
-        if (j < 8) return ((j < 4 ? 0x45676953u : 0x38343464u) >> (8 * (j & 3))) & 0xffu;
-        if (j == 8) return ph;
-        if (j == 9) return ctxlen;
-        j -= 10;
-        if (j < ctxlen) return ctx[j];
-        j -= ctxlen;
-        if (j < 57) return sig[j];
-        j -= 57;
-        if (j < 57) return pk[j];
-        return msg[j - 57];
+        if (dom) {
+            // "SigEd448" as two little-endian words
+            if (j < 8) return ((j < 4 ? 0x45676953u : 0x38343464u) >> (8 * (j & 3))) & 0xffu;
+            if (j == 8) return ph;
+            if (j == 9) return ctxlen;
+            j -= 10;
+            if (j < ctxlen) return ctx[j];
+            j -= ctxlen;
+        }
+        if (j < alen) return a[j];
+        j -= alen;
+        if (j < blen) return b[j];
+        return msg[j - blen];
     }
 };
+GD_FN Ed448Msg ed448_challenge_string(const uint8_t *r57, const uint8_t *pk57, const uint8_t *msg, uint32_t msglen,
+                                      uint32_t ph, const uint8_t *ctx, uint32_t ctxlen) {
+    Ed448Msg m;
+    m.a = r57; m.alen = 57; m.b = pk57; m.blen = 57; m.msg = msg; m.msglen = msglen;
+    m.ctx = ctx; m.ctxlen = ctxlen; m.ph = ph ? 1u : 0u; m.dom = true;
+    return m;
+}
 
 GD_FN void load_bytes_as_words(uint32_t *w, const uint8_t *p, int nbytes, int nwords) {
     for (int i = 0; i < nwords; i++) {
@@ -186,14 +200,14 @@ template <class BT, class AT, class STAGE, class MKBITS>
 GD_FN bool ed448_verify_core(const Ed448Msg &m, const BT &base_tab, AT &a_tab, STAGE &stage, MKBITS &mkbits) {
     uint32_t w[29];
     pt A, R;
-    load_bytes_as_words(w, m.pk, 57, 15);
+    load_bytes_as_words(w, m.b, 57, 15);          // public key
     bool ok = pt_decode_eddsa_words(A, w);
-    load_bytes_as_words(w, m.sig, 57, 15);
+    load_bytes_as_words(w, m.a, 57, 15);          // R = sig[0:57]
     ok = pt_decode_eddsa_words(R, w) && ok;   // (both decoded: lanes stay uniform)
 
     shake256_114(w, m, m.total(), stage);
     sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));   // -h mod q
-    load_bytes_as_words(w, m.sig + 57, 57, 15);
+    load_bytes_as_words(w, m.a + 57, 57, 15);     // S = sig[57:114]
     sc response = sc_decode_long_words<57>(w);                        // S mod q, no range check
 
     build_window_table(a_tab, A);
@@ -201,6 +215,76 @@ GD_FN bool ed448_verify_core(const Ed448Msg &m, const BT &base_tab, AT &a_tab, S
     auto bits_c = mkbits(sc_recode_signed(challenge), 1);
     pt P = ladder_double(bits_s, base_tab, bits_c, a_tab);            // S*B - h*A
     return ok && pt_eq(P, R);
+}
+
+// ------------------------------------------------------------------ key derivation and signing
+// ("next" row f1 of SURVEY.md section 8; restates src/eddsa.c:34-48, 98-230)
+
+GD_FN void ed448_clamp_words(uint32_t w[15]) {   // src/eddsa.c:34-48 on 57 bytes
+    w[0] &= ~3u;              // byte 0 &= -COFACTOR
+    w[13] |= 0x80000000u;     // byte 55 |= 0x80
+    w[14] = 0;                // byte 56 = 0
+}
+GD_FN void store_words_as_bytes(uint8_t *p, const uint32_t *w, int nbytes) {
+    for (int i = 0; i < nbytes; i++) p[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+}
+
+// pk = encode_like_eddsa( (clamp(SHAKE256(sk)[0:57]) / 4) * B )      src/eddsa.c:98-147
+template <class COMB, class STAGE, class MKBITS>
+GD_FN void ed448_derive_core(uint8_t *pk57, const uint8_t *sk57, const COMB &comb, STAGE &stage, MKBITS &mkbits) {
+    Ed448Msg m;
+    m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
+    m.ctx = sk57; m.ctxlen = 0; m.ph = 0; m.dom = false;
+    uint32_t w[29];
+    shake256_114(w, m, 57, stage);
+    ed448_clamp_words(w);
+    sc secret = sc_decode_long_words<57>(w);
+    secret = sc_halve(sc_halve(secret));                       // ENCODE_RATIO = 4
+    auto bits = mkbits(sc_recode_signed(secret), 0);
+    pt p = ladder_comb(bits, comb);
+    uint32_t e[15];
+    pt_encode_eddsa_words(e, p);
+    store_words_as_bytes(pk57, e, 57);
+}
+
+// RFC 8032 signing (src/eddsa.c:149-230).  scratch: 64 bytes of lane-private memory for the
+// hashed-key seed.  sig114 doubles as the place R is read back from for the challenge hash.
+template <class COMB, class STAGE, class MKBITS>
+GD_FN void ed448_sign_core(uint8_t *sig114, const uint8_t *sk57, const uint8_t *pk57, const uint8_t *msg,
+                           uint32_t msglen, uint32_t ph, const uint8_t *ctx, uint32_t ctxlen, uint8_t *scratch,
+                           const COMB &comb, STAGE &stage, MKBITS &mkbits) {
+    Ed448Msg m;
+    m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
+    m.ctx = ctx; m.ctxlen = 0; m.ph = 0; m.dom = false;
+    uint32_t w[29];
+    shake256_114(w, m, 57, stage);                             // expanded = secret(57) | seed(57)
+    // seed = bytes 57..113: park them in lane-private memory to be hashed next
+    for (int i = 0; i < 57; i++) scratch[i] = (uint8_t)(w[(57 + i) >> 2] >> (8 * ((57 + i) & 3)));
+    uint32_t sw[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) sw[i] = w[i];
+    ed448_clamp_words(sw);
+    sc secret = sc_decode_long_words<57>(sw);
+
+    m.a = scratch; m.alen = 57; m.blen = 0; m.msg = msg; m.msglen = msglen;
+    m.ctx = ctx; m.ctxlen = ctxlen; m.ph = ph ? 1u : 0u; m.dom = true;
+    shake256_114(w, m, m.total(), stage);
+    sc nonce = sc_decode_long_words<114>(w);
+    auto bits = mkbits(sc_recode_signed(sc_halve(sc_halve(nonce))), 0);
+    pt rp = ladder_comb(bits, comb);
+    uint32_t e[15];
+    pt_encode_eddsa_words(e, rp);
+    store_words_as_bytes(sig114, e, 57);
+
+    Ed448Msg c = ed448_challenge_string(sig114, pk57, msg, msglen, ph, ctx, ctxlen);
+    shake256_114(w, c, c.total(), stage);
+    sc challenge = sc_decode_long_words<114>(w);
+    sc resp = sc_add(sc_mul(challenge, secret), nonce);
+    uint32_t rw[15];
+#pragma unroll
+    for (int i = 0; i < 14; i++) rw[i] = resp.w[i];
+    rw[14] = 0;
+    store_words_as_bytes(sig114 + 57, rw, 57);
 }
 
 #if !defined(__HIPCC__)
@@ -228,7 +312,7 @@ struct HostMkBits {
 template <class BT, class AT>
 static inline bool ed448_verify_lane(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen,
                                      uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const BT &bt, AT &at) {
-    Ed448Msg m{sig, pk, msg, ctx, (uint32_t)msglen, ctxlen, prehashed ? 1u : 0u};
+    Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
     HostStage stage;
     HostMkBits mk;
     return ed448_verify_core(m, bt, at, stage, mk);

@@ -280,21 +280,93 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
     LdsStage stage{s_stage + threadIdx.x};
     LdsMkBits mk{s_bits + threadIdx.x};
     for (uint32_t i = lane; i < n; i += stride) {
-        Ed448Msg m;
-        m.sig = sig + 114 * (size_t)i;
-        m.pk = pk + 57 * (size_t)i;
-        if (msg_offsets) {
-            m.msg = msgs + msg_offsets[i];
-            m.msglen = (uint32_t)(msg_offsets[i + 1] - msg_offsets[i]);
-        } else {
-            m.msg = msgs + (size_t)msg_len * i;
-            m.msglen = msg_len;
-        }
-        m.ctx = ctx;
-        m.ctxlen = ctx_len;
-        m.ph = prehashed ? 1u : 0u;
+        const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
+        const uint32_t mlen = msg_offsets ? (uint32_t)(msg_offsets[i + 1] - msg_offsets[i]) : msg_len;
+        Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx,
+                                            ctx_len);
         bool ok = ed448_verify_core(m, b_tab, a_tab, stage, mk);
         status[i] = ok ? -1 : 0;
+    }
+}
+
+// "next" row f1: pk[i] = derive_public_key(sk[i])   (ref: goldilocks_ed448_derive_public_key)
+GD_KERNEL k_ed448_derive_public_key(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
+                                    const uint4 *__restrict__ comb) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint32_t s_stage[34 * BLOCK];
+    __shared__ uint32_t s_comb[COMB_LDS_WORDS];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    stage_comb_lds(s_comb, comb);
+    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
+    LdsStage stage{s_stage + threadIdx.x};
+    LdsMkBits mk{s_bits + threadIdx.x};
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {   // wave-uniform trip count: the comb gather shuffles
+        const uint32_t i_raw = lane + r * stride;
+        const bool live = i_raw < n;
+        const uint32_t i = live ? i_raw : n - 1;
+        // lanes past the end mirror lane n-1 and store the identical bytes to the same address
+        ed448_derive_core(pk + 57 * (size_t)i, sk + 57 * (size_t)i, tab, stage, mk);
+    }
+}
+
+// "next" row f1: sig[i] = sign(sk[i], pk[i], msg[i])   (ref: goldilocks_ed448_sign)
+GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,
+                       const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
+                       uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
+                       uint32_t n, const uint4 *__restrict__ comb, uint8_t *__restrict__ workspace) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint32_t s_stage[34 * BLOCK];
+    __shared__ uint32_t s_comb[COMB_LDS_WORDS];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    stage_comb_lds(s_comb, comb);
+    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
+    LdsStage stage{s_stage + threadIdx.x};
+    LdsMkBits mk{s_bits + threadIdx.x};
+    uint8_t *scratch = workspace + (size_t)lane * 256;   // 64 B seed + 114 B signature under construction
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i_raw = lane + r * stride;
+        const bool live = i_raw < n;
+        const uint32_t i = live ? i_raw : n - 1;
+        const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
+        const uint32_t mlen = msg_offsets ? (uint32_t)(msg_offsets[i + 1] - msg_offsets[i]) : msg_len;
+        uint8_t *dst = scratch + 64;   // dead lanes must not race with the live lane they mirror
+        ed448_sign_core(dst, sk + 57 * (size_t)i, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx, ctx_len, scratch,
+                        tab, stage, mk);
+        if (live)
+            for (int k = 0; k < 114; k++) sig[114 * (size_t)i + k] = dst[k];
+    }
+}
+
+// "next" row f2: wire-format scalarmul, 56 bytes in / 56 bytes out   (ref: goldilocks_448_direct_scalarmul)
+GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                             const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
+                             int allow_identity, int short_circuit, uint4 *__restrict__ workspace,
+                             const uint64_t *__restrict__ point_base_abi) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    LaneTable tab{workspace + (size_t)lane * TABLE_U4};
+    for (uint32_t i = lane; i < n; i += stride) {
+        uint32_t w[14];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(base + 56 * (size_t)i);
+#pragma unroll
+        for (int k = 0; k < 14; k++) w[k] = src[k];
+        pt b;
+        bool ok = pt_decode_words(b, w, allow_identity != 0);
+        status[i] = ok ? -1 : 0;
+        if (!ok && short_circuit) continue;
+        if (!ok) b = pt_load_abi(point_base_abi);   // src/goldilocks.c:898: multiply the base point instead
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(scalar + 7 * (size_t)i)));
+        build_window_table(tab, b);
+        pt r = ladder_varbase(bits, tab);
+        pt_encode_words(w, r);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(scaled + 56 * (size_t)i);
+#pragma unroll
+        for (int k = 0; k < 14; k++) dst[k] = w[k];
     }
 }
 

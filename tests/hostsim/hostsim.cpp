@@ -169,4 +169,21 @@ int hs_ed448_verify(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, s
     return ed448_verify_lane(sig, pk, msg, msglen, prehashed, ctx, ctxlen, tb, ta) ? -1 : 0;
 }
 
+void hs_ed448_derive_public_key(uint8_t *pk, const uint8_t *sk, const uint64_t *comb_table) {
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    HostStage stage;
+    HostMkBits mk;
+    ed448_derive_core(pk, sk, comb, stage, mk);
+}
+void hs_ed448_sign(uint8_t *sig, const uint8_t *sk, const uint8_t *pk, const uint8_t *msg, size_t msglen,
+                   uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    HostStage stage;
+    HostMkBits mk;
+    uint8_t scratch[64];
+    ed448_sign_core(sig, sk, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen, scratch, comb, stage, mk);
+}
+
 }  // extern "C"

@@ -359,3 +359,63 @@ def test_golden_f6_full_batch_digest(ga):
     enc_all = ser.cpu().numpy()
     for lg in (10, 16, 20):
         assert hashlib.shake_256(enc_all[:1 << lg].tobytes()).hexdigest(32) == dig[str(lg)], lg
+
+
+# ----------------------------------------------------------------------------- "next" rows
+
+
+def test_derive_public_key_and_sign_vs_oracle_and_rfc8032(ga, O):
+    kats = json.load(open(os.path.join(GOLD, "kats.json")))["rfc8032_ed448"]
+    for c in kats:
+        sk, pk, ctx = bytes.fromhex(c["sk"]), bytes.fromhex(c["pk"]), bytes.fromhex(c["context"])
+        msg = bytes.fromhex(c["message"])
+        if c["prehashed"]:
+            msg = hashlib.shake_256(msg).digest(64)
+        sk_a, pk_a = np.frombuffer(sk, np.uint8).reshape(1, 57), np.frombuffer(pk, np.uint8).reshape(1, 57)
+        assert ga.ed448_derive_public_key_batch(sk_a)[0].tobytes() == pk
+        sig = ga.ed448_sign_batch(sk_a, pk_a, [msg], prehashed=c["prehashed"], context=ctx)
+        assert sig[0].tobytes().hex() == c["sig"]
+    # seeded batch vs the oracle's signer, ragged message lengths, then verify on the GPU
+    n = 200
+    sk = np.frombuffer(_gen.stream(b"t-sign-sk", 57 * n), np.uint8).reshape(n, 57).copy()
+    want_pk = np.empty((n, 57), np.uint8)
+    O.orc_ed448_derive_public_key_batch(want_pk.ctypes.data, sk.ctypes.data, n, 8)
+    pk = ga.ed448_derive_public_key_batch(sk)
+    assert (pk == want_pk).all()
+    msgs = [_gen.stream(b"t-sign-m%d" % i, 400)[:(i * 7) % 311] for i in range(n)]
+    for ctx, ph in ((b"", False), (b"ctx!", False), (b"", True)):
+        sig = ga.ed448_sign_batch(sk, pk, msgs, prehashed=ph, context=ctx)
+        for i in range(0, n, 3):
+            w = (C.c_uint8 * 114)()
+            m = (C.c_uint8 * max(1, len(msgs[i]))).from_buffer_copy(msgs[i] or b"\0")
+            cb = (C.c_uint8 * max(1, len(ctx))).from_buffer_copy(ctx or b"\0")
+            O.orc_ed448_sign(w, sk[i].ctypes.data, pk[i].ctypes.data, m, len(msgs[i]), 1 if ph else 0, cb, len(ctx))
+            assert bytes(w) == sig[i].tobytes(), (i, ctx, ph)
+        assert (ga.ed448_verify_batch(sig, pk, msgs, prehashed=ph, context=ctx) == -1).all()
+
+
+def test_direct_scalarmul_wire_format(ga, O):
+    n = 300
+    s = _gen.random_scalars(n, b"t-direct-s")
+    pts = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-direct-b"))
+    base = _gen.oracle_encode(pts)
+    base[5] = 0                       # identity encoding
+    base[6] = 0xff                    # not a field element
+    base[7, 0] |= 1                   # negative s
+    for allow_id in (False, True):
+        for short in (False, True):
+            got, st = ga.direct_scalarmul_batch(base, s, allow_identity=allow_id, short_circuit=short)
+            for i in list(range(12)) + list(range(12, n, 17)):
+                out = (C.c_uint8 * 56)()
+                from _libs import Scalar
+                r = O.orc_direct_scalarmul(out, base[i].ctypes.data, C.cast(s[i].ctypes.data, C.POINTER(Scalar)),
+                                           1 if allow_id else 0, 1 if short else 0)
+                assert r == st[i], (i, allow_id, short)
+                if r == -1 or not short:
+                    assert bytes(out) == got[i].tobytes(), (i, allow_id, short)
+                else:
+                    assert not got[i].any()          # untouched (the binding passes zeros in)
+    one = np.frombuffer(bytes(base[0]), np.uint8)
+    out = (C.c_uint8 * 56)()
+    r = ga.lib().goldilocks_448_direct_scalarmul(out, one.ctypes.data, s[0].ctypes.data, 0, 0)
+    assert r == -1 and bytes(out) == ga.direct_scalarmul_batch(base[:1], s[:1])[0][0].tobytes()
