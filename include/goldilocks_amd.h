@@ -163,6 +163,17 @@ GOLDILOCKS_AMD_API void goldilocks_ed448_sign(
         const uint8_t *message, size_t message_len, uint8_t prehashed,
         const uint8_t *context, uint8_t context_len);
 
+/* --- "next" row f3: X448 (RFC 7748) --- */
+#define GOLDILOCKS_X448_PUBLIC_BYTES 56   /* ref: point_448.h:60 */
+#define GOLDILOCKS_X448_PRIVATE_BYTES 56  /* ref: point_448.h:63 */
+/* shared = X448(scalar, base); FAILURE iff the result is all zero.  ref: point_448.h:398-402, src/goldilocks.c:1006-1076 */
+GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_x448(uint8_t shared[GOLDILOCKS_X448_PUBLIC_BYTES],
+        const uint8_t base[GOLDILOCKS_X448_PUBLIC_BYTES], const uint8_t scalar[GOLDILOCKS_X448_PRIVATE_BYTES]);
+/* out = X448(scalar, 5) computed on the fixed-base comb.  ref: point_448.h:445-448, src/goldilocks.c:1115-1141 */
+GOLDILOCKS_AMD_API void goldilocks_x448_derive_public_key(uint8_t out[GOLDILOCKS_X448_PUBLIC_BYTES],
+        const uint8_t scalar[GOLDILOCKS_X448_PRIVATE_BYTES]);
+GOLDILOCKS_AMD_API extern const uint8_t goldilocks_x448_base_point[GOLDILOCKS_X448_PUBLIC_BYTES]; /* ref: point_448.h:413 */
+
 /* ------------------------------------------------------------------ (2) host-array batches
  * All return 0 on success, nonzero on a runtime (HIP) error -- see goldilocks_amd_last_error().
  * Arrays are dense AoS of the reference structs; outputs may alias inputs of the same type. */
@@ -199,6 +210,10 @@ GOLDILOCKS_AMD_API int goldilocks_ed448_sign_batch(uint8_t *signature /* n*114 *
 GOLDILOCKS_AMD_API int goldilocks_448_direct_scalarmul_batch(uint8_t *scaled /* n*56 */,
         goldilocks_error_t *status, const uint8_t *base /* n*56 */, const goldilocks_448_scalar_s *scalar,
         goldilocks_bool_t allow_identity, goldilocks_bool_t short_circuit, size_t n);
+
+/* status[i] = goldilocks_x448(shared[i], base[i], scalar[i]); base == NULL: the base point (derive_public_key) */
+GOLDILOCKS_AMD_API int goldilocks_x448_batch(uint8_t *shared /* n*56 */, goldilocks_error_t *status,
+        const uint8_t *base /* n*56 or NULL */, const uint8_t *scalar /* n*56 */, size_t n);
 
 /* ------------------------------------------------------------------ (3) device-array API
  * Pointers are device pointers (hipMalloc / torch.Tensor.data_ptr()); `stream` is a
@@ -258,6 +273,10 @@ GOLDILOCKS_AMD_API int goldilocks_amd_ed448_sign_dev(void *signature /* n*114 */
 GOLDILOCKS_AMD_API int goldilocks_amd_direct_scalarmul_dev(void *scaled /* n*56 */, void *status,
         const void *base /* n*56 */, const void *scalar, int allow_identity, int short_circuit, size_t n,
         void *stream);
+
+/* base == NULL: x448_derive_public_key for every lane (status all success); status: int32[n] or NULL */
+GOLDILOCKS_AMD_API int goldilocks_amd_x448_dev(void *shared /* n*56 */, void *status, const void *base,
+        const void *scalar /* n*56 */, size_t n, void *stream);
 
 /* Field-level test hook (parity tests for gf_mul / gf_sqr / gf_isr, ref: src/f_field.h:76-79):
  * op 0: out = a*b, 1: out = a^2, 2: out = isr(a) (status = mask), 3: out = strong_reduce(a).

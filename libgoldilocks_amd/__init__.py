@@ -47,6 +47,8 @@ FUNCTIONS = {
     "goldilocks_448_point_double": (None, "pp"),
     "goldilocks_ed448_verify": (C.c_int, "pppzBpB"),
     "goldilocks_ed448_derive_public_key": (None, "pp"),
+    "goldilocks_x448": (C.c_int, "ppp"),
+    "goldilocks_x448_derive_public_key": (None, "pp"),
     "goldilocks_ed448_sign": (None, "ppppzBpB"),
     # (2) host-array batches
     "goldilocks_448_point_scalarmul_batch": (C.c_int, "pppz"),
@@ -60,6 +62,7 @@ FUNCTIONS = {
     "goldilocks_ed448_derive_public_key_batch": (C.c_int, "ppz"),
     "goldilocks_ed448_sign_batch": (C.c_int, "pppppBpBz"),
     "goldilocks_448_direct_scalarmul_batch": (C.c_int, "ppppQQz"),
+    "goldilocks_x448_batch": (C.c_int, "ppppz"),
     # (3) device-array API
     "goldilocks_amd_init": (C.c_int, "i"),
     "goldilocks_amd_shutdown": (None, ""),
@@ -81,11 +84,12 @@ FUNCTIONS = {
     "goldilocks_amd_ed448_derive_public_key_dev": (C.c_int, "ppzp"),
     "goldilocks_amd_ed448_sign_dev": (C.c_int, "pppppzBpBzp"),
     "goldilocks_amd_direct_scalarmul_dev": (C.c_int, "ppppiizp"),
+    "goldilocks_amd_x448_dev": (C.c_int, "ppppzp"),
 }
 DATA_SYMBOLS = [
     "goldilocks_448_sizeof_precomputed_s", "goldilocks_448_alignof_precomputed_s",
     "goldilocks_448_scalar_one", "goldilocks_448_scalar_zero", "goldilocks_448_point_identity",
-    "goldilocks_448_point_base", "goldilocks_448_precomputed_base",
+    "goldilocks_448_point_base", "goldilocks_448_precomputed_base", "goldilocks_x448_base_point",
 ]
 _CT = {"p": C.c_void_p, "z": C.c_size_t, "Q": C.c_uint64, "B": C.c_uint8, "i": C.c_int}
 
@@ -284,6 +288,17 @@ def direct_scalarmul_batch(bases56, scalars, allow_identity=False, short_circuit
     _check(lib().goldilocks_448_direct_scalarmul_batch(_ptr(out), _ptr(st), _ptr(bases56), _ptr(scalars),
                                                        2**64 - 1 if allow_identity else 0,
                                                        2**64 - 1 if short_circuit else 0, n))
+    return out, st
+
+
+def x448_batch(scalars56, bases56=None):
+    """X448(scalar, base) for each row; bases56=None computes public keys (base point 5)."""
+    scalars56 = _u8(scalars56, 56)
+    n = len(scalars56)
+    out = np.empty((n, 56), dtype=np.uint8)
+    st = np.empty(n, dtype=np.int32)
+    b = None if bases56 is None else _ptr(_u8(bases56, 56))
+    _check(lib().goldilocks_x448_batch(_ptr(out), _ptr(st), b, _ptr(scalars56), n))
     return out, st
 
 

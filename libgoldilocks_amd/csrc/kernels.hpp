@@ -17,6 +17,7 @@
 #include "abi.hpp"
 #include "eddsa.hpp"
 #include "scalarmul.hpp"
+#include "x448.hpp"
 
 namespace gd {
 
@@ -367,6 +368,48 @@ GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__
         uint32_t *dst = reinterpret_cast<uint32_t *>(scaled + 56 * (size_t)i);
 #pragma unroll
         for (int k = 0; k < 14; k++) dst[k] = w[k];
+    }
+}
+
+// "next" row f3: X448.  base == nullptr: derive_public_key through the comb   (ref: goldilocks_x448*)
+GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
+                 const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ comb) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint32_t s_comb[COMB_LDS_WORDS];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    if (!base) stage_comb_lds(s_comb, comb);   // uniform
+    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i_raw = lane + r * stride;
+        const bool live = i_raw < n;
+        const uint32_t i = live ? i_raw : n - 1;
+        uint32_t w[14], o[14];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(scalar + 56 * (size_t)i);
+#pragma unroll
+        for (int k = 0; k < 14; k++) w[k] = src[k];
+        bool ok = true;
+        if (base) {
+            uint32_t b[14];
+            const uint32_t *bs = reinterpret_cast<const uint32_t *>(base + 56 * (size_t)i);
+#pragma unroll
+            for (int k = 0; k < 14; k++) b[k] = bs[k];
+            sc raw;
+#pragma unroll
+            for (int k = 0; k < 14; k++) raw.w[k] = w[k];
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, raw);
+            ok = x448_core(o, b, bits);
+        } else {
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(x448_public_scalar(w)));
+            pt_encode_x448_words(o, ladder_comb(bits, tab));
+        }
+        if (live) {
+            uint32_t *dst = reinterpret_cast<uint32_t *>(shared + 56 * (size_t)i);
+#pragma unroll
+            for (int k = 0; k < 14; k++) dst[k] = o[k];
+            if (status) status[i] = ok ? -1 : 0;
+        }
     }
 }
 

@@ -1,0 +1,66 @@
+// x448.hpp -- RFC 7748 X448 on the same lane arithmetic ("next" row f3 of SURVEY.md section 8):
+//   goldilocks_x448                       src/goldilocks.c:1006-1076   Montgomery ladder, 448 steps of
+//                                                                      5M + 4S + 1 mulw
+//   goldilocks_x448_derive_public_key     src/goldilocks.c:1115-1141   fixed-base comb + (y/x)^2
+#pragma once
+#include "scalarmul.hpp"
+
+namespace gd {
+
+// BITS: bits.word(k) = k-th 32-bit word of the 56-byte scalar as given (clamping is applied here).
+// base/out: 56-byte strings as 14 words.  Returns false iff the result is zero (reference :1065,1075).
+template <class BITS>
+GD_FN bool x448_core(uint32_t out[14], const uint32_t base[14], const BITS &bits) {
+    fe x1;
+    (void)fe_deserialize_words(x1, base);   // the reference ignores the range check too (:1014)
+    fe x2 = fe_one(), z2 = fe_zero(), x3 = x1, z3 = fe_one();
+    bool swap = false;
+#pragma unroll 1
+    for (int t = 447; t >= 0; t--) {
+        uint32_t bit = (bits.word(t >> 5) >> (t & 31)) & 1u;
+        if (t < 2) bit = 0;          // scalar[0] &= -COFACTOR
+        if (t == 447) bit = 1;       // top bit forced
+        const bool k_t = bit != 0;
+        const bool sw = swap != k_t;
+        fe a2 = fe_select(x2, x3, sw), a3 = fe_select(x3, x2, sw);
+        fe c2 = fe_select(z2, z3, sw), c3 = fe_select(z3, z2, sw);
+        swap = k_t;
+        fe t1 = fe_add(a2, c2);                         // A = x2 + z2            mag 2
+        fe t2 = fe_weak(fe_sub<2>(a2, c2));             // B = x2 - z2            mag 1
+        fe d = fe_weak(fe_sub<2>(a3, c3));              // D = x3 - z3            mag 1
+        fe da = fe_mul(t1, d);                          // DA
+        fe c = fe_add(c3, a3);                          // C = x3 + z3            mag 2
+        fe cb = fe_mul(c, t2);                          // CB
+        fe dm = fe_weak(fe_sub<2>(da, cb));             // DA - CB                mag 1
+        z3 = fe_mul(x1, fe_sqr(dm));                    // z3 = x1 (DA-CB)^2
+        x3 = fe_sqr(fe_add(da, cb));                    // x3 = (DA+CB)^2   (input mag 2)
+        fe aa = fe_sqr(t1);                             // AA   (input mag 2)
+        fe bb = fe_sqr(t2);                             // BB
+        x2 = fe_mul(aa, bb);
+        fe e = fe_weak(fe_sub<2>(aa, bb));              // E = AA - BB            mag 1
+        fe f = fe_add(fe_mulw(e, 39081), aa);           // AA + a24 E             mag 2
+        z2 = fe_mul(f, e);
+    }
+    fe rx = fe_select(x2, x3, swap), rz = fe_select(z2, z3, swap);
+    fe r = fe_mul(rx, fe_invert(rz));
+    fe_serialize_words(out, r);
+    return !fe_is_zero(r);
+}
+
+// (y/x)^2 of a twisted-Edwards point, serialized (src/goldilocks.c:1102-1113)
+GD_FN void pt_encode_x448_words(uint32_t out[14], const pt &p) {
+    fe r = fe_mul(fe_invert(p.x), p.y);
+    fe_serialize_words(out, fe_sqr(r));
+}
+
+// the scalar x448_derive_public_key multiplies the base point by (src/goldilocks.c:1119-1136)
+GD_FN sc x448_public_scalar(const uint32_t scalar_words[14]) {
+    sc s;
+#pragma unroll
+    for (int i = 0; i < 14; i++) s.w[i] = scalar_words[i];
+    s.w[0] &= ~3u;
+    s.w[13] = (s.w[13] & 0x7fffffffu) | 0x80000000u;
+    return sc_halve(sc_reduce(s));           // decode_long of exactly 56 bytes = reduce; ratio 2 = one halving
+}
+
+}  // namespace gd

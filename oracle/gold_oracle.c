@@ -929,6 +929,67 @@ int orc_direct_scalarmul(uint8_t out[56], const uint8_t base[56], const orc_scal
     return succ;
 }
 
+/* ---- X448 (RFC 7748): src/goldilocks.c:1006-1141 ---- */
+
+int orc_x448(uint8_t out[56], const uint8_t base[56], const uint8_t scalar[56]) { /* goldilocks.c:1006-1076 */
+    orc_gf x1, x2 = FE_ONE, z2 = FE_ZERO, x3, z3 = FE_ONE, t1, t2;
+    mask_t swap = 0;
+    (void)orc_gf_deserialize(&x1, base, 0);
+    x3 = x1;
+    for (int t = 447; t >= 0; t--) {
+        uint8_t sb = scalar[t / 8];
+        if (t / 8 == 0) sb &= 0xFC;          /* clear the cofactor bits */
+        else if (t == 447) sb = 0xFF;        /* force the top bit */
+        mask_t k_t = (mask_t)0 - ((sb >> (t % 8)) & 1);
+        swap ^= k_t;
+        fe_cond_swap(&x2, &x3, swap);
+        fe_cond_swap(&z2, &z3, swap);
+        swap = k_t;
+        fe_add_nr(&t1, &x2, &z2);
+        fe_sub_nr(&t2, &x2, &z2);
+        fe_sub_nr(&z2, &x3, &z3);
+        fe_mul_ip(&x2, &t1, &z2);
+        fe_add_nr(&z2, &z3, &x3);
+        fe_mul_ip(&x3, &t2, &z2);
+        fe_sub_nr(&z3, &x2, &x3);
+        fe_sqr(&z2, &z3);
+        fe_mul_ip(&z3, &x1, &z2);
+        fe_add_nr(&z2, &x2, &x3);
+        fe_sqr(&x3, &z2);
+        fe_sqr(&z2, &t1);
+        fe_sqr(&t1, &t2);
+        fe_mul_ip(&x2, &z2, &t1);
+        fe_sub_nr(&t2, &z2, &t1);
+        orc_gf_mulw(&t1, &t2, 39081);        /* a24 = -EDWARDS_D */
+        fe_add_nr(&t1, &t1, &z2);
+        fe_mul_ip(&z2, &t2, &t1);
+    }
+    fe_cond_swap(&x2, &x3, swap);
+    fe_cond_swap(&z2, &z3, swap);
+    fe_invert(&z2, &z2);
+    fe_mul_ip(&x1, &x2, &z2);
+    orc_gf_serialize(out, &x1);
+    return orc_gf_eq(&x1, &FE_ZERO) ? ORC_FAILURE : ORC_SUCCESS;
+}
+
+void orc_x448_derive_public_key(uint8_t out[56], const uint8_t scalar[56]) { /* goldilocks.c:1115-1141 */
+    uint8_t s2[56];
+    orc_scalar s;
+    orc_point p;
+    orc_gf inv, r, sq;
+    memcpy(s2, scalar, 56);
+    s2[0] &= 0xFC;
+    s2[55] &= 0x7F;
+    s2[55] |= 0x80;
+    orc_scalar_decode_long(&s, s2, 56);
+    orc_scalar_halve(&s, &s);                /* X448_ENCODE_RATIO = 2 */
+    orc_precomputed_scalarmul(&p, orc_precomputed_base(), &s);
+    fe_invert(&inv, &p.x);                   /* goldilocks.c:1102-1113: (y/x)^2 */
+    fe_mul(&r, &inv, &p.y);
+    fe_sqr(&sq, &r);
+    orc_gf_serialize(out, &sq);
+}
+
 /* ---- constants regenerated by this file's own generator (gen_tables.c:21-23, 59-86) ---- */
 
 static pthread_once_t g_tables_once = PTHREAD_ONCE_INIT;

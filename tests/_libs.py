@@ -120,6 +120,8 @@ def oracle():
         "orc_base_double_scalarmul_non_secret": (None, [pp, ps, pp, ps]),
         "orc_direct_scalarmul": (C.c_int, [vp, vp, ps, C.c_int, C.c_int]),
         "orc_shake256": (None, [vp, C.c_size_t, vp, C.c_size_t]),
+        "orc_x448": (C.c_int, [vp, vp, vp]),
+        "orc_x448_derive_public_key": (None, [vp, vp]),
         "orc_ed448_derive_public_key": (None, [vp, vp]),
         "orc_ed448_sign": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8]),
         "orc_ed448_verify": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8]),
@@ -184,6 +186,8 @@ def ref():
         "goldilocks_ed448_sign": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8]),
         "goldilocks_ed448_verify": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8]),
         "goldilocks_sha3_hash": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp]),
+        "goldilocks_x448": (C.c_int, [vp, vp, vp]),
+        "goldilocks_x448_derive_public_key": (None, [vp, vp]),
     }
     for name, (res, args) in proto.items():
         f = getattr(L, name)

@@ -9,6 +9,7 @@
 #include "../../libgoldilocks_amd/csrc/abi.hpp"
 #include "../../libgoldilocks_amd/csrc/scalarmul.hpp"
 #include "../../libgoldilocks_amd/csrc/eddsa.hpp"
+#include "../../libgoldilocks_amd/csrc/x448.hpp"
 
 #include <string.h>
 
@@ -184,6 +185,25 @@ void hs_ed448_sign(uint8_t *sig, const uint8_t *sk, const uint8_t *pk, const uin
     HostMkBits mk;
     uint8_t scratch[64];
     ed448_sign_core(sig, sk, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen, scratch, comb, stage, mk);
+}
+
+int hs_x448(uint8_t *out, const uint8_t *base, const uint8_t *scalar) {
+    uint32_t b[14], o[14];
+    HostBits bits;
+    bytes_to_words(b, base, 56, 14);
+    bytes_to_words(bits.w, scalar, 56, 15);
+    bool ok = x448_core(o, b, bits);
+    words_to_bytes(out, o, 56);
+    return ok ? -1 : 0;
+}
+void hs_x448_derive_public_key(uint8_t *out, const uint8_t *scalar, const uint64_t *comb_table) {
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    uint32_t w[14], o[14];
+    bytes_to_words(w, scalar, 56, 14);
+    HostBits bits = make_bits(x448_public_scalar(w));
+    pt_encode_x448_words(o, ladder_comb(bits, comb));
+    words_to_bytes(out, o, 56);
 }
 
 }  // extern "C"

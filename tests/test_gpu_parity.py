@@ -419,3 +419,39 @@ def test_direct_scalarmul_wire_format(ga, O):
     out = (C.c_uint8 * 56)()
     r = ga.lib().goldilocks_448_direct_scalarmul(out, one.ctypes.data, s[0].ctypes.data, 0, 0)
     assert r == -1 and bytes(out) == ga.direct_scalarmul_batch(base[:1], s[:1])[0][0].tobytes()
+
+
+def test_x448_vs_oracle_and_rfc7748(ga, O):
+    kats = json.load(open(os.path.join(GOLD, "kats.json")))["rfc7748_x448_iterated"]
+    u = k = np.frombuffer(bytes([5] + [0] * 55), np.uint8).reshape(1, 56)
+    for i in range(1000):                       # the reference's iterated test (test_goldilocks.cxx:545-552)
+        out, st = ga.x448_batch(k, u)
+        assert st[0] == -1
+        u, k = k, out
+        if i == 0:
+            assert k[0].tobytes().hex() == kats["1"]
+    assert k[0].tobytes().hex() == kats["1000"]
+    n = 512
+    sc = np.frombuffer(_gen.stream(b"t-x448-s", 56 * n), np.uint8).reshape(n, 56).copy()
+    bs = np.frombuffer(_gen.stream(b"t-x448-b", 56 * n), np.uint8).reshape(n, 56).copy()
+    bs[0] = 0                     # low-order input: result must be zero -> FAILURE
+    bs[1] = 0xff
+    bs[2] = 0; bs[2, 0] = 1
+    got, st = ga.x448_batch(sc, bs)
+    pub, _ = ga.x448_batch(sc)
+    for i in range(n):
+        w = (C.c_uint8 * 56)()
+        assert O.orc_x448(w, bs[i].ctypes.data, sc[i].ctypes.data) == st[i], i
+        assert bytes(w) == got[i].tobytes(), i
+        O.orc_x448_derive_public_key(w, sc[i].ctypes.data)
+        assert bytes(w) == pub[i].tobytes(), i
+    assert st[0] == 0 and st[3] == -1
+    # Diffie-Hellman consistency through the drop-in single-op names
+    L = ga.lib()
+    a, b = sc[10].copy(), sc[11].copy()
+    pa, pb, s1, s2 = (np.empty(56, np.uint8) for _ in range(4))
+    L.goldilocks_x448_derive_public_key(pa.ctypes.data, a.ctypes.data)
+    L.goldilocks_x448_derive_public_key(pb.ctypes.data, b.ctypes.data)
+    assert L.goldilocks_x448(s1.ctypes.data, pb.ctypes.data, a.ctypes.data) == -1
+    assert L.goldilocks_x448(s2.ctypes.data, pa.ctypes.data, b.ctypes.data) == -1
+    assert (s1 == s2).all()

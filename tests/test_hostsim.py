@@ -115,3 +115,24 @@ def test_verify(H, O):
             got = H.hs_ed448_verify(buf(sig), buf(pks[j].tobytes()), m, C.c_size_t(mlen), C.c_uint8(it & 1), c,
                                     C.c_uint8(len(ctx)), C.byref(base))
             assert got == want and (j or got == -1)
+
+
+def test_x448_and_signing(H, O):
+    tab = O.orc_precomputed_base()
+    rnd = random.Random(6)
+    rb = lambda n: bytes(rnd.getrandbits(8) for _ in range(n))
+    for it in range(12):
+        b = (bytes(56), b"\xff" * 56, bytes([5] + [0] * 55))[it] if it < 3 else rb(56)
+        s = rb(56)
+        o1, o2 = (C.c_uint8 * 56)(), (C.c_uint8 * 56)()
+        assert O.orc_x448(o1, buf(b), buf(s)) == H.hs_x448(o2, buf(b), buf(s)) and bytes(o1) == bytes(o2)
+        O.orc_x448_derive_public_key(o1, buf(s)); H.hs_x448_derive_public_key(o2, buf(s), tab)
+        assert bytes(o1) == bytes(o2)
+        sk, msg, ctx = rb(57), rb((0, 1, 70, 71, 126, 300)[it % 6]), rb((0, 3, 255)[it % 3])
+        p1, p2, s1, s2 = (C.c_uint8 * 57)(), (C.c_uint8 * 57)(), (C.c_uint8 * 114)(), (C.c_uint8 * 114)()
+        O.orc_ed448_derive_public_key(p1, buf(sk)); H.hs_ed448_derive_public_key(p2, buf(sk), tab)
+        assert bytes(p1) == bytes(p2)
+        m, c = (buf(msg) if msg else None), (buf(ctx) if ctx else None)
+        O.orc_ed448_sign(s1, buf(sk), p1, m, len(msg), it & 1, c, len(ctx))
+        H.hs_ed448_sign(s2, buf(sk), p1, m, C.c_size_t(len(msg)), C.c_uint8(it & 1), c, C.c_uint8(len(ctx)), tab)
+        assert bytes(s1) == bytes(s2)

@@ -153,3 +153,18 @@ def test_scalar_ops_against_python_ints(O):
             raw = bytes(rnd.getrandbits(8) for _ in range(n))
             O.orc_scalar_decode_long(C.byref(o), buf(raw), n)
             assert o.value() == int.from_bytes(raw, "little") % Q
+
+
+def test_x448_rfc7748_iterated(O):
+    """RFC 7748 section 5.2 iteration (reference test_goldilocks.cxx:545-552), 1 and 1000 rounds."""
+    kats = KATS["rfc7748_x448_iterated"]
+    u = k = bytes([5] + [0] * 55)
+    for i in range(1000):
+        out = (C.c_uint8 * 56)()
+        assert O.orc_x448(out, buf(u), buf(k)) == -1
+        u, k = k, bytes(out)
+        if i == 0:
+            assert k.hex() == kats["1"]
+    assert k.hex() == kats["1000"]
+    zero = (C.c_uint8 * 56)()
+    assert O.orc_x448(zero, buf(bytes(56)), buf(k)) == 0 and bytes(zero) == bytes(56)

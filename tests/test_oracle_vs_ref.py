@@ -80,3 +80,15 @@ def test_precompute_matches_reference(O):
     R.goldilocks_448_precompute(t1, C.byref(p))
     O.orc_precompute(C.byref(t2), C.byref(p))
     assert bytes(t1) == bytes(t2)
+
+
+def test_x448_differential(O):
+    R = ref()
+    rnd = random.Random(12)
+    for it in range(100):
+        b = bytes(rnd.getrandbits(8) for _ in range(56)) if it > 1 else (bytes(56), b"\xff" * 56)[it]
+        s = bytes(rnd.getrandbits(8) for _ in range(56))
+        o1, o2 = (C.c_uint8 * 56)(), (C.c_uint8 * 56)()
+        assert R.goldilocks_x448(o1, buf(b), buf(s)) == O.orc_x448(o2, buf(b), buf(s)) and bytes(o1) == bytes(o2)
+        R.goldilocks_x448_derive_public_key(o1, buf(s)); O.orc_x448_derive_public_key(o2, buf(s))
+        assert bytes(o1) == bytes(o2)
