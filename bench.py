@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="varbase", choices=["varbase", "fixed", "verify"])
+    ap.add_argument("--workload", default="varbase", choices=["varbase", "fixed", "verify", "sign", "x448"])
     return ap.parse_args()
 
 
@@ -129,6 +129,27 @@ def main():
     elif args.workload == "fixed":
         step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
         bytes_per_op, kernel = 312, "k_precomputed_scalarmul"
+    elif args.workload in ("sign", "x448"):
+        import _gen
+        nb = 57 if args.workload == "sign" else 56
+        sk = torch.from_numpy(np.frombuffer(_gen.stream(b"bench_%s_v1/%d/sk" % (args.workload.encode(), rank), nb * n),
+                                            np.uint8).reshape(n, nb).copy()).cuda()
+        if args.workload == "sign":
+            pk = torch.empty((n, 57), dtype=torch.uint8, device="cuda")
+            ga.dev("ed448_derive_public_key", pk.data_ptr(), sk.data_ptr(), n, None)
+            msg = torch.from_numpy(np.frombuffer(_gen.stream(b"bench_sign_v1/%d/msg" % rank, 32 * n), np.uint8)
+                                   .reshape(n, 32).copy()).cuda()
+            sig_out = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
+            step = lambda: ga.dev("ed448_sign", sig_out.data_ptr(), sk.data_ptr(), pk.data_ptr(), msg.data_ptr(), None,
+                                  32, 0, None, 0, n, stream)
+            bytes_per_op, kernel = 57 + 57 + 32 + 114, "k_ed448_sign"
+        else:
+            peer = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+            ga.dev("x448", peer.data_ptr(), None, None, sk.data_ptr(), n, None)     # public keys as peer inputs
+            shared = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+            st448 = torch.empty(n, dtype=torch.int32, device="cuda")
+            step = lambda: ga.dev("x448", shared.data_ptr(), st448.data_ptr(), peer.data_ptr(), sk.data_ptr(), n, stream)
+            bytes_per_op, kernel = 56 * 3 + 4, "k_x448"
     else:
         from _libs import oracle
         import _gen
@@ -169,7 +190,26 @@ def main():
     # parity spot check of what was just timed (not in the timed region)
     ok = True
     extra = {}
-    if rank == 0 and args.workload != "verify":
+    if rank == 0 and args.workload == "sign":
+        import _gen
+        from _libs import oracle
+        O = oracle()
+        sel = np.random.default_rng(1).integers(0, n, 64)
+        sk_h, pk_h, m_h, s_h = sk.cpu().numpy(), pk.cpu().numpy(), msg.cpu().numpy(), sig_out.cpu().numpy()
+        for i in sel:
+            w = (C.c_uint8 * 114)()
+            O.orc_ed448_sign(w, sk_h[i].ctypes.data, pk_h[i].ctypes.data, m_h[i].ctypes.data, 32, 0, None, 0)
+            ok = ok and bytes(w) == s_h[i].tobytes()
+    elif rank == 0 and args.workload == "x448":
+        from _libs import oracle
+        O = oracle()
+        sel = np.random.default_rng(1).integers(0, n, 64)
+        sk_h, p_h, o_h = sk.cpu().numpy(), peer.cpu().numpy(), shared.cpu().numpy()
+        for i in sel:
+            w = (C.c_uint8 * 56)()
+            O.orc_x448(w, p_h[i].ctypes.data, sk_h[i].ctypes.data)
+            ok = ok and bytes(w) == o_h[i].tobytes()
+    elif rank == 0 and args.workload != "verify":
         from _libs import oracle
         import _gen
         O = oracle()
@@ -204,14 +244,18 @@ def main():
         line = {
             "metric": {"varbase": "Ed448 variable-base scalarmuls/sec, batch=2^20",
                        "fixed": "Ed448 fixed-base scalarmuls/sec, batch=2^20",
-                       "verify": "Ed448 verifies/sec, batch=2^20"}[args.workload],
-            "value": value, "unit": "scalarmuls/s" if args.workload != "verify" else "verifies/s",
+                       "verify": "Ed448 verifies/sec, batch=2^20", "sign": "Ed448 signatures/sec, batch=2^20",
+                       "x448": "X448 shared secrets/sec, batch=2^20"}[args.workload],
+            "value": value, "unit": {"varbase": "scalarmuls/s", "fixed": "scalarmuls/s", "verify": "verifies/s",
+                                     "sign": "signatures/s", "x448": "shared secrets/s"}[args.workload],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": {"varbase": "goldilocks_448_point_scalarmul, variable base, random scalars",
                                     "fixed": "goldilocks_448_precomputed_scalarmul, base-point comb",
-                                    "verify": "goldilocks_ed448_verify, 32-byte messages, 1% corrupted"}[args.workload],
+                                    "verify": "goldilocks_ed448_verify, 32-byte messages, 1% corrupted",
+                                    "sign": "goldilocks_ed448_sign, 32-byte messages, no context",
+                                    "x448": "goldilocks_x448, random peer public keys"}[args.workload],
                        "batch_per_gpu": n, "sharding": "independent batch per GPU, no data-path collective",
                        "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],
                        "parity_spot_check": "ok" if ok else "FAILED"},

@@ -26,7 +26,7 @@ constexpr int BLOCK = 256;          // 4 waves: one per SIMD
 #define GD_WAVES_PER_SIMD 2
 #endif
 constexpr int WAVES_PER_SIMD = GD_WAVES_PER_SIMD;   // 2 blocks per CU -> 256-VGPR budget per lane
-constexpr int TABLE_U4 = 256;       // uint4 per lane window table (16 entries x 4 fe x 4 uint4)
+constexpr int TABLE_U4 = 17 * 16;    // uint4 per lane window table (16 entries + 1 build slot, x 4 fe x 4 uint4)
 constexpr int PRECOMP_U4 = 80 * 20 + 64;  // uint4 per lane for k_precompute: 80 x 5 fe + 4 doubled teeth
 
 // ---------------------------------------------------------------- register <-> memory

@@ -11,7 +11,8 @@
 // (a) instantiated by the HIP kernels with HBM/LDS-backed storage and (b) run on
 // the host by tests/hostsim with plain arrays (checker only, never shipped):
 //   BITS  : bits.word(k) -> k-th 32-bit word of s' (k < 15, word 14 is zero)
-//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table
+//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table (17 slots:
+//           16 entries + one scratch slot used while the table is built)
 #pragma once
 #include "point.hpp"
 #include "sc14.hpp"
@@ -35,16 +36,18 @@ GD_FN void signed_digit(uint32_t w, uint32_t &idx, bool &neg) {
 }
 
 // multiples[k] = (2k+1)*B, k < 16, as projective niels (src/goldilocks.c:382-403).
+// The step 2B is parked in slot 16 of the lane's table memory and re-read every iteration, as the
+// ladder re-reads its entries: holding it in registers next to the accumulator spills.
 template <class TABLE>
 GD_FN void build_window_table(TABLE &table, const pt &b) {
     pt twice = b;
     pt_double(twice, true);
-    pniels step = pt_to_pniels(twice);
+    table.store(16, pt_to_pniels(twice));
     table.store(0, pt_to_pniels(b));
     pt acc = b;
 #pragma unroll 1
     for (int k = 1; k < 16; k++) {
-        pt_add_pniels(acc, step, false, true);
+        pt_add_pniels(acc, table.load(16), false, true);
         table.store(k, pt_to_pniels(acc));
     }
 }
