@@ -109,6 +109,39 @@ DEF_KERNEL(k_mix_mac_lshladd, uint64_t, "v_mad_u64_u32 %0, vcc, %8, %9, %0", "v_
            "v_mad_u64_u32 %1, vcc, %8, %9, %1", "v_lshl_add_u64 %5, %5, 0, %6", "v_mad_u64_u32 %2, vcc, %8, %9, %2",
            "v_lshl_add_u64 %6, %6, 0, %7", "v_mad_u64_u32 %3, vcc, %8, %9, %3", "v_lshl_add_u64 %7, %7, 0, %4")
 
+// Does the order matter?  Same 16 MACs + 16 simple ops per block on independent registers,
+// (a) strictly alternating, (b) clustered in runs of 8, (c) clustered in runs of 16.
+#define MIXK(NAME, BODY)                                                                           \
+    template <int K>                                                                               \
+    __global__ void __launch_bounds__(256) NAME(uint64_t *out, uint32_t a0, uint32_t b0,           \
+                                                unsigned long long *cyc) {                         \
+        uint64_t m0, m1, m2, m3;                                                                   \
+        uint32_t s0, s1, s2, s3;                                                                   \
+        uint32_t a = a0 + threadIdx.x, b = b0 ^ threadIdx.x;                                       \
+        m0 = a; m1 = a * 2; m2 = a * 3; m3 = a * 4; s0 = b; s1 = b * 3; s2 = b * 5; s3 = b * 7;     \
+        unsigned long long t0 = __builtin_readcyclecounter();                                      \
+        for (int it = 0; it < ITERS; it++) {                                                       \
+            asm volatile(BODY : "+v"(m0), "+v"(m1), "+v"(m2), "+v"(m3), "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3) \
+                         : "v"(a), "v"(b) : "vcc");                                                \
+        }                                                                                          \
+        unsigned long long t1 = __builtin_readcyclecounter();                                      \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = m0 ^ m1 ^ m2 ^ m3 ^ s0 ^ s1 ^ s2 ^ s3;        \
+        if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;                                           \
+    }
+#define M0 "v_mad_u64_u32 %0, vcc, %8, %9, %0\n"
+#define M1 "v_mad_u64_u32 %1, vcc, %8, %9, %1\n"
+#define M2 "v_mad_u64_u32 %2, vcc, %8, %9, %2\n"
+#define M3 "v_mad_u64_u32 %3, vcc, %8, %9, %3\n"
+#define S0 "v_add_u32_e32 %4, %8, %4\n"
+#define S1 "v_and_b32_e32 %5, %9, %5\n"
+#define S2 "v_add_u32_e32 %6, %8, %6\n"
+#define S3 "v_lshrrev_b32_e32 %7, 1, %7\n"
+MIXK(k_ord_alternating, ".rept 4\n" M0 S0 M1 S1 M2 S2 M3 S3 "\n.endr")
+MIXK(k_ord_runs_of_4, ".rept 4\n" M0 M1 M2 M3 S0 S1 S2 S3 "\n.endr")
+MIXK(k_ord_runs_of_16, ".rept 4\n" M0 M1 M2 M3 "\n.endr\n.rept 4\n" S0 S1 S2 S3 "\n.endr")
+MIXK(k_ord_mac_only16, ".rept 4\n" M0 M1 M2 M3 "\n.endr")
+MIXK(k_ord_simple_only16, ".rept 4\n" S0 S1 S2 S3 "\n.endr")
+
 typedef void (*kern_t)(uint64_t *, uint32_t, uint32_t, unsigned long long *);
 
 struct Entry {
@@ -127,7 +160,8 @@ int main(int argc, char **argv) {
                     ENT(k_and_b32), ENT(k_and_or_b32), ENT(k_bfe_u32), ENT(k_lshrrev_b32), ENT(k_alignbit_b32),
                     ENT(k_add_co_u32), ENT(k_addc_co_u32), ENT(k_mov_b32), ENT(k_lshl_add_u64), ENT(k_lshrrev_b64),
                     ENT(k_fma_f32), ENT(k_pk_fma_f32), ENT(k_fma_f64), ENT(k_mix_mac_add), ENT(k_mix_mac3_add),
-                    ENT(k_mix_mac_lshladd)};
+                    ENT(k_mix_mac_lshladd), ENT(k_ord_alternating), ENT(k_ord_runs_of_4),
+                    ENT(k_ord_runs_of_16), ENT(k_ord_mac_only16), ENT(k_ord_simple_only16)};
     uint64_t *out;
     unsigned long long *cyc;
     const int max_blocks = cus * 8;
