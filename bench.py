@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="varbase", choices=["varbase", "fixed", "verify", "sign", "x448"])
+    ap.add_argument("--workload", default="varbase", choices=["varbase", "fixed", "base", "verify", "sign", "x448"])
     return ap.parse_args()
 
 
@@ -126,9 +126,13 @@ def main():
     if args.workload == "varbase":
         step = lambda: ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, stream)
         bytes_per_op, kernel = BYTES_PER_OP, "k_point_scalarmul"
-    elif args.workload == "fixed":
-        step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
+    elif args.workload == "fixed":     # BASELINE config 3: caller's precomputed_s -> the 5x5x18 comb staged in LDS
+        comb_tab = torch.from_numpy(ga.precomputed_base().view(np.int64)).cuda()
+        step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), comb_tab.data_ptr(), scalars.data_ptr(), n, stream)
         bytes_per_op, kernel = 312, "k_precomputed_scalarmul"
+    elif args.workload == "base":      # the built-in base point: 8-bit window table (no doublings)
+        step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
+        bytes_per_op, kernel = 312, "k_base_scalarmul"
     elif args.workload in ("sign", "x448"):
         import _gen
         nb = 57 if args.workload == "sign" else 56
@@ -244,15 +248,17 @@ def main():
         line = {
             "metric": {"varbase": "Ed448 variable-base scalarmuls/sec, batch=2^20",
                        "fixed": "Ed448 fixed-base scalarmuls/sec, batch=2^20",
+                       "base": "Ed448 base-point scalarmuls/sec, batch=2^20",
                        "verify": "Ed448 verifies/sec, batch=2^20", "sign": "Ed448 signatures/sec, batch=2^20",
                        "x448": "X448 shared secrets/sec, batch=2^20"}[args.workload],
-            "value": value, "unit": {"varbase": "scalarmuls/s", "fixed": "scalarmuls/s", "verify": "verifies/s",
+            "value": value, "unit": {"varbase": "scalarmuls/s", "fixed": "scalarmuls/s", "base": "scalarmuls/s", "verify": "verifies/s",
                                      "sign": "signatures/s", "x448": "shared secrets/s"}[args.workload],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": {"varbase": "goldilocks_448_point_scalarmul, variable base, random scalars",
-                                    "fixed": "goldilocks_448_precomputed_scalarmul, base-point comb",
+                                    "fixed": "goldilocks_448_precomputed_scalarmul, 5x5x18 comb table staged in LDS",
+                                    "base": "goldilocks_448_precomputed_scalarmul(precomputed_base), 8-bit window table",
                                     "verify": "goldilocks_ed448_verify, 32-byte messages, 1% corrupted",
                                     "sign": "goldilocks_ed448_sign, 32-byte messages, no context",
                                     "x448": "goldilocks_x448, random peer public keys"}[args.workload],

@@ -193,11 +193,13 @@ GD_FN void load_bytes_as_words(uint32_t *w, const uint8_t *p, int nbytes, int nw
     }
 }
 
-// BT: window table of the base point (shared, read-only).  AT: this lane's table,
-// filled here.  STAGE/BITS: see above; `mkbits(sc)` turns a recoded scalar into a
-// BITS reader (LDS-backed on the device).
-template <class BT, class AT, class STAGE, class MKBITS>
-GD_FN bool ed448_verify_core(const Ed448Msg &m, const BT &base_tab, AT &a_tab, STAGE &stage, MKBITS &mkbits) {
+// FB: fixed-base multiplier for the base point (FixedComb / FixedBwt).  AT: this lane's window
+// table, filled here.  STAGE: sponge block; `mkbits(sc, slot)` turns a recoded scalar into a BITS
+// reader (LDS-backed on the device).  The two halves S*B and (-h)*A are computed separately --
+// fixed-base table for one, signed-window ladder for the other -- and added: fewer field
+// multiplications than interleaving them on one doubling chain, and no lane divergence.
+template <class FB, class AT, class STAGE, class MKBITS>
+GD_FN bool ed448_verify_core(const Ed448Msg &m, const FB &fb, AT &a_tab, STAGE &stage, MKBITS &mkbits) {
     uint32_t w[29];
     pt A, R;
     load_bytes_as_words(w, m.b, 57, 15);          // public key
@@ -211,9 +213,10 @@ GD_FN bool ed448_verify_core(const Ed448Msg &m, const BT &base_tab, AT &a_tab, S
     sc response = sc_decode_long_words<57>(w);                        // S mod q, no range check
 
     build_window_table(a_tab, A);
-    auto bits_s = mkbits(sc_recode_signed(response), 0);
     auto bits_c = mkbits(sc_recode_signed(challenge), 1);
-    pt P = ladder_double(bits_s, base_tab, bits_c, a_tab);            // S*B - h*A
+    pt hA = ladder_varbase(bits_c, a_tab);                            // -h*A
+    pt sB = fb.mul(response, mkbits);                                 // S*B
+    pt P = pt_add(hA, sB, false);
     return ok && pt_eq(P, R);
 }
 
@@ -230,8 +233,8 @@ GD_FN void store_words_as_bytes(uint8_t *p, const uint32_t *w, int nbytes) {
 }
 
 // pk = encode_like_eddsa( (clamp(SHAKE256(sk)[0:57]) / 4) * B )      src/eddsa.c:98-147
-template <class COMB, class STAGE, class MKBITS>
-GD_FN void ed448_derive_core(uint8_t *pk57, const uint8_t *sk57, const COMB &comb, STAGE &stage, MKBITS &mkbits) {
+template <class FB, class STAGE, class MKBITS>
+GD_FN void ed448_derive_core(uint8_t *pk57, const uint8_t *sk57, const FB &fb, STAGE &stage, MKBITS &mkbits) {
     Ed448Msg m;
     m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
     m.ctx = sk57; m.ctxlen = 0; m.ph = 0; m.dom = false;
@@ -240,8 +243,7 @@ GD_FN void ed448_derive_core(uint8_t *pk57, const uint8_t *sk57, const COMB &com
     ed448_clamp_words(w);
     sc secret = sc_decode_long_words<57>(w);
     secret = sc_halve(sc_halve(secret));                       // ENCODE_RATIO = 4
-    auto bits = mkbits(sc_recode_signed(secret), 0);
-    pt p = ladder_comb(bits, comb);
+    pt p = fb.mul(secret, mkbits);
     uint32_t e[15];
     pt_encode_eddsa_words(e, p);
     store_words_as_bytes(pk57, e, 57);
@@ -249,10 +251,10 @@ GD_FN void ed448_derive_core(uint8_t *pk57, const uint8_t *sk57, const COMB &com
 
 // RFC 8032 signing (src/eddsa.c:149-230).  scratch: 64 bytes of lane-private memory for the
 // hashed-key seed.  sig114 doubles as the place R is read back from for the challenge hash.
-template <class COMB, class STAGE, class MKBITS>
+template <class FB, class STAGE, class MKBITS>
 GD_FN void ed448_sign_core(uint8_t *sig114, const uint8_t *sk57, const uint8_t *pk57, const uint8_t *msg,
                            uint32_t msglen, uint32_t ph, const uint8_t *ctx, uint32_t ctxlen, uint8_t *scratch,
-                           const COMB &comb, STAGE &stage, MKBITS &mkbits) {
+                           const FB &fb, STAGE &stage, MKBITS &mkbits) {
     Ed448Msg m;
     m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
     m.ctx = ctx; m.ctxlen = 0; m.ph = 0; m.dom = false;
@@ -270,8 +272,7 @@ GD_FN void ed448_sign_core(uint8_t *sig114, const uint8_t *sk57, const uint8_t *
     m.ctx = ctx; m.ctxlen = ctxlen; m.ph = ph ? 1u : 0u; m.dom = true;
     shake256_114(w, m, m.total(), stage);
     sc nonce = sc_decode_long_words<114>(w);
-    auto bits = mkbits(sc_recode_signed(sc_halve(sc_halve(nonce))), 0);
-    pt rp = ladder_comb(bits, comb);
+    pt rp = fb.mul(sc_halve(sc_halve(nonce)), mkbits);
     uint32_t e[15];
     pt_encode_eddsa_words(e, rp);
     store_words_as_bytes(sig114, e, 57);
@@ -309,9 +310,9 @@ struct HostMkBits {
         return b;
     }
 };
-template <class BT, class AT>
+template <class FB, class AT>
 static inline bool ed448_verify_lane(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen,
-                                     uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const BT &bt, AT &at) {
+                                     uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const FB &bt, AT &at) {
     Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
     HostStage stage;
     HostMkBits mk;

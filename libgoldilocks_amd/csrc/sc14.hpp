@@ -23,6 +23,9 @@ GD_CONST uint32_t SC_R2[14] = {0x049b9b60u, 0xe3539257u, 0xc1b195d9u, 0x7af32c4b
 // (2^450 - 1) mod q: signed-window recoding offset (src/goldilocks.c:33-37)
 GD_CONST uint32_t SC_ADJ[14] = {0x4a7bb0cfu, 0xc873d6d5u, 0x23a70aadu, 0xe933d8d7u, 0x129c96fdu,
                                 0xbb124b65u, 0x335dc163u, 0x00000008u, 0, 0, 0, 0, 0, 0};
+// (2^448 - 1) mod q: the same recoding for 56 signed 8-bit windows (fixed-base window table)
+GD_CONST uint32_t SC_ADJ8[14] = {0x529eec33u, 0x721cf5b5u, 0xc8e9c2abu, 0x7a4cf635u, 0x44a725bfu,
+                                 0xeec492d9u, 0x0cd77058u, 0x00000002u, 0, 0, 0, 0, 0, 0};
 // -q^-1 mod 2^32 (low word of src/scalar.c:17 MONTGOMERY_FACTOR)
 constexpr uint32_t SC_MONT32 = 0xae918bc5u;
 
@@ -135,5 +138,9 @@ GD_FN sc sc_reduce(const sc &a) {
 // s' = (s + 2^450 - 1)/2 mod q: recoding for signed fixed windows
 // (src/goldilocks.c:420-421 and :842-843).
 GD_FN sc sc_recode_signed(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_ADJ))); }
+
+// W = (s + 2^448 - 1)/2 mod q: its 56 bytes w_i encode s = sum (2 w_i - 255) 256^i, odd digits in
+// [-255, 255] (same derivation as above with 8-bit windows: sum 255*256^i = 2^448 - 1).
+GD_FN sc sc_recode_signed8(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_ADJ8))); }
 
 }  // namespace gd

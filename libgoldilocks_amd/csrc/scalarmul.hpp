@@ -107,6 +107,52 @@ GD_FN pt ladder_comb(const BITS &bits, const COMB &comb) {
     return acc;
 }
 
+// Fixed-base, no doublings: s*B = sum_i (+-) T_i[idx_i] over the 56 signed 8-bit digits of
+// W = sc_recode_signed8(s), with T_i[k] = (2k+1) * 256^i * B as affine niels (56 x 128 entries,
+// 1.3 MiB, built once per device and L2-resident).  55 mixed additions instead of the comb's
+// 17 doublings + 89 additions.  The reference has no such table; results are the same group
+// element (parity is on encodings).  BWT: bwt.load(i, idx) -> niels.
+template <class BITS>
+GD_FN uint32_t window8(const BITS &bits, int i) { return (bits.word(i >> 2) >> (8 * (i & 3))) & 255u; }
+GD_FN void signed_digit8(uint32_t w, uint32_t &idx, bool &neg) {
+    neg = w < 128;
+    idx = (neg ? ~w : w) & 127u;
+}
+template <class BITS, class BWT>
+GD_FN pt ladder_bwt(const BITS &bits, const BWT &bwt) {
+    uint32_t idx;
+    bool neg;
+    signed_digit8(window8(bits, 55), idx, neg);
+    pt acc = niels_to_pt(bwt.load(55, idx), neg);
+#pragma unroll 1
+    for (int i = 54; i >= 0; i--) {
+        signed_digit8(window8(bits, i), idx, neg);
+        pt_add_niels(acc, bwt.load(i, idx), neg, true);
+    }
+    return acc;
+}
+
+// Fixed-base multiplication behind one interface, so that sign / derive / verify do not care which
+// table serves the base point.  MK: mk(recoded scalar, slot) -> BITS (LDS-backed on the device).
+template <class COMB>
+struct FixedComb {
+    const COMB &comb;
+    template <class MK>
+    GD_MFN pt mul(const sc &s, MK &mk) const {
+        auto bits = mk(sc_recode_signed(s), 0);
+        return ladder_comb(bits, comb);
+    }
+};
+template <class BWT>
+struct FixedBwt {
+    const BWT &bwt;
+    template <class MK>
+    GD_MFN pt mul(const sc &s, MK &mk) const {
+        auto bits = mk(sc_recode_signed8(s), 0);
+        return ladder_bwt(bits, bwt);
+    }
+};
+
 // out = s1*P1 + s2*P2, both through 16-entry window tables (src/goldilocks.c:467-541).
 template <class BITS, class TABLE1, class TABLE2>
 GD_FN pt ladder_double(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2) {

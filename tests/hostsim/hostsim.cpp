@@ -36,6 +36,19 @@ struct HostComb {
     niels e[80];
     niels load(int j, uint32_t idx) const { return e[16 * j + idx]; }
 };
+struct HostBwt {
+    niels *e;  // 56 * 128
+    niels load(int i, uint32_t idx) const { return e[128 * i + idx]; }
+};
+// affine niels of a point in our convention: ((Y-X)/(2Z), (Y+X)/(2Z), 78164*T/(2Z))
+niels host_affine_niels(const pt &p) {
+    fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
+    niels n;
+    n.a = fe_mul(fe_weak(fe_sub<2>(p.y, p.x)), zi);
+    n.b = fe_mul(fe_weak(fe_add(p.x, p.y)), zi);
+    n.cn = fe_mul(fe_mulw(p.t, TWO_EFF_D), zi);
+    return n;
+}
 void words_to_bytes(uint8_t *out, const uint32_t *w, int nbytes) {
     for (int i = 0; i < nbytes; i++) out[i] = (uint8_t)(w[i / 4] >> (8 * (i % 4)));
 }
@@ -163,11 +176,12 @@ void hs_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen) {
     h.squeeze(out, outlen);
 }
 int hs_ed448_verify(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen, uint8_t prehashed,
-                    const uint8_t *ctx, uint8_t ctxlen, const uint64_t *base_point) {
-    HostTable tb;  // fixed-base window table built on the fly (the device keeps it staged)
-    build_window_table(tb, pt_from_abi(base_point));
+                    const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
+    static HostComb comb;   // the device serves the base point from its 8-bit window table instead
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    FixedComb<HostComb> fb{comb};
     HostTable ta;
-    return ed448_verify_lane(sig, pk, msg, msglen, prehashed, ctx, ctxlen, tb, ta) ? -1 : 0;
+    return ed448_verify_lane(sig, pk, msg, msglen, prehashed, ctx, ctxlen, fb, ta) ? -1 : 0;
 }
 
 void hs_ed448_derive_public_key(uint8_t *pk, const uint8_t *sk, const uint64_t *comb_table) {
@@ -175,7 +189,8 @@ void hs_ed448_derive_public_key(uint8_t *pk, const uint8_t *sk, const uint64_t *
     for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
     HostStage stage;
     HostMkBits mk;
-    ed448_derive_core(pk, sk, comb, stage, mk);
+    FixedComb<HostComb> fb{comb};
+    ed448_derive_core(pk, sk, fb, stage, mk);
 }
 void hs_ed448_sign(uint8_t *sig, const uint8_t *sk, const uint8_t *pk, const uint8_t *msg, size_t msglen,
                    uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
@@ -184,7 +199,8 @@ void hs_ed448_sign(uint8_t *sig, const uint8_t *sk, const uint8_t *pk, const uin
     HostStage stage;
     HostMkBits mk;
     uint8_t scratch[64];
-    ed448_sign_core(sig, sk, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen, scratch, comb, stage, mk);
+    FixedComb<HostComb> fb{comb};
+    ed448_sign_core(sig, sk, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen, scratch, fb, stage, mk);
 }
 
 int hs_x448(uint8_t *out, const uint8_t *base, const uint8_t *scalar) {
@@ -204,6 +220,35 @@ void hs_x448_derive_public_key(uint8_t *out, const uint8_t *scalar, const uint64
     HostBits bits = make_bits(x448_public_scalar(w));
     pt_encode_x448_words(o, ladder_comb(bits, comb));
     words_to_bytes(out, o, 56);
+}
+
+// s*B through the 56 x 128 window table, the table being built here from the comb (slow; test only)
+void hs_bwt_scalarmul(uint64_t *out, const uint64_t *comb_table, const uint64_t *scalars, int n) {
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    static niels tab[56 * 128];
+    static bool built = false;
+    if (!built) {
+        for (int i = 0; i < 56; i++)
+            for (int k = 0; k < 128; k++) {
+                sc v = sc_zero();
+                uint32_t m = 2 * k + 1;               // (2k+1) << 8i as a 448-bit value
+                int bit = 8 * i;
+                v.w[bit >> 5] |= m << (bit & 31);
+                if ((bit & 31) > 23 && (bit >> 5) + 1 < 14) v.w[(bit >> 5) + 1] |= m >> (32 - (bit & 31));
+                HostBits b = make_bits(sc_reduce(v));
+                tab[128 * i + k] = host_affine_niels(ladder_comb(b, comb));
+            }
+        built = true;
+    }
+    HostBwt bwt{tab};
+    for (int j = 0; j < n; j++) {
+        sc r = sc_recode_signed8(sc_from_abi(scalars + 7 * j));
+        HostBits b;
+        for (int i = 0; i < 14; i++) b.w[i] = r.w[i];
+        b.w[14] = 0;
+        pt_to_abi(out + 32 * j, ladder_bwt(b, bwt));
+    }
 }
 
 }  // extern "C"

@@ -101,7 +101,7 @@ def test_ladders_and_codecs(H, O):
 
 
 def test_verify(H, O):
-    base = O.orc_point_base().contents
+    base = O.orc_precomputed_base().contents
     rnd = random.Random(5)
     for it, mlen in enumerate((0, 1, 32, 125, 126, 136, 300)):
         ctx = bytes(rnd.getrandbits(8) for _ in range((0, 3, 255)[it % 3]))
@@ -136,3 +136,14 @@ def test_x448_and_signing(H, O):
         O.orc_ed448_sign(s1, buf(sk), p1, m, len(msg), it & 1, c, len(ctx))
         H.hs_ed448_sign(s2, buf(sk), p1, m, C.c_size_t(len(msg)), C.c_uint8(it & 1), c, C.c_uint8(len(ctx)), tab)
         assert bytes(s1) == bytes(s2)
+
+
+def test_fixed_base_window_table_ladder(H, O):
+    """The 56 x 128 signed 8-bit window table (the device's fast path for the base point)."""
+    H.hs_bwt_scalarmul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    n = 24
+    s = _gen.random_scalars(n, b"hs-bwt")
+    s[:6] = _gen.scalars_from_ints([0, 1, Q - 1, 2**445, 2, 255])
+    out = np.empty((n, 32), np.uint64)
+    H.hs_bwt_scalarmul(out.ctypes.data, C.cast(O.orc_precomputed_base(), C.c_void_p), s.ctypes.data, n)
+    assert (_gen.oracle_encode(out) == _gen.oracle_encode(_gen.oracle_fixed(O, s))).all()
