@@ -231,7 +231,7 @@ def main():
             digest = hashlib.shake_256(ser.cpu().numpy().tobytes()).hexdigest(32)
             ok = ok and digest == json.load(open(dig_path))["digest_shake256_32"][str(args.log2_batch)]
             extra["full_batch_digest"] = {"shake256_32": digest, "matches_reference_fixture": ok}
-        if not args.no_cpu_baseline and args.workload == "varbase":
+        if not args.no_cpu_baseline and args.workload == "varbase" and world == 1:   # rank 0 at N=1 only
             extra["cpu_baseline"], _, _ = cpu_baseline(np, b_h, s_h)
     elif rank == 0:
         ok = abs(int((status == -1).sum()) - int((~bad).sum())) == 0
