@@ -163,6 +163,17 @@ GOLDILOCKS_AMD_API void goldilocks_ed448_sign(
         const uint8_t *message, size_t message_len, uint8_t prehashed,
         const uint8_t *context, uint8_t context_len);
 
+/* --- "next" row f4: one base / two scalars, and Elligator 2 hash-to-curve --- */
+/* a1 = scalar1*base1, a2 = scalar2*base1.  ref: point_448.h:517-523, src/goldilocks.c:543-642 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_dual_scalarmul(goldilocks_448_point_p a1, goldilocks_448_point_p a2,
+        const goldilocks_448_point_p base1, const goldilocks_448_scalar_p scalar1,
+        const goldilocks_448_scalar_p scalar2);
+/* Elligator 2 map of one 56-byte string / sum of the maps of two.  ref: point_448.h:647-677, src/elligator.c:32-94 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_from_hash_nonuniform(goldilocks_448_point_p pt,
+        const unsigned char hashed_data[GOLDILOCKS_448_SER_BYTES]);
+GOLDILOCKS_AMD_API void goldilocks_448_point_from_hash_uniform(goldilocks_448_point_p pt,
+        const unsigned char hashed_data[2 * GOLDILOCKS_448_SER_BYTES]);
+
 /* --- "next" row f3: X448 (RFC 7748) --- */
 #define GOLDILOCKS_X448_PUBLIC_BYTES 56   /* ref: point_448.h:60 */
 #define GOLDILOCKS_X448_PRIVATE_BYTES 56  /* ref: point_448.h:63 */
@@ -211,6 +222,12 @@ GOLDILOCKS_AMD_API int goldilocks_448_direct_scalarmul_batch(uint8_t *scaled /* 
         goldilocks_error_t *status, const uint8_t *base /* n*56 */, const goldilocks_448_scalar_s *scalar,
         goldilocks_bool_t allow_identity, goldilocks_bool_t short_circuit, size_t n);
 
+GOLDILOCKS_AMD_API int goldilocks_448_point_dual_scalarmul_batch(goldilocks_448_point_s *a1,
+        goldilocks_448_point_s *a2, const goldilocks_448_point_s *base, const goldilocks_448_scalar_s *scalar1,
+        const goldilocks_448_scalar_s *scalar2, size_t n);
+/* uniform == 0: n*56 bytes in; otherwise n*112 */
+GOLDILOCKS_AMD_API int goldilocks_448_point_from_hash_batch(goldilocks_448_point_s *pt,
+        const uint8_t *hashed_data, int uniform, size_t n);
 /* status[i] = goldilocks_x448(shared[i], base[i], scalar[i]); base == NULL: the base point (derive_public_key) */
 GOLDILOCKS_AMD_API int goldilocks_x448_batch(uint8_t *shared /* n*56 */, goldilocks_error_t *status,
         const uint8_t *base /* n*56 or NULL */, const uint8_t *scalar /* n*56 */, size_t n);
@@ -274,6 +291,10 @@ GOLDILOCKS_AMD_API int goldilocks_amd_direct_scalarmul_dev(void *scaled /* n*56 
         const void *base /* n*56 */, const void *scalar, int allow_identity, int short_circuit, size_t n,
         void *stream);
 
+GOLDILOCKS_AMD_API int goldilocks_amd_point_dual_scalarmul_dev(void *a1, void *a2, const void *base,
+        const void *scalar1, const void *scalar2, size_t n, void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_point_from_hash_dev(void *pt, const void *hashed_data, int uniform,
+        size_t n, void *stream);
 /* base == NULL: x448_derive_public_key for every lane (status all success); status: int32[n] or NULL */
 GOLDILOCKS_AMD_API int goldilocks_amd_x448_dev(void *shared /* n*56 */, void *status, const void *base,
         const void *scalar /* n*56 */, size_t n, void *stream);

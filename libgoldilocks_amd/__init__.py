@@ -47,6 +47,9 @@ FUNCTIONS = {
     "goldilocks_448_point_double": (None, "pp"),
     "goldilocks_ed448_verify": (C.c_int, "pppzBpB"),
     "goldilocks_ed448_derive_public_key": (None, "pp"),
+    "goldilocks_448_point_dual_scalarmul": (None, "ppppp"),
+    "goldilocks_448_point_from_hash_nonuniform": (None, "pp"),
+    "goldilocks_448_point_from_hash_uniform": (None, "pp"),
     "goldilocks_x448": (C.c_int, "ppp"),
     "goldilocks_x448_derive_public_key": (None, "pp"),
     "goldilocks_ed448_sign": (None, "ppppzBpB"),
@@ -63,6 +66,8 @@ FUNCTIONS = {
     "goldilocks_ed448_sign_batch": (C.c_int, "pppppBpBz"),
     "goldilocks_448_direct_scalarmul_batch": (C.c_int, "ppppQQz"),
     "goldilocks_x448_batch": (C.c_int, "ppppz"),
+    "goldilocks_448_point_dual_scalarmul_batch": (C.c_int, "pppppz"),
+    "goldilocks_448_point_from_hash_batch": (C.c_int, "ppiz"),
     # (3) device-array API
     "goldilocks_amd_init": (C.c_int, "i"),
     "goldilocks_amd_shutdown": (None, ""),
@@ -85,6 +90,8 @@ FUNCTIONS = {
     "goldilocks_amd_ed448_sign_dev": (C.c_int, "pppppzBpBzp"),
     "goldilocks_amd_direct_scalarmul_dev": (C.c_int, "ppppiizp"),
     "goldilocks_amd_x448_dev": (C.c_int, "ppppzp"),
+    "goldilocks_amd_point_dual_scalarmul_dev": (C.c_int, "pppppzp"),
+    "goldilocks_amd_point_from_hash_dev": (C.c_int, "ppizp"),
 }
 DATA_SYMBOLS = [
     "goldilocks_448_sizeof_precomputed_s", "goldilocks_448_alignof_precomputed_s",
@@ -289,6 +296,23 @@ def direct_scalarmul_batch(bases56, scalars, allow_identity=False, short_circuit
                                                        2**64 - 1 if allow_identity else 0,
                                                        2**64 - 1 if short_circuit else 0, n))
     return out, st
+
+
+def point_dual_scalarmul_batch(bases, scalars1, scalars2):
+    bases, scalars1, scalars2 = _u64(bases, 32), _u64(scalars1, 7), _u64(scalars2, 7)
+    n = len(bases)
+    o1, o2 = np.empty((n, 32), dtype=np.uint64), np.empty((n, 32), dtype=np.uint64)
+    _check(lib().goldilocks_448_point_dual_scalarmul_batch(_ptr(o1), _ptr(o2), _ptr(bases), _ptr(scalars1),
+                                                           _ptr(scalars2), n))
+    return o1, o2
+
+
+def point_from_hash_batch(hashes, uniform=False):
+    """Elligator 2: uint8 [n, 56] (nonuniform) or [n, 112] (uniform) -> points."""
+    hashes = _u8(hashes, 112 if uniform else 56)
+    out = np.empty((len(hashes), 32), dtype=np.uint64)
+    _check(lib().goldilocks_448_point_from_hash_batch(_ptr(out), _ptr(hashes), 1 if uniform else 0, len(hashes)))
+    return out
 
 
 def x448_batch(scalars56, bases56=None):

@@ -386,6 +386,44 @@ GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__
     }
 }
 
+// "next" row f4: (s1*B, s2*B) for one base   (ref: goldilocks_448_point_dual_scalarmul)
+GD_KERNEL k_point_dual_scalarmul(uint64_t *__restrict__ out1, uint64_t *__restrict__ out2,
+                                 const uint64_t *__restrict__ base, const uint64_t *__restrict__ s1,
+                                 const uint64_t *__restrict__ s2, uint32_t n, uint4 *__restrict__ workspace) {
+    __shared__ uint32_t s_bits[30 * BLOCK];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    LaneTable tab{workspace + (size_t)lane * TABLE_U4};
+    for (uint32_t i = lane; i < n; i += stride) {
+        LdsBits b1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(s1 + 7 * (size_t)i)));
+        LdsBits b2 = lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_signed(sc_load_abi(s2 + 7 * (size_t)i)));
+        build_window_table(tab, pt_load_abi(base + 32 * (size_t)i));
+        pt r1, r2;
+        ladder_dual(r1, r2, b1, b2, tab);
+        pt_store_abi(out1 + 32 * (size_t)i, r1);
+        pt_store_abi(out2 + 32 * (size_t)i, r2);
+    }
+}
+
+// "next" row f4: Elligator 2 hash-to-curve   (ref: goldilocks_448_point_from_hash_nonuniform / _uniform)
+GD_KERNEL k_point_from_hash(uint64_t *__restrict__ out, const uint8_t *__restrict__ hash, uint32_t n, int uniform) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t nb = uniform ? 112 : 56;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        uint32_t w[14];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(hash + (size_t)nb * i);   // 56 | nb: 8-byte aligned
+#pragma unroll
+        for (int k = 0; k < 14; k++) w[k] = src[k];
+        pt p = pt_from_hash_words(w);
+        if (uniform) {
+#pragma unroll
+            for (int k = 0; k < 14; k++) w[k] = src[14 + k];
+            p = pt_add(p, pt_from_hash_words(w), false);
+        }
+        pt_store_abi(out + 32 * (size_t)i, p);
+    }
+}
+
 // "next" row f3: X448.  base == nullptr: derive_public_key through the comb   (ref: goldilocks_x448*)
 GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
                  const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt) {

@@ -236,6 +236,39 @@ GD_FN bool pt_decode_eddsa_words(pt &p, const uint32_t in[15]) {
     return ok;
 }
 
+// Elligator 2 hash-to-curve, one 56-byte string -> point ("next" row f4; src/elligator.c:32-83).
+GD_FN pt pt_from_hash_words(const uint32_t in[14]) {
+    fe r0;
+    (void)fe_deserialize_words(r0, in);                  // any 448-bit string (reduced mod p below)
+    r0 = fe_strong(r0);
+    fe r = fe_weak(fe_neg(fe_sqr(r0)));                  // r = -r0^2 (qnr = -1)
+    fe rm1 = fe_weak(fe_sub<2>(r, fe_one()));            // r - 1
+    fe drd = fe_weak(fe_neg(fe_mulw(rm1, NEG_EDWARDS_D)));   // d r - d, d = -39081
+    fe a = fe_add(drd, fe_one());                        // mag 2
+    fe b = fe_weak(fe_sub<2>(drd, r));
+    fe D = fe_mul(a, b);                                 // (dr - d + 1)(dr - d - r)
+    fe N = fe_mulw(fe_add(r, fe_one()), 78163);          // (r + 1)(1 - 2d)
+    bool square;
+    fe isr = fe_isr(fe_mul(D, N), &square);
+    fe e = fe_mul(isr, fe_select(r0, fe_one(), square));
+    fe s = fe_mul(N, e);
+    s = fe_weak(fe_cond_neg(s, fe_lobit(s) != !square)); // negate iff lobit(s) ^ ~square
+    fe c = fe_mulw(e, 78163);
+    fe t = fe_mul(fe_mul(fe_sqr(c), rm1), N);
+    t = fe_weak(fe_cond_neg(t, square));
+    t = fe_weak(fe_sub<2>(t, fe_one()));
+    fe s2 = fe_sqr(s);
+    fe two_s = fe_add(s, s);                             // mag 2
+    fe ep = fe_add(s2, fe_one());                        // 1 + s^2, mag 2
+    fe em = fe_weak(fe_sub<2>(fe_one(), s2));            // 1 - s^2
+    pt p;
+    p.t = fe_mul(two_s, ep);
+    p.x = fe_mul(two_s, t);
+    p.y = fe_mul(ep, em);
+    p.z = fe_mul(em, t);
+    return p;
+}
+
 // Dual isogeny back to Ed448 and RFC 8032 encoding (src/goldilocks.c:905-946).
 // out: 57 bytes as 15 words (upper 3 bytes of word 14 are zero).
 GD_FN void pt_encode_eddsa_words(uint32_t out[15], const pt &p) {

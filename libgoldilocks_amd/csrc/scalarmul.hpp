@@ -72,6 +72,15 @@ GD_FN pt ladder_varbase(const BITS &bits, const TABLE &table) {
     return acc;
 }
 
+// (s1*B, s2*B) for one base: the window table is built once and walked twice ("next" row f4;
+// the reference's point_dual_scalarmul, src/goldilocks.c:543-642, gets there with a bucket
+// method -- same two group elements).
+template <class BITS, class TABLE>
+GD_FN void ladder_dual(pt &out1, pt &out2, const BITS &bits1, const BITS &bits2, const TABLE &table) {
+    out1 = ladder_varbase(bits1, table);
+    out2 = ladder_varbase(bits2, table);
+}
+
 // Comb: 18 rounds; round i adds, for each of the 5 combs j, the entry selected by
 // bits i + 18*(k + 5j), k < 5, of s'  (src/goldilocks.c:846-873).
 // COMB: comb.load(j, idx) -> affine niels entry 16*j + idx (our sign convention).

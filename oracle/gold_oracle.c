@@ -929,6 +929,50 @@ int orc_direct_scalarmul(uint8_t out[56], const uint8_t base[56], const orc_scal
     return succ;
 }
 
+/* ---- Elligator 2 hash-to-curve: src/elligator.c:32-94 ---- */
+
+void orc_point_from_hash_nonuniform(orc_point *p, const uint8_t ser[56]) {
+    orc_gf r0, r, a, b, c, N, e;
+    (void)orc_gf_deserialize(&r0, ser, 0);     /* mask (uint8_t)(0xFE << 7) == 0: all 448 bits are used */
+    orc_gf_strong_reduce(&r0);
+    fe_sqr(&a, &r0);
+    fe_sub(&r, &FE_ZERO, &a);                   /* r = qnr * r0^2, qnr = -1 */
+    fe_sub(&a, &r, &FE_ONE);
+    fe_mulw_signed(&b, &a, EDWARDS_D);          /* d r - d */
+    fe_add(&a, &b, &FE_ONE);
+    fe_sub(&b, &b, &r);
+    fe_mul(&c, &a, &b);                         /* D = (dr - d + 1)(dr - d - r) */
+    fe_add(&a, &r, &FE_ONE);
+    fe_mulw_signed(&N, &a, 1 - 2 * EDWARDS_D);  /* N = (r + 1)(1 - 2d) */
+    fe_mul(&a, &c, &N);
+    mask_t square = orc_gf_isr(&b, &a);
+    for (int i = 0; i < 8; i++) c.limb[i] = (r0.limb[i] & ~square) | (FE_ONE.limb[i] & square);
+    fe_mul(&e, &b, &c);
+    fe_mul(&a, &N, &e);
+    fe_cond_neg(&a, orc_gf_lobit(&a) ^ ~square);               /* s */
+    fe_mulw_signed(&c, &e, 1 - 2 * EDWARDS_D);
+    fe_sqr(&b, &c);
+    fe_sub(&e, &r, &FE_ONE);
+    fe_mul_ip(&c, &b, &e);
+    fe_mul_ip(&b, &c, &N);
+    fe_cond_neg(&b, square);
+    fe_sub(&b, &b, &FE_ONE);                                   /* t */
+    fe_sqr(&c, &a);
+    fe_add(&a, &a, &a);
+    fe_add(&e, &c, &FE_ONE);
+    fe_mul(&p->t, &a, &e);
+    fe_mul(&p->x, &a, &b);
+    fe_sub(&a, &FE_ONE, &c);
+    fe_mul(&p->y, &e, &a);
+    fe_mul(&p->z, &a, &b);
+}
+void orc_point_from_hash_uniform(orc_point *p, const uint8_t ser[112]) {
+    orc_point p2;
+    orc_point_from_hash_nonuniform(p, ser);
+    orc_point_from_hash_nonuniform(&p2, ser + 56);
+    orc_point_add(p, p, &p2);
+}
+
 /* ---- X448 (RFC 7748): src/goldilocks.c:1006-1141 ---- */
 
 int orc_x448(uint8_t out[56], const uint8_t base[56], const uint8_t scalar[56]) { /* goldilocks.c:1006-1076 */

@@ -90,6 +90,10 @@ ORC_API void orc_base_double_scalarmul_non_secret(orc_point *out, const orc_scal
 ORC_API int  orc_direct_scalarmul(uint8_t out[56], const uint8_t base[56], const orc_scalar *s,
                                   int allow_identity, int short_circuit);
 
+/* ---- Elligator 2 hash-to-curve ---- */
+ORC_API void orc_point_from_hash_nonuniform(orc_point *p, const uint8_t ser[56]);
+ORC_API void orc_point_from_hash_uniform(orc_point *p, const uint8_t ser[112]);
+
 /* ---- X448 (RFC 7748) ---- */
 ORC_API int  orc_x448(uint8_t out[56], const uint8_t base[56], const uint8_t scalar[56]);
 ORC_API void orc_x448_derive_public_key(uint8_t out[56], const uint8_t scalar[56]);

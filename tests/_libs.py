@@ -120,6 +120,8 @@ def oracle():
         "orc_base_double_scalarmul_non_secret": (None, [pp, ps, pp, ps]),
         "orc_direct_scalarmul": (C.c_int, [vp, vp, ps, C.c_int, C.c_int]),
         "orc_shake256": (None, [vp, C.c_size_t, vp, C.c_size_t]),
+        "orc_point_from_hash_nonuniform": (None, [pp, vp]),
+        "orc_point_from_hash_uniform": (None, [pp, vp]),
         "orc_x448": (C.c_int, [vp, vp, vp]),
         "orc_x448_derive_public_key": (None, [vp, vp]),
         "orc_ed448_derive_public_key": (None, [vp, vp]),

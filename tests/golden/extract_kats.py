@@ -63,12 +63,16 @@ def main():
                       "message": get("eddsa_message", i).hex(), "context": get("eddsa_context", i).hex(),
                       "prehashed": prehashed[i], "sig": get("eddsa_sig", i).hex()})
     assert len(cases) == 11 and all(len(c["sig"]) == 228 and len(c["pk"]) == 114 for c in cases)
-    bm = byte_arrays(e)["values"]
+    ea = byte_arrays(e)
+    bm = ea["values"]
     assert len(bm) == 16 and all(len(b) == 56 for b in bm)
+    ell_in, ell_out = ea["inputs"], ea["outputs"]
+    assert len(ell_in) == 16 and len(ell_out) == 16 and all(len(b) == 56 for b in ell_in + ell_out)
     kats = {
-        "source": "otrv4/libgoldilocks test/vectors.inc.cxx:3-751, test/elligator_vectors.inc.cxx:3-73",
+        "source": "otrv4/libgoldilocks test/vectors.inc.cxx:3-751, test/elligator_vectors.inc.cxx:3-217",
         "rfc8032_ed448": cases,
         "base_multiples": [b.hex() for b in bm],
+        "elligator_nonuniform": [{"hash": i.hex(), "point": o.hex()} for i, o in zip(ell_in, ell_out)],
         "rfc7748_x448_iterated": {"1": arrs["rfc7748_1"][0].hex(), "1000": arrs["rfc7748_1000"][0].hex(),
                                   "1000000": arrs["rfc7748_1000000"][0].hex()},
     }

@@ -251,4 +251,24 @@ void hs_bwt_scalarmul(uint64_t *out, const uint64_t *comb_table, const uint64_t 
     }
 }
 
+void hs_point_from_hash(uint64_t *out, const uint8_t *hash, int uniform) {
+    uint32_t w[14];
+    bytes_to_words(w, hash, 56, 14);
+    pt p = pt_from_hash_words(w);
+    if (uniform) {
+        bytes_to_words(w, hash + 56, 56, 14);
+        p = pt_add(p, pt_from_hash_words(w), false);
+    }
+    pt_to_abi(out, p);
+}
+void hs_point_dual_scalarmul(uint64_t *o1, uint64_t *o2, const uint64_t *base, const uint64_t *s1, const uint64_t *s2) {
+    HostBits b1 = make_bits(sc_from_abi(s1)), b2 = make_bits(sc_from_abi(s2));
+    HostTable tab;
+    build_window_table(tab, pt_from_abi(base));
+    pt r1, r2;
+    ladder_dual(r1, r2, b1, b2, tab);
+    pt_to_abi(o1, r1);
+    pt_to_abi(o2, r2);
+}
+
 }  // extern "C"

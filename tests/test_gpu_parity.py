@@ -455,3 +455,27 @@ def test_x448_vs_oracle_and_rfc7748(ga, O):
     assert L.goldilocks_x448(s1.ctypes.data, pb.ctypes.data, a.ctypes.data) == -1
     assert L.goldilocks_x448(s2.ctypes.data, pa.ctypes.data, b.ctypes.data) == -1
     assert (s1 == s2).all()
+
+
+def test_elligator_and_dual_scalarmul(ga, O):
+    from _libs import Point
+    kats = json.load(open(os.path.join(GOLD, "kats.json")))["elligator_nonuniform"]
+    h = np.array([np.frombuffer(bytes.fromhex(c["hash"]), np.uint8) for c in kats])
+    want = np.array([np.frombuffer(bytes.fromhex(c["point"]), np.uint8) for c in kats])
+    assert (enc(ga, ga.point_from_hash_batch(h)) == want).all()          # the reference's elligator_examples
+    n = 300
+    raw = np.frombuffer(_gen.stream(b"t-elligator", 112 * n), np.uint8).reshape(n, 112).copy()
+    raw[0] = 0
+    raw[1] = 0xff
+    for uniform in (False, True):
+        got = ga.point_from_hash_batch(raw if uniform else raw[:, :56].copy(), uniform=uniform)
+        w = np.empty((n, 32), np.uint64)
+        for i in range(n):
+            f = O.orc_point_from_hash_uniform if uniform else O.orc_point_from_hash_nonuniform
+            f(C.cast(w[i].ctypes.data_as(C.c_void_p), C.POINTER(Point)), raw[i].ctypes.data)
+        assert (enc(ga, got) == _gen.oracle_encode(w)).all(), uniform
+    pts = ga.point_from_hash_batch(raw, uniform=True)
+    s1, s2 = _gen.random_scalars(n, b"t-dual-1"), _gen.random_scalars(n, b"t-dual-2")
+    o1, o2 = ga.point_dual_scalarmul_batch(pts, s1, s2)
+    assert (enc(ga, o1) == _gen.oracle_encode(_gen.oracle_varbase(O, pts, s1))).all()
+    assert (enc(ga, o2) == _gen.oracle_encode(_gen.oracle_varbase(O, pts, s2))).all()

@@ -147,3 +147,24 @@ def test_fixed_base_window_table_ladder(H, O):
     out = np.empty((n, 32), np.uint64)
     H.hs_bwt_scalarmul(out.ctypes.data, C.cast(O.orc_precomputed_base(), C.c_void_p), s.ctypes.data, n)
     assert (_gen.oracle_encode(out) == _gen.oracle_encode(_gen.oracle_fixed(O, s))).all()
+
+
+def test_elligator_and_dual(H, O):
+    import json
+    H.hs_point_from_hash.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    kats = json.load(open(os.path.join(os.path.dirname(HS_DIR), "golden", "kats.json")))["elligator_nonuniform"]
+    for c in kats:
+        p = Point()
+        H.hs_point_from_hash(C.byref(p), buf(bytes.fromhex(c["hash"])), 0)
+        assert _enc(O, p).hex() == c["point"]
+    rnd = random.Random(8)
+    for it in range(20):
+        h = bytes(rnd.getrandbits(8) for _ in range(112)) if it > 1 else (bytes(112), b"\xff" * 112)[it]
+        a, b = Point(), Point()
+        O.orc_point_from_hash_uniform(C.byref(a), buf(h)); H.hs_point_from_hash(C.byref(b), buf(h), 1)
+        assert _enc(O, a) == _enc(O, b)
+        s1, s2 = Scalar.from_int(rnd.getrandbits(446) % Q), Scalar.from_int(rnd.getrandbits(446) % Q)
+        o1, o2, w1, w2 = Point(), Point(), Point(), Point()
+        H.hs_point_dual_scalarmul(C.byref(o1), C.byref(o2), C.byref(a), C.byref(s1), C.byref(s2))
+        O.orc_point_scalarmul(C.byref(w1), C.byref(a), C.byref(s1)); O.orc_point_scalarmul(C.byref(w2), C.byref(a), C.byref(s2))
+        assert _enc(O, o1) == _enc(O, w1) and _enc(O, o2) == _enc(O, w2)

@@ -168,3 +168,11 @@ def test_x448_rfc7748_iterated(O):
     assert k.hex() == kats["1000"]
     zero = (C.c_uint8 * 56)()
     assert O.orc_x448(zero, buf(bytes(56)), buf(k)) == 0 and bytes(zero) == bytes(56)
+
+
+def test_elligator_examples(O):
+    """The reference's elligator_examples (test/elligator_vectors.inc.cxx:75-217): 56-byte hash -> point."""
+    for c in KATS["elligator_nonuniform"]:
+        p = Point()
+        O.orc_point_from_hash_nonuniform(C.byref(p), buf(bytes.fromhex(c["hash"])))
+        assert _enc(O, p).hex() == c["point"] and O.orc_point_valid(C.byref(p)) == -1

@@ -92,3 +92,15 @@ def test_x448_differential(O):
         assert R.goldilocks_x448(o1, buf(b), buf(s)) == O.orc_x448(o2, buf(b), buf(s)) and bytes(o1) == bytes(o2)
         R.goldilocks_x448_derive_public_key(o1, buf(s)); O.orc_x448_derive_public_key(o2, buf(s))
         assert bytes(o1) == bytes(o2)
+
+
+def test_elligator_differential(O):
+    R = ref()
+    rnd = random.Random(13)
+    for it in range(100):
+        h = bytes(rnd.getrandbits(8) for _ in range(112)) if it > 1 else (bytes(112), b"\xff" * 112)[it]
+        a, b = Point(), Point()
+        R.goldilocks_448_point_from_hash_nonuniform(C.byref(a), buf(h)); O.orc_point_from_hash_nonuniform(C.byref(b), buf(h))
+        assert bytes(a) == bytes(b)
+        R.goldilocks_448_point_from_hash_uniform(C.byref(a), buf(h)); O.orc_point_from_hash_uniform(C.byref(b), buf(h))
+        assert bytes(a) == bytes(b)
