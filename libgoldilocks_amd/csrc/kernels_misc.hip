@@ -1,0 +1,213 @@
+// kernels_misc.hip -- kernel definitions (see kernels.hpp for the memory plan and policies).
+#include "kernels.hpp"
+
+namespace gd {
+
+__device__ __forceinline__ void store_bytes_from_words(uint8_t *dst, const uint32_t *w, int nbytes) {
+    for (int i = 0; i < nbytes; i++) dst[i] = (uint8_t)(w[i >> 2] >> (8 * (i & 3)));
+}
+
+GD_KERNEL k_point_encode(uint8_t *__restrict__ ser, const uint64_t *__restrict__ pts, uint32_t n, int eddsa) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        pt p = pt_load_abi(pts + 32 * (size_t)i);
+        uint32_t w[15];
+        if (eddsa) {  // uniform
+            pt_encode_eddsa_words(w, p);
+            uint8_t *dst = ser + 57 * (size_t)i;
+#pragma unroll 1
+            for (int k = 0; k < 57; k++) dst[k] = (uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+        } else {
+            pt_encode_words(w, p);
+            uint32_t *dst = reinterpret_cast<uint32_t *>(ser + 56 * (size_t)i);  // 56*i is 8-byte aligned
+#pragma unroll
+            for (int k = 0; k < 14; k++) dst[k] = w[k];
+        }
+    }
+}
+
+GD_KERNEL k_point_decode(uint64_t *__restrict__ pts, int32_t *__restrict__ status,
+                         const uint8_t *__restrict__ ser, uint32_t n, int eddsa, int allow_identity) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        uint32_t w[15];
+        pt p;
+        bool ok;
+        if (eddsa) {
+            load_bytes_as_words(w, ser + 57 * (size_t)i, 57, 15);
+            ok = pt_decode_eddsa_words(p, w);
+        } else {
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(ser + 56 * (size_t)i);
+#pragma unroll
+            for (int k = 0; k < 14; k++) w[k] = src[k];
+            ok = pt_decode_words(p, w, allow_identity != 0);
+        }
+        pt_store_abi(pts + 32 * (size_t)i, p);
+        status[i] = ok ? -1 : 0;
+    }
+}
+
+GD_KERNEL k_point_op(uint64_t *__restrict__ out, const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+                     uint32_t n, int op) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        pt p = pt_load_abi(a + 32 * (size_t)i);
+        if (op == 2) {
+            pt_double(p, true);
+        } else {
+            pt q = pt_load_abi(b + 32 * (size_t)i);
+            p = pt_add(p, q, op == 1);
+        }
+        pt_store_abi(out + 32 * (size_t)i, p);
+    }
+}
+
+GD_KERNEL k_point_pred(int32_t *__restrict__ status, const uint64_t *__restrict__ a,
+                       const uint64_t *__restrict__ b, uint32_t n, int op) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        pt p = pt_load_abi(a + 32 * (size_t)i);
+        bool r;
+        if (op == 0) r = pt_eq(p, pt_load_abi(b + 32 * (size_t)i));
+        else r = pt_valid(p);
+        status[i] = r ? -1 : 0;
+    }
+}
+
+GD_KERNEL k_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, const uint64_t *__restrict__ a,
+                     const uint64_t *__restrict__ b, uint32_t n, int op) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        fe x = fe_load_abi(a + 8 * (size_t)i), r;
+        bool ok = true;
+        if (op == 0) r = fe_mul(x, fe_load_abi(b + 8 * (size_t)i));
+        else if (op == 1) r = fe_sqr(x);
+        else if (op == 2) r = fe_isr(x, &ok);
+        else r = fe_strong(x);
+        if (op == 3) {  // canonical limbs, no weak pass on store
+            uint64_t *dst = out + 8 * (size_t)i;
+#pragma unroll
+            for (int k = 0; k < 8; k++) dst[k] = (uint64_t)r.v[2 * k] | (uint64_t)r.v[2 * k + 1] << 28;
+        } else {
+            fe_store_abi(out + 8 * (size_t)i, r);
+        }
+        if (status) status[i] = ok ? -1 : 0;
+    }
+}
+
+// Reference-format comb (80 x {a,b,c} canonical 56-bit limbs) -> ours (28-bit limbs, cn = -c).
+GD_KERNEL k_import_comb(uint4 *__restrict__ dst, const uint64_t *__restrict__ src, uint32_t ntables) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < 80 * ntables; i += stride) {
+        const uint64_t *s = src + 24 * (size_t)i;
+        uint64_t l[8];
+        uint4 *d = dst + 12 * (size_t)i;
+#pragma unroll
+        for (int k = 0; k < 8; k++) l[k] = s[k];
+        fe_store(d, fe_weak(fe_from_limbs56(l)));
+#pragma unroll
+        for (int k = 0; k < 8; k++) l[k] = s[8 + k];
+        fe_store(d + 4, fe_weak(fe_from_limbs56(l)));
+#pragma unroll
+        for (int k = 0; k < 8; k++) l[k] = s[16 + k];
+        fe_store(d + 8, fe_weak(fe_neg(fe_from_limbs56(l))));
+    }
+}
+
+// 16-entry window table (our pniels form) of one point, by lane 0
+GD_KERNEL k_build_shared_table(uint4 *__restrict__ dst, const uint64_t *__restrict__ point) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        LaneTable t{dst};
+        build_window_table(t, pt_load_abi(point));
+    }
+}
+
+// ref: goldilocks_448_precompute (src/goldilocks.c:755-818).  One table per lane.
+// work: PRECOMP_U4 per lane of HBM workspace: 80 x {Y-X, Y+X, T, 2Z, prefix product} + 4 teeth.
+GD_KERNEL k_precompute(uint64_t *__restrict__ tables, const uint64_t *__restrict__ base, uint32_t n,
+                       uint4 *__restrict__ workspace) {
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    uint4 *work = workspace + (size_t)lane * PRECOMP_U4;
+    for (uint32_t i = lane; i < n; i += stride) {
+        pt working = pt_load_abi(base + 32 * (size_t)i);
+        // entry idx of comb j = sum_k (+-) 2^(18(k+5j)) B, tooth 4 always +, tooth k<4 + iff bit k of idx
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) {
+            // teeth of this comb, kept as doubled pniels for the Gray-code walk
+            pt start = working;
+            uint4 *teeth = work + 80 * 20;  // 4 pniels behind the 80 entries
+#pragma unroll 1
+            for (int k = 0; k < 5; k++) {
+                if (k) start = pt_add(start, working, false);
+                if (k == 4 && j == 4) break;
+                pt_double(working, true);
+                if (k < 4) LaneTable{teeth}.store(k, pt_to_pniels(working));  // 2 * tooth_k
+#pragma unroll 1
+                for (int d = 0; d < 17; d++) pt_double(working, d == 16);
+            }
+#pragma unroll 1
+            for (uint32_t g = 0;; g++) {
+                const uint32_t gray = g ^ (g >> 1);
+                const uint32_t idx = (((j + 1) << 4) - 1) ^ gray;
+                uint4 *w = work + (size_t)idx * 20;
+                fe_store(w, fe_weak(fe_sub<2>(start.y, start.x)));
+                fe_store(w + 4, fe_weak(fe_add(start.x, start.y)));
+                fe_store(w + 8, start.t);
+                fe_store(w + 12, fe_weak(fe_add(start.z, start.z)));
+                if (g >= 15) break;
+                const uint32_t delta = (g + 1) ^ ((g + 1) >> 1) ^ gray;  // the Gray bit that flips
+                const uint32_t k = 31 - __clz(delta);
+                pniels step = LaneTable{teeth}.load(k);
+                pt_add_pniels(start, step, /*neg=*/(gray & (1u << k)) == 0, true);
+            }
+        }
+        // Montgomery's trick over the 80 values 2Z (src/goldilocks.c:703-726)
+        fe acc = fe_one();
+#pragma unroll 1
+        for (int e = 0; e < 80; e++) {
+            fe_store(work + (size_t)e * 20 + 16, acc);
+            acc = fe_mul(acc, fe_load(work + (size_t)e * 20 + 12));
+        }
+        fe inv = fe_invert(acc);
+        uint64_t *dst = tables + (size_t)i * (80 * 24);
+#pragma unroll 1
+        for (int e = 79; e >= 0; e--) {
+            uint4 *w = work + (size_t)e * 20;
+            fe zi = fe_mul(inv, fe_load(w + 16));
+            inv = fe_mul(inv, fe_load(w + 12));
+            fe a = fe_strong(fe_mul(fe_load(w), zi));
+            fe b = fe_strong(fe_mul(fe_load(w + 4), zi));
+            // c = 2 d' T / (2Z) = -(78164 T) * zi
+            fe c = fe_strong(fe_neg(fe_mul(fe_mulw(fe_load(w + 8), TWO_EFF_D), zi)));
+            uint64_t *d = dst + 24 * e;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                d[k] = (uint64_t)a.v[2 * k] | (uint64_t)a.v[2 * k + 1] << 28;
+                d[8 + k] = (uint64_t)b.v[2 * k] | (uint64_t)b.v[2 * k + 1] << 28;
+                d[16 + k] = (uint64_t)c.v[2 * k] | (uint64_t)c.v[2 * k + 1] << 28;
+            }
+        }
+    }
+}
+
+// "next" row f4: Elligator 2 hash-to-curve   (ref: goldilocks_448_point_from_hash_nonuniform / _uniform)
+GD_KERNEL k_point_from_hash(uint64_t *__restrict__ out, const uint8_t *__restrict__ hash, uint32_t n, int uniform) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t nb = uniform ? 112 : 56;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        uint32_t w[14];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(hash + (size_t)nb * i);   // 56 | nb: 8-byte aligned
+#pragma unroll
+        for (int k = 0; k < 14; k++) w[k] = src[k];
+        pt p = pt_from_hash_words(w);
+        if (uniform) {
+#pragma unroll
+            for (int k = 0; k < 14; k++) w[k] = src[14 + k];
+            p = pt_add(p, pt_from_hash_words(w), false);
+        }
+        pt_store_abi(out + 32 * (size_t)i, p);
+    }
+}
+
+}  // namespace gd
