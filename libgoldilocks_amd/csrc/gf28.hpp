@@ -63,7 +63,16 @@ struct acc_t {
     uint64_t x;
     GD_MFN acc_t() : x(0) {}
     GD_MFN explicit acc_t(uint64_t v) : x(v) {}
-    GD_MFN void mac(uint32_t a, uint32_t b) { x += (uint64_t)a * b; }  // v_mad_u64_u32
+    // v_mad_u64_u32 acc, a, b, acc.  The empty asm pins the accumulation ORDER (no instruction is
+    // emitted for it): without it LLVM reassociates carry + sum(products) into sum(products) +
+    // carry and pays an extra 64-bit add per chain and column (16 per multiplication); with it the
+    // incoming carry is the first MAC's addend.
+    GD_MFN void mac(uint32_t a, uint32_t b) {
+        x += (uint64_t)a * b;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm("" : "+v"(x));
+#endif
+    }
     GD_MFN void add(const acc_t &o) { x += o.x; }
     GD_MFN void add32(uint32_t o) { x += o; }
     GD_MFN void sub(const acc_t &o) { x -= o.x; }
