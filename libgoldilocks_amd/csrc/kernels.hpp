@@ -119,23 +119,6 @@ struct LaneTable {  // this lane's 16-entry window table in the HBM workspace
         e.z = fe_load(q + 12);
         return e;
     }
-    // Pull the entry's two 128-byte lines towards L2 long before they are needed.  hipcc does not
-    // track asm loads, so the two destination registers stay reserved (the token) until retire(),
-    // which sits behind the wait for the entry's real loads: vector memory returns in issue order,
-    // so by then these two have landed too and the registers may be reused.
-    struct PrefetchToken {
-        uint32_t t0, t1;
-    };
-    __device__ __forceinline__ PrefetchToken prefetch(uint32_t k) const {
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(p + 16 * k);
-        PrefetchToken t;
-        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %2, off offset:128"
-                     : "=&v"(t.t0), "=&v"(t.t1) : "v"(q) : "memory");
-        return t;
-    }
-    __device__ __forceinline__ void retire(const PrefetchToken &t, const pniels &e) const {
-        asm volatile("" ::"v"(t.t0), "v"(t.t1), "v"(e.z.v[15]), "v"(e.a.v[0]));
-    }
 };
 struct SharedTable {  // read-only 16-entry table shared by all lanes (base point)
     const uint4 *p;

@@ -62,11 +62,9 @@ GD_FN pt ladder_varbase(const BITS &bits, const TABLE &table) {
 #pragma unroll 1
     for (int pos = 440; pos >= 0; pos -= 5) {
         signed_digit(window5(bits, pos), idx, neg);
-        auto tok = table.prefetch(idx);   // touch the entry's two cache lines now; consumed after 5 doublings
 #pragma unroll 1
         for (int j = 0; j < 5; j++) pt_double(acc, j == 4);
         pniels e = table.load(idx);
-        table.retire(tok, e);
         // T is only needed by a following addition, i.e. never after the last window's
         // add -- except that the caller wants a complete extended point at pos == 0.
         pt_add_pniels(acc, e, neg, pos == 0);

@@ -31,8 +31,6 @@ struct HostTable {
     pniels e[17];
     void store(int k, const pniels &p) { e[k] = p; }
     pniels load(uint32_t k) const { return e[k]; }
-    int prefetch(uint32_t) const { return 0; }
-    void retire(int, const pniels &) const {}
 };
 struct HostComb {
     niels e[80];
