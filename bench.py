@@ -112,8 +112,9 @@ def main():
     assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("GOLDILOCKS_BENCH_FORCE_DIST"):   # the env knob lets a 1-GPU box exercise the RCCL path
         import torch.distributed as dist
+        os.environ.setdefault("NCCL_DEBUG", "WARN")    # keep RCCL's banner off stdout: one JSON line only
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     ga.lib()
     info = ga.device_info()
