@@ -37,3 +37,16 @@ for logn in (14, 17, 20):
     ms = timeit(lambda: ga.dev("ed448_verify", st.data_ptr(), ds.data_ptr(), dp.data_ptr(), dm.data_ptr(), None, 32, 0, None, 0, n, None))
     assert int((st == -1).sum()) == n
     print("verify   n=2^%d  %.2f ms  %.3f M/s" % (logn, ms, n / ms / 1e3), flush=True)
+
+# PCIe-inclusive rate of the host-array API (pageable numpy buffers in, pre-touched buffer out)
+import ctypes as C
+n = 1 << 20
+bh = np.ascontiguousarray(bk[rng.integers(0, k, n)]); sh = np.ascontiguousarray(sk[rng.integers(0, k, n)])
+outh = np.zeros((n, 32), dtype=np.uint64)
+L = ga.lib()
+call = lambda: L.goldilocks_448_point_scalarmul_batch(outh.ctypes.data, bh.ctypes.data, sh.ctypes.data, n)
+assert call() == 0
+for rep in range(3):
+    t0 = time.perf_counter(); assert call() == 0; dt = time.perf_counter() - t0
+    print("varbase host-array API (H2D + kernel + D2H) n=2^20  %.1f ms  %.2f M/s" % (dt * 1e3, n / dt / 1e6), flush=True)
+assert (ga.point_encode_batch(outh[:64]) == _gen.oracle_encode(_gen.oracle_varbase(O, bh[:64], sh[:64]))).all()
