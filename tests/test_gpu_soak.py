@@ -1,0 +1,77 @@
+"""Larger randomized differential runs of every kernel against the oracle (rare-carry hunting):
+32768 lanes per kernel, bit-exact on encodings / bytes / status."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _gen
+from _libs import Q
+
+pytestmark = pytest.mark.gpu
+N = 1 << 15
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_soak_scalarmuls(ga, O):
+    k = _gen.stream_scalars(N, b"soak/base")
+    s = _gen.stream_scalars(N, b"soak/scalar")
+    bases = ga.precomputed_scalarmul_batch(k)                                     # 8-bit window table
+    assert (ga.point_encode_batch(bases) == _gen.oracle_encode(_gen.oracle_fixed(O, k))).all()
+    comb = ga.precomputed_scalarmul_batch(k, table=ga.precomputed_base())         # LDS comb
+    assert (ga.point_encode_batch(comb) == ga.point_encode_batch(bases)).all()
+    got = ga.point_scalarmul_batch(bases, s)
+    assert (ga.point_encode_batch(got) == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all()
+    e57 = ga.point_encode_like_eddsa_batch(got)
+    dec, st = ga.point_decode_like_eddsa_batch(e57)
+    four = ga.point_scalarmul_batch(got, _gen.scalars_from_ints([4] * N))
+    ok = st == -1        # the encoding of the identity (4P = 0) does not decode, as in the reference
+    assert ok.sum() >= N - 4 and (ga.point_encode_batch(dec)[ok] == ga.point_encode_batch(four)[ok]).all()
+
+
+def test_soak_sign_verify(ga, O):
+    sk = np.frombuffer(_gen.stream(b"soak/sk", 57 * N), np.uint8).reshape(N, 57).copy()
+    pk = ga.ed448_derive_public_key_batch(sk)
+    want_pk = np.empty_like(pk)
+    O.orc_ed448_derive_public_key_batch(_p(want_pk), _p(sk), N, _gen.NTHREADS)
+    assert (pk == want_pk).all()
+    msg = np.frombuffer(_gen.stream(b"soak/msg", 48 * N), np.uint8).reshape(N, 48).copy()
+    msgs = [m.tobytes() for m in msg]
+    sig = ga.ed448_sign_batch(sk, pk, msgs, context=b"soak")
+    want = np.empty_like(sig)
+    ctx = (C.c_uint8 * 4).from_buffer_copy(b"soak")
+    O.orc_ed448_sign_batch(_p(want), _p(sk), _p(pk), _p(msg), 48, 0, ctx, 4, N, _gen.NTHREADS)
+    assert (sig == want).all()
+    rng = np.random.default_rng(5)
+    bad = rng.random(N) < 0.25
+    sig2 = sig.copy()
+    sig2[bad, rng.integers(0, 114, bad.sum())] ^= (1 << rng.integers(0, 8, bad.sum())).astype(np.uint8)
+    st = ga.ed448_verify_batch(sig2, pk, msgs, context=b"soak")
+    want_st = np.empty(N, np.int32)
+    O.orc_ed448_verify_batch(_p(want_st), _p(sig2), _p(pk), _p(msg), 48, 0, ctx, 4, N, _gen.NTHREADS)
+    assert (st == want_st).all() and (st[~bad] == -1).all()
+
+
+def test_soak_x448_and_elligator(ga, O):
+    from _libs import Point
+    n = N // 4
+    sc = np.frombuffer(_gen.stream(b"soak/x448-s", 56 * n), np.uint8).reshape(n, 56).copy()
+    pub, _ = ga.x448_batch(sc)
+    peer = np.roll(pub, 1, axis=0)
+    got, st = ga.x448_batch(sc, peer)
+    for i in range(0, n, 7):
+        w = (C.c_uint8 * 56)()
+        assert O.orc_x448(w, _p(peer[i]), _p(sc[i])) == st[i] and bytes(w) == got[i].tobytes()
+    # DH symmetry over the whole batch: x448(a_i, pub_{i-1}) == x448(a_{i-1}, pub_i)
+    other, _ = ga.x448_batch(np.roll(sc, 1, axis=0), pub)
+    assert (got == other).all()
+    h = np.frombuffer(_gen.stream(b"soak/elligator", 112 * n), np.uint8).reshape(n, 112).copy()
+    pts = ga.point_from_hash_batch(h, uniform=True)
+    w = np.empty((n, 32), np.uint64)
+    for i in range(0, n, 5):
+        O.orc_point_from_hash_uniform(C.cast(_p(w[i]), C.POINTER(Point)), _p(h[i]))
+    sel = np.arange(0, n, 5)
+    assert (ga.point_encode_batch(pts[sel]) == _gen.oracle_encode(w[sel])).all()
