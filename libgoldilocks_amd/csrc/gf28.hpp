@@ -199,10 +199,15 @@ GD_FN fe fe_mul(const fe &a, const fe &b) {
     return c;
 }
 
-// c = a^2 mod p.  108 MACs: with U = a0^2, V = a1^2, S = (a0+a1)^2 (8-limb
-// squares, columns 0..14; X_i' = column i+8),
-//     low_i  = U_i + V_i + S_i' - U_i'        high_i = V_i' + S_i + S_i' - U_i
-// and each column of a square is sum_{j<k} (2 x_j) x_k (+ x_j^2 on the diagonal).
+// c = a^2 mod p.  136 MACs and no 64-bit combine arithmetic.  With a = a0 + a1 phi,
+// s = a0 + a1 and t = 2 a0 + a1:
+//     a^2 = (a0^2 + a1^2) + phi * (a1 * t)                       (phi^2 = phi + 1)
+// and since a0^2 + a1^2 + a1 t = s^2 + a1^2, the wrapped columns (X_i' = column i+8) give
+//     low_i  = (a0^2)_i + (a1^2)_i + (a1 t)_i'        high_i = (a1 t)_i + (s^2)_i' + (a1^2)_i'
+// Every term is positive, so each output limb is ONE MAC chain whose first addend is the carry
+// (a Karatsuba square has 108 MACs but pays 7 64-bit add/sub instructions per column pair).
+// Each column of a square is sum_{j<k} (2 x_j) x_k (+ x_j^2 on the diagonal).
+// Column bound: high_0 = 3 + 7*(4+1) = 38 products of mag^2 (the multiplication has 46).
 struct sq8 {
     uint32_t x[8], x2[8];
 };
@@ -216,24 +221,26 @@ GD_FN void sq_col(acc_t &acc, const sq8 &s) {  // acc += column COL (0..14) of x
         else acc.mac(s.x2[j], s.x[k]);
     }
 }
+template <int COL>
+GD_FN void mul_col(acc_t &acc, const uint32_t (&x)[8], const uint32_t (&y)[8]) {  // column COL of x*y
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = COL - j;
+        if (k < 0 || k > 7) continue;
+        acc.mac(x[j], y[k]);
+    }
+}
 template <int I>
-GD_FN void sqr_column(fe &c, acc_t &lo, acc_t &hi, const sq8 &u, const sq8 &v, const sq8 &s) {
-    acc_t A, Cw, E;
-    sq_col<I>(A, u);
+GD_FN void sqr_column(fe &c, acc_t &lo, acc_t &hi, const sq8 &u, const sq8 &v, const sq8 &s,
+                      const uint32_t (&t)[8]) {
+    sq_col<I>(lo, u);
+    sq_col<I>(lo, v);
+    mul_col<I>(hi, v.x, t);
     if (I < 7) {
-        sq_col<I + 8>(Cw, u);
-        sq_col<I + 8>(E, s);
+        mul_col<I + 8>(lo, v.x, t);
+        sq_col<I + 8>(hi, s);
         sq_col<I + 8>(hi, v);
     }
-    sq_col<I>(lo, v);
-    sq_col<I>(hi, s);
-    lo.add(A);
-    if (I < 7) {
-        lo.add(E);
-        lo.sub(Cw);
-        hi.add(E);
-    }
-    hi.sub(A);
     c.v[I] = lo.lo28();
     c.v[I + 8] = hi.lo28();
     lo.shr28();
@@ -241,6 +248,7 @@ GD_FN void sqr_column(fe &c, acc_t &lo, acc_t &hi, const sq8 &u, const sq8 &v, c
 }
 GD_FN fe fe_sqr(const fe &a) {
     sq8 u, v, s;
+    uint32_t t[8];
 #pragma unroll
     for (int j = 0; j < 8; j++) {
         u.x[j] = a.v[j];
@@ -249,17 +257,18 @@ GD_FN fe fe_sqr(const fe &a) {
         u.x2[j] = u.x[j] << 1;
         v.x2[j] = v.x[j] << 1;
         s.x2[j] = s.x[j] << 1;
+        t[j] = u.x2[j] + v.x[j];
     }
     fe c;
     acc_t lo, hi;
-    sqr_column<0>(c, lo, hi, u, v, s);
-    sqr_column<1>(c, lo, hi, u, v, s);
-    sqr_column<2>(c, lo, hi, u, v, s);
-    sqr_column<3>(c, lo, hi, u, v, s);
-    sqr_column<4>(c, lo, hi, u, v, s);
-    sqr_column<5>(c, lo, hi, u, v, s);
-    sqr_column<6>(c, lo, hi, u, v, s);
-    sqr_column<7>(c, lo, hi, u, v, s);
+    sqr_column<0>(c, lo, hi, u, v, s, t);
+    sqr_column<1>(c, lo, hi, u, v, s, t);
+    sqr_column<2>(c, lo, hi, u, v, s, t);
+    sqr_column<3>(c, lo, hi, u, v, s, t);
+    sqr_column<4>(c, lo, hi, u, v, s, t);
+    sqr_column<5>(c, lo, hi, u, v, s, t);
+    sqr_column<6>(c, lo, hi, u, v, s, t);
+    sqr_column<7>(c, lo, hi, u, v, s, t);
     fe_fold_tails(c, lo, hi);
     return c;
 }

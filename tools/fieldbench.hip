@@ -1,0 +1,190 @@
+// fieldbench.hip -- A/B timing of the lane field operations on the whole chip (gfx950).
+//
+// Each lane runs a dependent chain of N field operations (x = op(x, y)); the grid puts W waves on
+// every SIMD (256 CUs x 4 SIMDs).  Reported: SIMD cycles per wave-operation at the nominal clock
+// (wall time x 2.4 GHz x W / N) -- the quantity the ladders are bound by -- next to the static
+// MAC / other-VALU instruction counts, so that candidate formulations of gf_mul / gf_sqr can be
+// compared on the same box in the same run.  Variants that lost are kept here (not in the
+// library) as the evidence for the choice made in gf28.hpp.
+//
+//   hipcc -std=c++17 -O3 --offload-arch=gfx950 -Ilibgoldilocks_amd/csrc -o tools/fieldbench tools/fieldbench.hip
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "gf28.hpp"
+#include "point.hpp"
+
+using namespace gd;
+
+#define CHECK(x)                                                       \
+    do {                                                               \
+        hipError_t e = (x);                                            \
+        if (e != hipSuccess) {                                         \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));     \
+            exit(1);                                                   \
+        }                                                              \
+    } while (0)
+
+// ---- variant: Karatsuba square, 108 MACs + 7 64-bit add/sub per column pair (round-1 original)
+namespace kar {
+template <int I>
+GD_FN void sqr_column(fe &c, acc_t &lo, acc_t &hi, const sq8 &u, const sq8 &v, const sq8 &s) {
+    acc_t A, Cw, E;
+    sq_col<I>(A, u);
+    if (I < 7) {
+        sq_col<I + 8>(Cw, u);
+        sq_col<I + 8>(E, s);
+        sq_col<I + 8>(hi, v);
+    }
+    sq_col<I>(lo, v);
+    sq_col<I>(hi, s);
+    lo.add(A);
+    if (I < 7) {
+        lo.add(E);
+        lo.sub(Cw);
+        hi.add(E);
+    }
+    hi.sub(A);
+    c.v[I] = lo.lo28();
+    c.v[I + 8] = hi.lo28();
+    lo.shr28();
+    hi.shr28();
+}
+GD_FN fe fe_sqr(const fe &a) {
+    sq8 u, v, s;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u.x[j] = a.v[j];
+        v.x[j] = a.v[j + 8];
+        s.x[j] = a.v[j] + a.v[j + 8];
+        u.x2[j] = u.x[j] << 1;
+        v.x2[j] = v.x[j] << 1;
+        s.x2[j] = s.x[j] << 1;
+    }
+    fe c;
+    acc_t lo, hi;
+    sqr_column<0>(c, lo, hi, u, v, s);
+    sqr_column<1>(c, lo, hi, u, v, s);
+    sqr_column<2>(c, lo, hi, u, v, s);
+    sqr_column<3>(c, lo, hi, u, v, s);
+    sqr_column<4>(c, lo, hi, u, v, s);
+    sqr_column<5>(c, lo, hi, u, v, s);
+    sqr_column<6>(c, lo, hi, u, v, s);
+    sqr_column<7>(c, lo, hi, u, v, s);
+    fe_fold_tails(c, lo, hi);
+    return c;
+}
+}  // namespace kar
+
+// ---- variant: schoolbook-over-phi multiplication, 256 MACs, no 64-bit combine arithmetic:
+//   low_i  = (a0 b0 + a1 b1)_i + (a0 b1 + a1 sb)_i'      high_i = (a0 b1 + a1 sb)_i + (sa sb + a1 b1)_i'
+namespace direct {
+GD_FN fe fe_mul(const fe &a, const fe &b) {
+    uint32_t a0[8], a1[8], b0[8], b1[8], sa[8], sb[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        a0[j] = a.v[j]; a1[j] = a.v[j + 8]; b0[j] = b.v[j]; b1[j] = b.v[j + 8];
+        sa[j] = a0[j] + a1[j];
+        sb[j] = b0[j] + b1[j];
+    }
+    fe c;
+    acc_t lo, hi;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j <= i) {
+                lo.mac(a0[j], b0[i - j]);
+                lo.mac(a1[j], b1[i - j]);
+                hi.mac(a0[j], b1[i - j]);
+                hi.mac(a1[j], sb[i - j]);
+            } else {
+                lo.mac(a0[j], b1[i - j + 8]);
+                lo.mac(a1[j], sb[i - j + 8]);
+                hi.mac(sa[j], sb[i - j + 8]);
+                hi.mac(a1[j], b1[i - j + 8]);
+            }
+        }
+        c.v[i] = lo.lo28();
+        c.v[i + 8] = hi.lo28();
+        lo.shr28();
+        hi.shr28();
+    }
+    fe_fold_tails(c, lo, hi);
+    return c;
+}
+}  // namespace direct
+
+enum Op { MUL, SQR, SQR_KAR, MUL_DIRECT, DBL, ADD_WEAK };
+
+template <int OP>
+__global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
+    const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe x, y;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        x.v[i] = io[t * 32 + i] & M28;
+        y.v[i] = io[t * 32 + 16 + i] & M28;
+    }
+    if (OP == DBL) {
+        pt p;
+        p.x = x; p.y = y; p.z = fe_add(x, y); p.z = fe_weak(p.z); p.t = x;
+        for (int k = 0; k < n; k++) pt_double(p, false);
+        x = fe_weak(fe_add(fe_add(p.x, p.y), p.z));
+    } else {
+        for (int k = 0; k < n; k++) {
+            if (OP == MUL) x = fe_mul(x, y);
+            if (OP == SQR) x = fe_sqr(x);
+            if (OP == SQR_KAR) x = kar::fe_sqr(x);
+            if (OP == MUL_DIRECT) x = direct::fe_mul(x, y);
+            if (OP == ADD_WEAK) x = fe_weak(fe_add(x, y));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; i++) io[t * 32 + i] = x.v[i];
+}
+
+template <int OP>
+static void run(const char *name, uint32_t *d_io, int macs, int waves_per_simd) {
+    const int n = 4000;
+    const int blocks = 256 * waves_per_simd;   // 256 CUs, 4 waves per block = 1 per SIMD
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_chain<OP>, dim3(blocks), dim3(256), 0, 0, d_io, 16);
+    CHECK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_chain<OP>, dim3(blocks), dim3(256), 0, 0, d_io, n);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipEventSynchronize(e1));
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
+    }
+    // every SIMD runs waves_per_simd chains of n ops concurrently
+    double cyc = best * 1e-3 * 2.4e9 / n / waves_per_simd;
+    printf("%-12s w/SIMD=%d  %8.3f ms  %8.1f SIMD-cycles per wave-op", name, waves_per_simd, best, cyc);
+    if (macs) printf("  (%d MACs -> %.2f cycles per MAC-equivalent)", macs, cyc / macs);
+    printf("\n");
+}
+
+int main() {
+    const size_t lanes = 256 * 2 * 256;
+    uint32_t *h = (uint32_t *)malloc(lanes * 32 * 4), *d;
+    for (size_t i = 0; i < lanes * 32; i++) h[i] = (uint32_t)(i * 2654435761u) >> 3;
+    CHECK(hipMalloc(&d, lanes * 32 * 4));
+    CHECK(hipMemcpy(d, h, lanes * 32 * 4, hipMemcpyHostToDevice));
+    for (int w = 1; w <= 2; w++) {
+        run<MUL>("mul", d, 192, w);
+        run<MUL_DIRECT>("mul_direct", d, 256, w);
+        run<SQR>("sqr", d, 136, w);
+        run<SQR_KAR>("sqr_kar", d, 108, w);
+        run<DBL>("pt_double", d, 4 * 136 + 3 * 192, w);
+        run<ADD_WEAK>("add+weak", d, 0, w);
+    }
+    return 0;
+}

@@ -1,0 +1,74 @@
+"""Condense the raw rocprofv3 output of tools/profile_round.sh into the small files kept in profiles/.
+
+  stats_<workload>/**/<pid>_kernel_stats.csv      -> rocprofv3_kernel_stats_bench_<workload>.csv (copied)
+  pmc_<counter-set>_<workload>/**/*_counter_collection.csv
+        -> rocprofv3_pmc_summary.json: per (workload, kernel, counter) dispatch count and the mean
+           value per dispatch (FETCH_SIZE / WRITE_SIZE are reported in KiB as rocprofv3 emits them;
+           the gfx950 correction -- FETCH_SIZE x2 -- is applied by the reader).
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+
+def newest(paths):
+    return max(paths, key=os.path.getmtime) if paths else None
+
+
+def main(raw, out):
+    os.makedirs(out, exist_ok=True)
+    for d in sorted(glob.glob(os.path.join(raw, "stats_*"))):
+        if not os.path.isdir(d):
+            continue
+        wl = os.path.basename(d)[len("stats_"):]
+        f = newest(glob.glob(os.path.join(d, "**", "*_kernel_stats.csv"), recursive=True))
+        if f:
+            shutil.copy(f, os.path.join(out, "rocprofv3_kernel_stats_bench_%s.csv" % wl))
+    rows = []
+    for d in sorted(glob.glob(os.path.join(raw, "pmc_*"))):
+        if not os.path.isdir(d):
+            continue
+        wl = os.path.basename(d).rsplit("_", 1)[1]
+        # the bench process is the one with the most dispatches
+        best = None
+        for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
+            n = sum(1 for _ in open(f))
+            if best is None or n > best[0]:
+                best = (n, f)
+        if not best:
+            continue
+        agg = collections.OrderedDict()
+        for r in csv.DictReader(open(best[1])):
+            k = (r["Kernel_Name"], r["Counter_Name"])
+            a = agg.setdefault(k, {"sum": 0.0, "ids": set(), "vgpr": r["VGPR_Count"], "agpr": r["Accum_VGPR_Count"],
+                                   "scratch": r["Scratch_Size"], "lds": r["LDS_Block_Size"]})
+            a["sum"] += float(r["Counter_Value"])
+            a["ids"].add(r["Dispatch_Id"])
+        for (kern, ctr), a in agg.items():
+            if kern.startswith("__amd_rocclr") or "at::native" in kern:
+                continue
+            rows.append({"bench": wl, "kernel": kern, "counter": ctr, "dispatches": len(a["ids"]),
+                         "avg_per_dispatch": a["sum"] / len(a["ids"]), "vgpr": a["vgpr"], "agpr": a["agpr"],
+                         "scratch": a["scratch"], "lds": a["lds"]})
+    json.dump(rows, open(os.path.join(out, "rocprofv3_pmc_summary.json"), "w"), indent=1)
+    # HBM bytes per launch for bench.py's roofline.traffic: 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes)
+    fetch, write = {}, {}
+    for r in rows:
+        tgt = fetch if r["counter"] == "FETCH_SIZE" else write if r["counter"] == "WRITE_SIZE" else None
+        if tgt is not None:
+            tgt[r["kernel"]] = max(tgt.get(r["kernel"], 0.0), r["avg_per_dispatch"])
+    traffic = {k: 2 * fetch[k] * 1024 + write[k] * 1024 for k in fetch if k in write}
+    traffic["_note"] = ("HBM bytes per launch (batch 2^20): 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (KiB units; FETCH_SIZE "
+                        "doubled per MI355X_MICROARCH.md HBM section), separate --pmc passes, rocprofv3_pmc_summary.json")
+    json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+    for r in rows:
+        if r["counter"] in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU") and r["dispatches"] >= 2:
+            print("%-8s %-28s %-14s x%d  %.4g" % (r["bench"], r["kernel"], r["counter"], r["dispatches"], r["avg_per_dispatch"]))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
