@@ -1,0 +1,74 @@
+"""BASELINE configs 3 and 4 at their full size (2^20 lanes) through size-independent properties, plus a
+sample of lanes bit-exact against the oracle.  (Config 2 at full size: test_full_size_linearity and
+test_golden_f6_full_batch_digest in test_gpu_parity.py.)"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import _gen
+
+pytestmark = pytest.mark.gpu
+N = 1 << 20
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_full_size_fixed_base_three_ways(ga, O):
+    """s*B from the base-point window table, from the LDS comb with a caller table, and from the
+    variable-base ladder must be the same group element in every lane."""
+    import torch
+    s = _gen.stream_scalars(N, b"full/fixed")
+    ds = torch.from_numpy(s.view(np.int64)).cuda()
+    tab = torch.from_numpy(np.ascontiguousarray(ga.precomputed_base()).view(np.uint8)).cuda()
+    base = torch.from_numpy(np.repeat(ga.point_base().reshape(1, 32), N, axis=0).view(np.int64)).cuda()
+    a, b, c = (torch.empty((N, 32), dtype=torch.int64, device="cuda") for _ in range(3))
+    ga.dev("precomputed_scalarmul", a.data_ptr(), None, ds.data_ptr(), N, None)
+    ga.dev("precomputed_scalarmul", b.data_ptr(), tab.data_ptr(), ds.data_ptr(), N, None)
+    ga.dev("point_scalarmul", c.data_ptr(), base.data_ptr(), ds.data_ptr(), N, None)
+    st = torch.empty(N, dtype=torch.int32, device="cuda")
+    for other in (b, c):
+        ga.dev("point_pred", st.data_ptr(), a.data_ptr(), other.data_ptr(), 0, N, None)
+        assert int((st == -1).sum()) == N
+    ga.dev("point_pred", st.data_ptr(), a.data_ptr(), None, 1, N, None)     # on the curve
+    assert int((st == -1).sum()) == N
+    idx = np.random.default_rng(11).integers(0, N, 512)
+    got = ga.point_encode_batch(a.cpu().numpy().view(np.uint64)[idx])
+    assert (got == _gen.oracle_encode(_gen.oracle_fixed(O, s[idx]))).all()
+
+
+def test_full_size_sign_verify_round_trip(ga, O):
+    """derive -> sign -> verify on 2^20 independent keys: every signature verifies, exactly the lanes
+    whose signature, key or message was corrupted are rejected; a sample is bit-exact vs the oracle."""
+    sk = np.frombuffer(_gen.stream(b"full/sk", 57 * N), np.uint8).reshape(N, 57).copy()
+    msg = np.frombuffer(_gen.stream(b"full/msg", 32 * N), np.uint8).reshape(N, 32).copy()
+    pk = ga.ed448_derive_public_key_batch(sk)
+    msgs = [m.tobytes() for m in msg]
+    sig = ga.ed448_sign_batch(sk, pk, msgs)
+    st = ga.ed448_verify_batch(sig, pk, msgs)
+    assert (st == -1).all()
+    rng = np.random.default_rng(13)
+    which = rng.integers(0, 4, N)                       # 0: untouched, 1: sig, 2: pk, 3: msg
+    bad = rng.random(N) < 0.01
+    sig2, pk2, msg2 = sig.copy(), pk.copy(), msg.copy()
+    m = bad & (which == 1)
+    sig2[m, rng.integers(0, 113, m.sum())] ^= (1 << rng.integers(0, 8, m.sum())).astype(np.uint8)
+    m = bad & (which == 2)
+    pk2[m, rng.integers(0, 56, m.sum())] ^= (1 << rng.integers(0, 8, m.sum())).astype(np.uint8)
+    m = bad & (which == 3)
+    msg2[m, rng.integers(0, 32, m.sum())] ^= (1 << rng.integers(0, 8, m.sum())).astype(np.uint8)
+    touched = bad & (which != 0)
+    st2 = ga.ed448_verify_batch(sig2, pk2, [r.tobytes() for r in msg2])
+    assert (st2[~touched] == -1).all() and (st2[touched] == 0).all() and touched.sum() > 5000
+    idx = np.concatenate([rng.integers(0, N, 256), np.flatnonzero(touched)[:256]])
+    k = len(idx)
+    want_pk, want_sig, want_st = np.empty((k, 57), np.uint8), np.empty((k, 114), np.uint8), np.empty(k, np.int32)
+    ski, msgi = np.ascontiguousarray(sk[idx]), np.ascontiguousarray(msg[idx])
+    O.orc_ed448_derive_public_key_batch(_p(want_pk), _p(ski), k, _gen.NTHREADS)
+    O.orc_ed448_sign_batch(_p(want_sig), _p(ski), _p(want_pk), _p(msgi), 32, 0, None, 0, k, _gen.NTHREADS)
+    assert (pk[idx] == want_pk).all() and (sig[idx] == want_sig).all()
+    s2i, p2i, m2i = (np.ascontiguousarray(x[idx]) for x in (sig2, pk2, msg2))
+    O.orc_ed448_verify_batch(_p(want_st), _p(s2i), _p(p2i), _p(m2i), 32, 0, None, 0, k, _gen.NTHREADS)
+    assert (st2[idx] == want_st).all()
