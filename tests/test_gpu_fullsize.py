@@ -72,3 +72,28 @@ def test_full_size_sign_verify_round_trip(ga, O):
     s2i, p2i, m2i = (np.ascontiguousarray(x[idx]) for x in (sig2, pk2, msg2))
     O.orc_ed448_verify_batch(_p(want_st), _p(s2i), _p(p2i), _p(m2i), 32, 0, None, 0, k, _gen.NTHREADS)
     assert (st2[idx] == want_st).all()
+
+
+def test_host_array_pipeline_matches_fixture_and_ragged_tail(ga, O):
+    """The host-array entry point is software-pipelined for large n: the 2^20 benchmark batch through it
+    must hash to the reference's digest (golden F6), and a batch with a ragged last chunk must agree
+    lane for lane with the single-launch device path."""
+    import hashlib
+    import json
+    import os
+    import torch
+    dig = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
+                                      "f6_bench_digest.json")))["digest_shake256_32"]
+    k = _gen.stream_scalars(N, b"bench_varbase_v1/0/base")
+    s = _gen.stream_scalars(N, b"bench_varbase_v1/0/scalar")
+    bases = ga.precomputed_scalarmul_batch(k)
+    out = ga.point_scalarmul_batch(bases, s)                      # 8 chunks of one chip residency
+    assert hashlib.shake_256(ga.point_encode_batch(out).tobytes()).hexdigest(32) == dig["20"]
+    n = 2 * 131072 + 777                                          # pipelined, last chunk ragged
+    part = ga.point_scalarmul_batch(bases[:n], s[:n])
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    db, dsc = d(bases[:n]), d(s[:n])
+    dout = torch.empty_like(db)
+    ga.dev("point_scalarmul", dout.data_ptr(), db.data_ptr(), dsc.data_ptr(), n, None)
+    torch.cuda.synchronize()
+    assert (dout.cpu().numpy().view(np.uint64) == part).all() and (part == out[:n]).all()
