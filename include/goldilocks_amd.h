@@ -242,6 +242,14 @@ GOLDILOCKS_AMD_API int goldilocks_x448_batch(uint8_t *shared /* n*56 */, goldilo
 GOLDILOCKS_AMD_API int goldilocks_amd_init(int device);
 GOLDILOCKS_AMD_API void goldilocks_amd_shutdown(void);
 GOLDILOCKS_AMD_API const char *goldilocks_amd_last_error(void);
+/* Multi-GPU for the host-array batches (independent operations, contiguous slice
+ * [g*n/G, (g+1)*n/G) per GPU, one host thread per GPU, no cross-device traffic): after this call
+ * goldilocks_448_point_scalarmul_batch, goldilocks_448_precomputed_scalarmul_batch and
+ * goldilocks_ed448_verify_batch split every batch over the listed HIP devices.  count = 0 restores
+ * the default (the calling thread's current device only); devices == NULL with count > 0 means
+ * devices 0..count-1.  A device may be listed more than once (its shards then run one after the
+ * other).  Returns 0 on success. */
+GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count);
 /* "gfx950", number of CUs, workspace bytes currently held */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
         size_t *workspace_bytes);

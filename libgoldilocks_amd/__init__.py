@@ -73,6 +73,7 @@ FUNCTIONS = {
     "goldilocks_amd_shutdown": (None, ""),
     "goldilocks_amd_last_error": (C.c_char_p, ""),
     "goldilocks_amd_device_info": (C.c_int, "pzpp"),
+    "goldilocks_amd_use_devices": (C.c_int, "pi"),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -371,6 +372,14 @@ class EDDSA448(object):
 def dev(name, *args):
     """Call goldilocks_amd_<name>_dev with raw device pointers (ints) / sizes; raises on error."""
     _check(getattr(lib(), "goldilocks_amd_%s_dev" % name)(*args))
+
+
+def use_devices(devices=None):
+    """Shard the host-array batches (variable-base, fixed-base, verify) over these HIP devices, one
+    host thread per device; None or [] restores the default (current device only)."""
+    devices = list(devices or [])
+    arr = (C.c_int * max(1, len(devices)))(*devices)
+    _check(lib().goldilocks_amd_use_devices(C.addressof(arr) if devices else None, len(devices)))
 
 
 def device_info():
