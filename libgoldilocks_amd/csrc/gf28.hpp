@@ -14,9 +14,13 @@
 //
 // MAGNITUDE CONTRACT (checked in the host-side checker build, GF_CHECKED):
 //   "mag k" = every limb <= k * 2^28 (+ a few units).  mul/sqr results are mag 1
-//   (limbs < 2^28, limbs 1 and 9 < 2^28 + 2^10).  mul(a,b) needs
-//   46 * maxlimb(a) * maxlimb(b) + 2^37 < 2^64, i.e. mag(a)*mag(b) <= 5.5,
-//   and mag(a) <= 7, mag(b) <= 5 so the pre-added halves fit 32 bits.
+//   (limbs < 2^28, limbs 1 and 9 < 2^28 + 2^10).  The accumulators are u64 and wrap: only the
+//   FINISHED column values (after Karatsuba's subtraction) have to fit 64 bits, intermediate
+//   chain values may exceed 2^64 because every step is exact mod 2^64.  The largest finished
+//   column of a product is high_0 = 3 + 7*5 = 38 limb products, so mul(a,b) needs
+//   38 * maxlimb(a) * maxlimb(b) + 2^37 < 2^64, i.e. mag(a)*mag(b) <= 6.7 (sum x difference = 2 x 3
+//   is fine, difference x difference = 9 is not), and mag(a) <= 7, mag(b) <= 5 so the pre-added
+//   halves (a0+a1, b0+2*b1) fit 32 bits.  sqr(a): 38 * maxlimb(a)^2, mag(a) <= 2.5.
 //
 // This header compiles for the device with hipcc and, for tests/hostsim only,
 // as plain C++ with g++ (the product never runs the host build).
@@ -46,16 +50,17 @@ struct fe {
 // Host-side checker accumulator: 128-bit, aborts if a 64-bit accumulator would
 // have overflowed or gone negative.
 struct acc_t {
-    unsigned __int128 x;
+    unsigned __int128 x;   // the exact value; the device accumulator holds it mod 2^64
     GD_MFN acc_t() : x(0) {}
     GD_MFN explicit acc_t(uint64_t v) : x(v) {}
+    // a finished column is read out: it must be what a wrapping u64 accumulator holds
     GD_MFN void chk() const { if (x >> 64) __builtin_trap(); }
-    GD_MFN void mac(uint32_t a, uint32_t b) { x += (unsigned __int128)a * b; chk(); }
-    GD_MFN void add(const acc_t &o) { x += o.x; chk(); }
-    GD_MFN void add32(uint32_t o) { x += o; chk(); }
+    GD_MFN void mac(uint32_t a, uint32_t b) { x += (unsigned __int128)a * b; }
+    GD_MFN void add(const acc_t &o) { x += o.x; }
+    GD_MFN void add32(uint32_t o) { x += o; }
     GD_MFN void sub(const acc_t &o) { if (o.x > x) __builtin_trap(); x -= o.x; }
-    GD_MFN uint32_t lo28() const { return (uint32_t)x & M28; }
-    GD_MFN void shr28() { x >>= 28; }
+    GD_MFN uint32_t lo28() const { chk(); return (uint32_t)x & M28; }
+    GD_MFN void shr28() { chk(); x >>= 28; }
     GD_MFN uint32_t lo32() const { if (x >> 32) __builtin_trap(); return (uint32_t)x; }
 };
 #else

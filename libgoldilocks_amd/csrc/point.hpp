@@ -72,7 +72,7 @@ GD_FN void pt_add_core(pt &p, const fe &zz, const fe &ea_, const fe &eb_, const 
     fe Cn = fe_mul(cn, p.t);                     // = -C of the reference
     fe E = fe_weak(fe_sub<2>(B, A));             // mag 1
     fe H = fe_add(A, B);                         // mag 2
-    fe zm = fe_weak(fe_sub<2>(zz, Cn));          // Z - Cn = Z + C   (G when adding)  mag 1
+    fe zm = fe_sub<2>(zz, Cn);                   // Z - Cn = Z + C   (G when adding)  mag 3: times E (1), H or zp (2)
     fe zp = fe_add(zz, Cn);                      // Z + Cn = Z - C   (F when adding)  mag 2
     fe F = fe_select(zp, zm, neg);
     fe G = fe_select(zm, zp, neg);

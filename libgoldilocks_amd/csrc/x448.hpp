@@ -27,7 +27,7 @@ GD_FN bool x448_core(uint32_t out[14], const uint32_t base[14], const BITS &bits
         swap = k_t;
         fe t1 = fe_add(a2, c2);                         // A = x2 + z2            mag 2
         fe t2 = fe_weak(fe_sub<2>(a2, c2));             // B = x2 - z2            mag 1
-        fe d = fe_weak(fe_sub<2>(a3, c3));              // D = x3 - z3            mag 1
+        fe d = fe_sub<2>(a3, c3);                       // D = x3 - z3            mag 3 (only multiplied by mag 2)
         fe da = fe_mul(t1, d);                          // DA
         fe c = fe_add(c3, a3);                          // C = x3 + z3            mag 2
         fe cb = fe_mul(c, t2);                          // CB
@@ -37,7 +37,7 @@ GD_FN bool x448_core(uint32_t out[14], const uint32_t base[14], const BITS &bits
         fe aa = fe_sqr(t1);                             // AA   (input mag 2)
         fe bb = fe_sqr(t2);                             // BB
         x2 = fe_mul(aa, bb);
-        fe e = fe_weak(fe_sub<2>(aa, bb));              // E = AA - BB            mag 1
+        fe e = fe_sub<2>(aa, bb);                       // E = AA - BB            mag 3 (mulw, and times f: 2 x 3)
         fe f = fe_add(fe_mulw(e, 39081), aa);           // AA + a24 E             mag 2
         z2 = fe_mul(f, e);
     }

@@ -46,7 +46,7 @@ def test_field_and_magnitude_contract(H, O):
         w = rnd.getrandbits(18)
         O.orc_gf_mulw(C.byref(o1), C.byref(a), w); H.hs_fe_mulw(C.byref(o2), C.byref(a), w)
         assert _ser(O, o1) == _ser(O, o2)
-        for ma, mb in ((2, 2), (5, 1), (1, 5), (4, 1), (3, 1), (1, 4)):      # documented magnitude limits
+        for ma, mb in ((2, 2), (5, 1), (1, 5), (4, 1), (3, 1), (1, 4), (2, 3), (3, 2), (6, 1)):   # documented limits
             H.hs_fe_mul_mag(C.byref(o2), C.byref(a), C.byref(b), ma, mb)
             assert o2.value() == a.value() * b.value() * ma * mb % P
         H.hs_fe_sqr_mag(C.byref(o2), C.byref(a), 2)
