@@ -46,16 +46,17 @@ GD_FN pt pt_identity() {
 GD_FN void pt_double(pt &p, bool need_t) {
     fe c = fe_sqr(p.x);
     fe a = fe_sqr(p.y);
-    fe d = fe_add(c, a);                         // mag 2
-    fe s = fe_add(p.x, p.y);                     // mag 2
-    fe b = fe_weak(fe_sub<4>(fe_sqr(s), d));     // (X+Y)^2 - X^2 - Y^2, mag 1
-    fe tt = fe_weak(fe_sub<2>(a, c));            // Y^2 - X^2, mag 1
+    fe d = fe_add(c, a);                         // X^2 + Y^2                     mag 2
+    fe s = fe_add(p.x, p.y);                     //                               mag 2
+    fe b = fe_sub<3>(fe_sqr(s), d);              // (X+Y)^2 - X^2 - Y^2           mag 4
+    fe tt = fe_sub<2>(a, c);                     // Y^2 - X^2                     mag 3
     fe zz = fe_sqr(p.z);
-    fe e = fe_sub<2>(fe_add(zz, zz), tt);        // 2Z^2 - (Y^2 - X^2), mag 4
+    fe e = fe_weak(fe_sub<4>(fe_add(zz, zz), tt));   // 2Z^2 - (Y^2 - X^2)        mag 1
+    // one weak reduction covers the three products every doubling needs (1x4, 1x3, 2x3 <= 6.7)
     p.x = fe_mul(e, b);
     p.z = fe_mul(e, tt);
     p.y = fe_mul(d, tt);
-    if (need_t) p.t = fe_mul(d, b);
+    if (need_t) p.t = fe_mul(d, fe_weak(b));     // 2 x 4 would not fit: reduce b for this one
 }
 
 // Core of the mixed additions.  zz = Z (niels) or Z*z (pniels); ea/eb/cn are the
