@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--workload", default="varbase", choices=["varbase", "fixed", "base", "verify", "sign", "x448"])
+    ap.add_argument("--table-access", default="fast", choices=["fast", "index-independent"],
+                    help="goldilocks_amd_set_table_access: how base-point tables are read for secret scalars "
+                         "(affects the base and sign workloads)")
     return ap.parse_args()
 
 
@@ -105,6 +108,7 @@ def main():
     import numpy as np
     import torch
     import libgoldilocks_amd as ga
+    ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT if args.table_access == "index-independent" else ga.TABLES_FAST)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -133,7 +137,7 @@ def main():
         bytes_per_op, kernel = 312, "k_precomputed_scalarmul"
     elif args.workload == "base":      # the built-in base point: 8-bit window table (no doublings)
         step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
-        bytes_per_op, kernel = 312, "k_base_scalarmul"
+        bytes_per_op, kernel = 312, ("k_precomputed_scalarmul" if args.table_access == "index-independent" else "k_base_scalarmul")
     elif args.workload in ("sign", "x448"):
         import _gen
         nb = 57 if args.workload == "sign" else 56
@@ -147,7 +151,7 @@ def main():
             sig_out = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
             step = lambda: ga.dev("ed448_sign", sig_out.data_ptr(), sk.data_ptr(), pk.data_ptr(), msg.data_ptr(), None,
                                   32, 0, None, 0, n, stream)
-            bytes_per_op, kernel = 57 + 57 + 32 + 114, "k_ed448_sign"
+            bytes_per_op, kernel = 57 + 57 + 32 + 114, ("k_ed448_sign_ct" if args.table_access == "index-independent" else "k_ed448_sign")
         else:
             peer = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
             ga.dev("x448", peer.data_ptr(), None, None, sk.data_ptr(), n, None)     # public keys as peer inputs
@@ -263,7 +267,8 @@ def main():
                                     "verify": "goldilocks_ed448_verify, 32-byte messages, 1% corrupted",
                                     "sign": "goldilocks_ed448_sign, 32-byte messages, no context",
                                     "x448": "goldilocks_x448, random peer public keys"}[args.workload],
-                       "batch_per_gpu": n, "sharding": "independent batch per GPU, no data-path collective",
+                       "batch_per_gpu": n, "table_access": args.table_access,
+                       "sharding": "independent batch per GPU, no data-path collective",
                        "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],
                        "parity_spot_check": "ok" if ok else "FAILED"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -250,6 +250,18 @@ GOLDILOCKS_AMD_API const char *goldilocks_amd_last_error(void);
  * devices 0..count-1.  A device may be listed more than once (its shards then run one after the
  * other).  Returns 0 on success. */
 GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count);
+/* Table-access policy for multiplications of the built-in base point by a SECRET scalar (key
+ * derivation, signing nonces, X448 key generation, precomputed_scalarmul on
+ * goldilocks_448_precomputed_base).  FAST (default): the 8-bit window table in global memory; the
+ * address of each lookup depends on the digit.  INDEX_INDEPENDENT: the reference's 5x5x18 comb
+ * staged in LDS, every lookup a wavefront-shuffle gather whose addresses and timing do not depend on
+ * the digit -- the counterpart of the reference's constant_time_lookup (src/include/
+ * constant_time.h:61-362), at about half the fixed-base throughput.  Process-wide; returns 0, or
+ * nonzero for an unknown mode.  Verification and caller-supplied precomputed_s tables are not
+ * affected (the latter always use the comb). */
+#define GOLDILOCKS_AMD_TABLES_FAST 0
+#define GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT 1
+GOLDILOCKS_AMD_API int goldilocks_amd_set_table_access(int mode);
 /* "gfx950", number of CUs, workspace bytes currently held */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
         size_t *workspace_bytes);

@@ -74,6 +74,7 @@ FUNCTIONS = {
     "goldilocks_amd_last_error": (C.c_char_p, ""),
     "goldilocks_amd_device_info": (C.c_int, "pzpp"),
     "goldilocks_amd_use_devices": (C.c_int, "pi"),
+    "goldilocks_amd_set_table_access": (C.c_int, "i"),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -380,6 +381,16 @@ def use_devices(devices=None):
     devices = list(devices or [])
     arr = (C.c_int * max(1, len(devices)))(*devices)
     _check(lib().goldilocks_amd_use_devices(C.addressof(arr) if devices else None, len(devices)))
+
+
+TABLES_FAST, TABLES_INDEX_INDEPENDENT = 0, 1
+
+
+def set_table_access(mode):
+    """TABLES_FAST (default) or TABLES_INDEX_INDEPENDENT: how the kernels that multiply the base point
+    by a secret scalar (derive, sign, X448 keygen, precomputed_scalarmul on the built-in table) look
+    up their table -- see include/goldilocks_amd.h."""
+    _check(lib().goldilocks_amd_set_table_access(int(mode)))
 
 
 def device_info():

@@ -33,8 +33,8 @@
 #define GD_MFN __device__ __forceinline__
 #define GD_CONST __device__ const
 #else
-#define GD_FN static inline __attribute__((always_inline))
-#define GD_MFN inline __attribute__((always_inline))
+#define GD_FN static inline   // the host checker build lets g++ decide (forced inlining costs minutes of compile time)
+#define GD_MFN inline
 #define GD_CONST static const
 #endif
 

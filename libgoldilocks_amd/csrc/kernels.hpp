@@ -241,6 +241,16 @@ GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk
                        const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
                        uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
                        uint32_t n, const uint4 *__restrict__ bwt, uint8_t *__restrict__ workspace);
+// index-independent variants (comb in LDS + wavefront-shuffle gather) of the three kernels that
+// multiply the base point by a SECRET scalar; selected by goldilocks_amd_set_table_access()
+GD_KERNEL k_ed448_derive_public_key_ct(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
+                                       const uint4 *__restrict__ comb);
+GD_KERNEL k_ed448_sign_ct(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,
+                          const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
+                          uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
+                          uint32_t n, const uint4 *__restrict__ comb, uint8_t *__restrict__ workspace);
+GD_KERNEL k_x448_derive_ct(uint8_t *__restrict__ shared, const uint8_t *__restrict__ scalar, uint32_t n,
+                           const uint4 *__restrict__ comb);
 GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
                              const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
                              int allow_identity, int short_circuit, uint4 *__restrict__ workspace,

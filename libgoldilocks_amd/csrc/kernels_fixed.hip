@@ -1,5 +1,5 @@
 // kernels_fixed.hip -- kernel definitions (see kernels.hpp for the memory plan and policies).
-#include "kernels.hpp"
+#include "fixed_bodies.hpp"
 
 namespace gd {
 
@@ -65,78 +65,21 @@ GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) {
     fe_store(q + 8, fe_mul(fe_mulw(p.t, TWO_EFF_D), zi));
 }
 
-// "next" row f1: pk[i] = derive_public_key(sk[i])   (ref: goldilocks_ed448_derive_public_key)
 GD_KERNEL k_ed448_derive_public_key(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
                                     const uint4 *__restrict__ bwt) {
-    __shared__ uint32_t s_bits[15 * BLOCK];
-    __shared__ uint32_t s_stage[34 * BLOCK];
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    GlobalBwt bwt_tab{bwt};
-    FixedBwt<GlobalBwt> fb{bwt_tab};
-    LdsStage stage{s_stage + threadIdx.x};
-    LdsMkBits mk{s_bits + threadIdx.x};
-    for (uint32_t i = lane; i < n; i += stride)
-        ed448_derive_core(pk + 57 * (size_t)i, sk + 57 * (size_t)i, fb, stage, mk);
+    derive_body<false>(pk, sk, n, bwt);
 }
 
-// "next" row f1: sig[i] = sign(sk[i], pk[i], msg[i])   (ref: goldilocks_ed448_sign)
 GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,
                        const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
                        uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
                        uint32_t n, const uint4 *__restrict__ bwt, uint8_t *__restrict__ workspace) {
-    __shared__ uint32_t s_bits[15 * BLOCK];
-    __shared__ uint32_t s_stage[34 * BLOCK];
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    GlobalBwt bwt_tab{bwt};
-    FixedBwt<GlobalBwt> fb{bwt_tab};
-    LdsStage stage{s_stage + threadIdx.x};
-    LdsMkBits mk{s_bits + threadIdx.x};
-    uint8_t *scratch = workspace + (size_t)lane * 64;   // the hashed-key seed of the signature in flight
-    for (uint32_t i = lane; i < n; i += stride) {
-        const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
-        const uint32_t mlen = msg_offsets ? (uint32_t)(msg_offsets[i + 1] - msg_offsets[i]) : msg_len;
-        ed448_sign_core(sig + 114 * (size_t)i, sk + 57 * (size_t)i, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx,
-                        ctx_len, scratch, fb, stage, mk);
-    }
+    sign_body<false>(sig, sk, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, workspace);
 }
 
-// "next" row f3: X448.  base == nullptr: derive_public_key through the comb   (ref: goldilocks_x448*)
 GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
                  const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt) {
-    __shared__ uint32_t s_bits[15 * BLOCK];
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    GlobalBwt tab{bwt};
-    for (uint32_t i = lane; i < n; i += stride) {
-        const bool live = true;
-        uint32_t w[14], o[14];
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(scalar + 56 * (size_t)i);
-#pragma unroll
-        for (int k = 0; k < 14; k++) w[k] = src[k];
-        bool ok = true;
-        if (base) {
-            uint32_t b[14];
-            const uint32_t *bs = reinterpret_cast<const uint32_t *>(base + 56 * (size_t)i);
-#pragma unroll
-            for (int k = 0; k < 14; k++) b[k] = bs[k];
-            sc raw;
-#pragma unroll
-            for (int k = 0; k < 14; k++) raw.w[k] = w[k];
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, raw);
-            ok = x448_core(o, b, bits);
-        } else {
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed8(x448_public_scalar(w)));
-            pt_encode_x448_words(o, ladder_bwt(bits, tab));
-        }
-        if (live) {
-            uint32_t *dst = reinterpret_cast<uint32_t *>(shared + 56 * (size_t)i);
-#pragma unroll
-            for (int k = 0; k < 14; k++) dst[k] = o[k];
-            if (status) status[i] = ok ? -1 : 0;
-        }
-    }
+    x448_body<false>(shared, status, base, scalar, n, bwt);
 }
 
 }  // namespace gd
