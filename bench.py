@@ -37,7 +37,7 @@ BYTES_PER_OP = 568          # algorithmic: 256 (point in) + 56 (scalar in) + 256
 MACS_PER_OP = 680_584       # 2279 M x 192 + 1785 S x 136 + 16 mulw x 16 MACs per op
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_MAC_PEAK = 36.0e12     # measured: 560-576 G v_mad_u64_u32 wave-instr/s x 64 lanes (profiles/r01/ubench.txt)
-VALU_INSTR_PER_OP = 1.113e6 # VALU wave-instructions per op: SQ_INSTS_VALU / wave-ops (profiles/r01/rocprofv3_pmc_summary.json)
+VALU_INSTR_PER_OP = 1.092e6 # VALU wave-instructions per op: SQ_INSTS_VALU / wave-ops (profiles/r01/rocprofv3_pmc_summary.json)
 VALU_ISSUE_PEAK = 600e9     # measured: wave-instr/s of a 1:1 MAC:simple mix at 2+ waves/SIMD (ubench mix_mac_add)
 
 
