@@ -64,3 +64,12 @@ assert call() == 0 and (sth == -1).all()
 for rep in range(3):
     t0 = time.perf_counter(); assert call() == 0; dt = time.perf_counter() - t0
     print("verify host-array API (pack + H2D + kernel + D2H) n=2^20  %.1f ms  %.2f M/s" % (dt * 1e3, n / dt / 1e6), flush=True)
+
+# PCIe-inclusive rate of the host-array fixed-base API (56 B up, 256 B down per operation)
+outf = np.zeros((n, 32), dtype=np.uint64)
+call = lambda: L.goldilocks_448_precomputed_scalarmul_batch(outf.ctypes.data, C.c_void_p.in_dll(L, "goldilocks_448_precomputed_base"), sh.ctypes.data, n)
+assert call() == 0
+for rep in range(3):
+    t0 = time.perf_counter(); assert call() == 0; dt = time.perf_counter() - t0
+    print("fixed-base host-array API (H2D + kernel + D2H) n=2^20  %.1f ms  %.2f M/s" % (dt * 1e3, n / dt / 1e6), flush=True)
+assert (ga.point_encode_batch(outf[:64]) == _gen.oracle_encode(_gen.oracle_fixed(O, sh[:64]))).all()
