@@ -77,6 +77,36 @@ int main(void) {
         puts("x448 DH");
         return 1;
     }
+
+    /* batch entry points: host arrays, then the same batch sharded over "two GPUs" (device 0 listed
+       twice on a one-GPU box) and with index-independent table access; all must agree */
+    enum { NB = 300 };
+    static goldilocks_448_scalar_s ks[NB];
+    static goldilocks_448_point_s fixed1[NB], fixed2[NB], var1[NB], var2[NB];
+    for (int i = 0; i < NB; i++) {
+        memset(&ks[i], 0, sizeof(ks[i]));
+        ks[i].limb[0] = 0x9e3779b97f4a7c15ull * (uint64_t)(i + 1);
+        ks[i].limb[3] = (uint64_t)i * i + 17;
+    }
+    if (goldilocks_448_precomputed_scalarmul_batch(fixed1, goldilocks_448_precomputed_base, ks, NB) ||
+        goldilocks_448_point_scalarmul_batch(var1, fixed1, ks, NB)) {
+        printf("batch: %s\n", goldilocks_amd_last_error());
+        return 1;
+    }
+    const int two[2] = {0, 0};
+    if (goldilocks_amd_use_devices(two, 2) || goldilocks_amd_set_table_access(GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT) ||
+        goldilocks_448_precomputed_scalarmul_batch(fixed2, goldilocks_448_precomputed_base, ks, NB) ||
+        goldilocks_448_point_scalarmul_batch(var2, fixed2, ks, NB) || goldilocks_amd_use_devices(NULL, 0) ||
+        goldilocks_amd_set_table_access(GOLDILOCKS_AMD_TABLES_FAST)) {
+        printf("sharded batch: %s\n", goldilocks_amd_last_error());
+        return 1;
+    }
+    for (int i = 0; i < NB; i++) {
+        if (!goldilocks_448_point_eq(&fixed1[i], &fixed2[i]) || !goldilocks_448_point_eq(&var1[i], &var2[i])) {
+            printf("sharded / index-independent batch differs at %d\n", i);
+            return 1;
+        }
+    }
     puts("dropin_test ok");
     return 0;
 }
