@@ -233,8 +233,12 @@ GD_FN void store_words_as_bytes(uint8_t *p, const uint32_t *w, int nbytes) {
 }
 
 // pk = encode_like_eddsa( (clamp(SHAKE256(sk)[0:57]) / 4) * B )      src/eddsa.c:98-147
+// Two halves around the one field inversion of the encoding: begin() returns its denominator.
+struct Ed448DeriveState {
+    fe xn, yn;
+};
 template <class FB, class STAGE, class MKBITS>
-GD_FN void ed448_derive_core(uint8_t *pk57, const uint8_t *sk57, const FB &fb, STAGE &stage, MKBITS &mkbits) {
+GD_FN fe ed448_derive_begin(Ed448DeriveState &st, const uint8_t *sk57, const FB &fb, STAGE &stage, MKBITS &mkbits) {
     Ed448Msg m;
     m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
     m.ctx = sk57; m.ctxlen = 0; m.ph = 0; m.dom = false;
@@ -244,17 +248,34 @@ GD_FN void ed448_derive_core(uint8_t *pk57, const uint8_t *sk57, const FB &fb, S
     sc secret = sc_decode_long_words<57>(w);
     secret = sc_halve(sc_halve(secret));                       // ENCODE_RATIO = 4
     pt p = fb.mul(secret, mkbits);
+    fe zn;
+    pt_eddsa_isogeny(st.xn, st.yn, zn, p);
+    return zn;
+}
+GD_FN void ed448_derive_finish(uint8_t *pk57, const Ed448DeriveState &st, const fe &zi) {
     uint32_t e[15];
-    pt_encode_eddsa_words(e, p);
+    eddsa_finish_words(e, st.xn, st.yn, zi);
     store_words_as_bytes(pk57, e, 57);
+}
+template <class FB, class STAGE, class MKBITS>
+GD_FN void ed448_derive_core(uint8_t *pk57, const uint8_t *sk57, const FB &fb, STAGE &stage, MKBITS &mkbits) {
+    Ed448DeriveState st;
+    fe zn = ed448_derive_begin(st, sk57, fb, stage, mkbits);
+    ed448_derive_finish(pk57, st, fe_invert(zn));
 }
 
 // RFC 8032 signing (src/eddsa.c:149-230).  scratch: 64 bytes of lane-private memory for the
 // hashed-key seed.  sig114 doubles as the place R is read back from for the challenge hash.
+// begin(): everything up to the point R = (nonce/4)*B and its isogeny image; returns the denominator
+// of R's encoding.  finish(): encode R with the inverse, hash the challenge, write R | S.
+struct Ed448SignState {
+    fe xn, yn;
+    sc nonce, secret;
+};
 template <class FB, class STAGE, class MKBITS>
-GD_FN void ed448_sign_core(uint8_t *sig114, const uint8_t *sk57, const uint8_t *pk57, const uint8_t *msg,
-                           uint32_t msglen, uint32_t ph, const uint8_t *ctx, uint32_t ctxlen, uint8_t *scratch,
-                           const FB &fb, STAGE &stage, MKBITS &mkbits) {
+GD_FN fe ed448_sign_begin(Ed448SignState &st, const uint8_t *sk57, const uint8_t *msg, uint32_t msglen, uint32_t ph,
+                          const uint8_t *ctx, uint32_t ctxlen, uint8_t *scratch, const FB &fb, STAGE &stage,
+                          MKBITS &mkbits) {
     Ed448Msg m;
     m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
     m.ctx = ctx; m.ctxlen = 0; m.ph = 0; m.dom = false;
@@ -266,26 +287,43 @@ GD_FN void ed448_sign_core(uint8_t *sig114, const uint8_t *sk57, const uint8_t *
 #pragma unroll
     for (int i = 0; i < 15; i++) sw[i] = w[i];
     ed448_clamp_words(sw);
-    sc secret = sc_decode_long_words<57>(sw);
+    st.secret = sc_decode_long_words<57>(sw);
 
     m.a = scratch; m.alen = 57; m.blen = 0; m.msg = msg; m.msglen = msglen;
     m.ctx = ctx; m.ctxlen = ctxlen; m.ph = ph ? 1u : 0u; m.dom = true;
     shake256_114(w, m, m.total(), stage);
-    sc nonce = sc_decode_long_words<114>(w);
-    pt rp = fb.mul(sc_halve(sc_halve(nonce)), mkbits);
+    st.nonce = sc_decode_long_words<114>(w);
+    pt rp = fb.mul(sc_halve(sc_halve(st.nonce)), mkbits);
+    fe zn;
+    pt_eddsa_isogeny(st.xn, st.yn, zn, rp);
+    return zn;
+}
+template <class STAGE>
+GD_FN void ed448_sign_finish(uint8_t *sig114, const Ed448SignState &st, const fe &zi, const uint8_t *pk57,
+                             const uint8_t *msg, uint32_t msglen, uint32_t ph, const uint8_t *ctx, uint32_t ctxlen,
+                             STAGE &stage) {
     uint32_t e[15];
-    pt_encode_eddsa_words(e, rp);
+    eddsa_finish_words(e, st.xn, st.yn, zi);
     store_words_as_bytes(sig114, e, 57);
 
+    uint32_t w[29];
     Ed448Msg c = ed448_challenge_string(sig114, pk57, msg, msglen, ph, ctx, ctxlen);
     shake256_114(w, c, c.total(), stage);
     sc challenge = sc_decode_long_words<114>(w);
-    sc resp = sc_add(sc_mul(challenge, secret), nonce);
+    sc resp = sc_add(sc_mul(challenge, st.secret), st.nonce);
     uint32_t rw[15];
 #pragma unroll
     for (int i = 0; i < 14; i++) rw[i] = resp.w[i];
     rw[14] = 0;
     store_words_as_bytes(sig114 + 57, rw, 57);
+}
+template <class FB, class STAGE, class MKBITS>
+GD_FN void ed448_sign_core(uint8_t *sig114, const uint8_t *sk57, const uint8_t *pk57, const uint8_t *msg,
+                           uint32_t msglen, uint32_t ph, const uint8_t *ctx, uint32_t ctxlen, uint8_t *scratch,
+                           const FB &fb, STAGE &stage, MKBITS &mkbits) {
+    Ed448SignState st;
+    fe zn = ed448_sign_begin(st, sk57, msg, msglen, ph, ctx, ctxlen, scratch, fb, stage, mkbits);
+    ed448_sign_finish(sig114, st, fe_invert(zn), pk57, msg, msglen, ph, ctx, ctxlen, stage);
 }
 
 #if !defined(__HIPCC__)

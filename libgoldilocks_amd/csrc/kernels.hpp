@@ -28,6 +28,10 @@ constexpr int BLOCK = 256;          // 4 waves: one per SIMD
 constexpr int WAVES_PER_SIMD = GD_WAVES_PER_SIMD;   // 2 blocks per CU -> 256-VGPR budget per lane
 constexpr int TABLE_U4 = 17 * 16;    // uint4 per lane window table (16 entries + 1 build slot, x 4 fe x 4 uint4)
 constexpr int PRECOMP_U4 = 80 * 20 + 64;  // uint4 per lane for k_precompute: 80 x 5 fe + 4 doubled teeth
+// per-OPERATION workspace of the kernels that share one inversion between a lane's operations
+// (fixed_bodies.hpp): numerator(s) | denominator | prefix product [| nonce | secret scalar]
+constexpr int DERIVE_SLOT_U4 = 16, SIGN_SLOT_U4 = 24, X448_SLOT_U4 = 12;
+constexpr int SHARED_INV_OPS_PER_LANE = 8;   // a launch covers at most this many operations per resident lane
 
 // ---------------------------------------------------------------- register <-> memory
 
@@ -236,21 +240,21 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
                          const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
                          uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt);
 GD_KERNEL k_ed448_derive_public_key(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
-                                    const uint4 *__restrict__ bwt);
+                                    const uint4 *__restrict__ bwt, uint4 *__restrict__ workspace);
 GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,
                        const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
                        uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
-                       uint32_t n, const uint4 *__restrict__ bwt, uint8_t *__restrict__ workspace);
+                       uint32_t n, const uint4 *__restrict__ bwt, uint4 *__restrict__ workspace);
 // index-independent variants (comb in LDS + wavefront-shuffle gather) of the three kernels that
 // multiply the base point by a SECRET scalar; selected by goldilocks_amd_set_table_access()
 GD_KERNEL k_ed448_derive_public_key_ct(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
-                                       const uint4 *__restrict__ comb);
+                                       const uint4 *__restrict__ comb, uint4 *__restrict__ workspace);
 GD_KERNEL k_ed448_sign_ct(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,
                           const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
                           uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
-                          uint32_t n, const uint4 *__restrict__ comb, uint8_t *__restrict__ workspace);
+                          uint32_t n, const uint4 *__restrict__ comb, uint4 *__restrict__ workspace);
 GD_KERNEL k_x448_derive_ct(uint8_t *__restrict__ shared, const uint8_t *__restrict__ scalar, uint32_t n,
-                           const uint4 *__restrict__ comb);
+                           const uint4 *__restrict__ comb, uint4 *__restrict__ workspace);
 GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
                              const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
                              int allow_identity, int short_circuit, uint4 *__restrict__ workspace,
@@ -260,7 +264,8 @@ GD_KERNEL k_point_dual_scalarmul(uint64_t *__restrict__ out1, uint64_t *__restri
                                  const uint64_t *__restrict__ s2, uint32_t n, uint4 *__restrict__ workspace);
 GD_KERNEL k_point_from_hash(uint64_t *__restrict__ out, const uint8_t *__restrict__ hash, uint32_t n, int uniform);
 GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
-                 const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt);
+                 const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt,
+                 uint4 *__restrict__ workspace);
 GD_KERNEL k_point_encode(uint8_t *__restrict__ ser, const uint64_t *__restrict__ pts, uint32_t n, int eddsa);
 GD_KERNEL k_point_decode(uint64_t *__restrict__ pts, int32_t *__restrict__ status,
                          const uint8_t *__restrict__ ser, uint32_t n, int eddsa, int allow_identity);

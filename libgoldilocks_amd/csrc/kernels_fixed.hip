@@ -66,20 +66,21 @@ GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) {
 }
 
 GD_KERNEL k_ed448_derive_public_key(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
-                                    const uint4 *__restrict__ bwt) {
-    derive_body<false>(pk, sk, n, bwt);
+                                    const uint4 *__restrict__ bwt, uint4 *__restrict__ workspace) {
+    derive_body<false>(pk, sk, n, bwt, workspace);
 }
 
 GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,
                        const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
                        uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
-                       uint32_t n, const uint4 *__restrict__ bwt, uint8_t *__restrict__ workspace) {
+                       uint32_t n, const uint4 *__restrict__ bwt, uint4 *__restrict__ workspace) {
     sign_body<false>(sig, sk, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, workspace);
 }
 
 GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
-                 const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt) {
-    x448_body<false>(shared, status, base, scalar, n, bwt);
+                 const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt,
+                 uint4 *__restrict__ workspace) {
+    x448_body<false>(shared, status, base, scalar, n, bwt, workspace);
 }
 
 }  // namespace gd

@@ -270,9 +270,10 @@ GD_FN pt pt_from_hash_words(const uint32_t in[14]) {
     return p;
 }
 
-// Dual isogeny back to Ed448 and RFC 8032 encoding (src/goldilocks.c:905-946).
-// out: 57 bytes as 15 words (upper 3 bytes of word 14 are zero).
-GD_FN void pt_encode_eddsa_words(uint32_t out[15], const pt &p) {
+// Dual isogeny back to Ed448 and RFC 8032 encoding (src/goldilocks.c:905-946), in two halves so that
+// a kernel can put one shared inversion between them (Montgomery's trick along a lane's operations).
+// (xn : yn : zn) = 4 * P in projective Ed448 coordinates.
+GD_FN void pt_eddsa_isogeny(fe &xn, fe &yn, fe &zn, const pt &p) {
     fe x = fe_sqr(p.x);
     fe t = fe_sqr(p.y);
     fe u = fe_add(x, t);                                     // mag 2
@@ -280,14 +281,21 @@ GD_FN void pt_encode_eddsa_words(uint32_t out[15], const pt &p) {
     fe z = fe_weak(fe_sub<2>(t, x));                         // Y^2 - X^2
     fe zz = fe_sqr(p.z);
     fe tt = fe_weak(fe_sub<2>(fe_add(zz, zz), z));           // 2Z^2 - (Y^2 - X^2)
-    fe xn = fe_mul(tt, y);
-    fe yn = fe_mul(u, z);
-    fe zn = fe_mul(u, tt);
-    fe zi = fe_invert(zn);
+    xn = fe_mul(tt, y);
+    yn = fe_mul(u, z);
+    zn = fe_mul(u, tt);
+}
+// out: 57 bytes as 15 words (upper 3 bytes of word 14 are zero); zi = 1/zn
+GD_FN void eddsa_finish_words(uint32_t out[15], const fe &xn, const fe &yn, const fe &zi) {
     fe xa = fe_mul(xn, zi);
     fe ya = fe_mul(yn, zi);
     fe_serialize_words(out, ya);
     out[14] = fe_lobit(xa) ? 0x80u : 0u;
+}
+GD_FN void pt_encode_eddsa_words(uint32_t out[15], const pt &p) {
+    fe xn, yn, zn;
+    pt_eddsa_isogeny(xn, yn, zn, p);
+    eddsa_finish_words(out, xn, yn, fe_invert(zn));
 }
 
 }  // namespace gd

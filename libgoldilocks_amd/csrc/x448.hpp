@@ -9,8 +9,11 @@ namespace gd {
 
 // BITS: bits.word(k) = k-th 32-bit word of the 56-byte scalar as given (clamping is applied here).
 // base/out: 56-byte strings as 14 words.  Returns false iff the result is zero (reference :1065,1075).
+// x448_ladder leaves the result as the fraction rx / rz; x448_finish takes 1/rz (0 for rz = 0, as
+// gf_invert(0) = 0 in the reference) -- two halves so a kernel can share one inversion between the
+// operations of a lane.
 template <class BITS>
-GD_FN bool x448_core(uint32_t out[14], const uint32_t base[14], const BITS &bits) {
+GD_FN void x448_ladder(fe &rx, fe &rz, const uint32_t base[14], const BITS &bits) {
     fe x1;
     (void)fe_deserialize_words(x1, base);   // the reference ignores the range check too (:1014)
     fe x2 = fe_one(), z2 = fe_zero(), x3 = x1, z3 = fe_one();
@@ -41,17 +44,27 @@ GD_FN bool x448_core(uint32_t out[14], const uint32_t base[14], const BITS &bits
         fe f = fe_add(fe_mulw(e, 39081), aa);           // AA + a24 E             mag 2
         z2 = fe_mul(f, e);
     }
-    fe rx = fe_select(x2, x3, swap), rz = fe_select(z2, z3, swap);
-    fe r = fe_mul(rx, fe_invert(rz));
+    rx = fe_select(x2, x3, swap);
+    rz = fe_select(z2, z3, swap);
+}
+GD_FN bool x448_finish(uint32_t out[14], const fe &rx, const fe &rzi) {
+    fe r = fe_mul(rx, rzi);
     fe_serialize_words(out, r);
     return !fe_is_zero(r);
 }
+template <class BITS>
+GD_FN bool x448_core(uint32_t out[14], const uint32_t base[14], const BITS &bits) {
+    fe rx, rz;
+    x448_ladder(rx, rz, base, bits);
+    return x448_finish(out, rx, fe_invert(rz));
+}
 
-// (y/x)^2 of a twisted-Edwards point, serialized (src/goldilocks.c:1102-1113)
-GD_FN void pt_encode_x448_words(uint32_t out[14], const pt &p) {
-    fe r = fe_mul(fe_invert(p.x), p.y);
+// (y/x)^2 of a twisted-Edwards point, serialized (src/goldilocks.c:1102-1113); xi = 1/x
+GD_FN void x448_public_finish(uint32_t out[14], const fe &y, const fe &xi) {
+    fe r = fe_mul(xi, y);
     fe_serialize_words(out, fe_sqr(r));
 }
+GD_FN void pt_encode_x448_words(uint32_t out[14], const pt &p) { x448_public_finish(out, p.y, fe_invert(p.x)); }
 
 // the scalar x448_derive_public_key multiplies the base point by (src/goldilocks.c:1119-1136)
 GD_FN sc x448_public_scalar(const uint32_t scalar_words[14]) {

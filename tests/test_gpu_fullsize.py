@@ -189,3 +189,66 @@ def test_index_independent_tables_match_fast_tables(ga, O):
         want_pk = np.empty((m, 57), np.uint8)
         O.orc_ed448_derive_public_key_batch(_p(want_pk), _p(np.ascontiguousarray(sk[:m])), m, _gen.NTHREADS)
         assert (pk1[:m] == want_pk).all()
+
+
+def test_shared_inversion_chains_with_zero_denominators(ga, O):
+    """derive / sign / X448 share one field inversion between the operations a lane handles back to
+    back (Montgomery's trick, fixed_bodies.hpp).  With more operations than resident lanes, put
+    low-order X448 inputs (result 0, denominator 0) at several positions of the same lane's chain and
+    compare those lanes, their neighbours and a random sample with the oracle one by one."""
+    lanes = ga.device_info()["compute_units"] * 2 * 256
+    n = 3 * lanes + 5
+    sc = np.frombuffer(_gen.stream(b"inv/x448-s", 56 * n), np.uint8).reshape(n, 56).copy()
+    bs = np.frombuffer(_gen.stream(b"inv/x448-b", 56 * n), np.uint8).reshape(n, 56).copy()
+    zero_at = [7, 7 + lanes, 9 + 2 * lanes, 11, 11 + lanes, 11 + 2 * lanes, n - 1]
+    for j, i in enumerate(zero_at):
+        bs[i] = 0
+        if j % 2:
+            bs[i, 0] = 1                       # u = 1 is low-order as well
+    got, st = ga.x448_batch(sc, bs)
+    rng = np.random.default_rng(3)
+    check = sorted(set(zero_at + [7 + 2 * lanes, 9, 9 + lanes, 0, 1, lanes, 2 * lanes, 3 * lanes]
+                       + list(rng.integers(0, n, 200))))
+    w = (C.c_uint8 * 56)()
+    for i in check:
+        assert O.orc_x448(w, bs[i].ctypes.data, sc[i].ctypes.data) == st[i], i
+        assert bytes(w) == got[i].tobytes(), i
+    assert all(st[i] == 0 and not got[i].any() for i in zero_at)
+    assert (st == -1).sum() == n - len(zero_at)
+    # sign with three operations per lane against the oracle on a sample (ragged message lengths)
+    m = 2 * lanes + 77
+    sk = np.frombuffer(_gen.stream(b"inv/sk", 57 * m), np.uint8).reshape(m, 57).copy()
+    pk = ga.ed448_derive_public_key_batch(sk)
+    msgs = [bytes([i & 255]) * (i % 70) for i in range(m)]
+    sig = ga.ed448_sign_batch(sk, pk, msgs, context=b"chain")
+    assert (ga.ed448_verify_batch(sig, pk, msgs, context=b"chain") == -1).all()
+    ctx = (C.c_uint8 * 5).from_buffer_copy(b"chain")
+    for i in [0, 1, lanes - 1, lanes, lanes + 1, 2 * lanes, m - 1] + list(rng.integers(0, m, 60)):
+        wpk, wsig = (C.c_uint8 * 57)(), (C.c_uint8 * 114)()
+        O.orc_ed448_derive_public_key(wpk, sk[i].ctypes.data)
+        mb = (C.c_uint8 * max(1, len(msgs[i]))).from_buffer_copy(msgs[i] or b"\0")
+        O.orc_ed448_sign(wsig, sk[i].ctypes.data, wpk, mb, len(msgs[i]), 0, ctx, 5)
+        assert bytes(wpk) == pk[i].tobytes() and bytes(wsig) == sig[i].tobytes(), i
+
+
+def test_sub_batched_launches_beyond_eight_operations_per_lane(ga, O):
+    """More than 8 operations per resident lane: the host splits the batch into several launches that
+    reuse the per-operation workspace; results must not depend on where the split falls."""
+    lanes = ga.device_info()["compute_units"] * 2 * 256
+    n = 8 * lanes + 1234
+    sk = np.frombuffer(_gen.stream(b"sub/sk", 57 * n), np.uint8).reshape(n, 57).copy()
+    pk = ga.ed448_derive_public_key_batch(sk)
+    tail = ga.ed448_derive_public_key_batch(sk[8 * lanes - 50:])          # a different split of the same keys
+    assert (pk[8 * lanes - 50:] == tail).all()
+    idx = np.concatenate([np.arange(8 * lanes - 3, 8 * lanes + 3), np.array([0, n - 1]),
+                          np.random.default_rng(4).integers(0, n, 100)])
+    want = np.empty((len(idx), 57), np.uint8)
+    O.orc_ed448_derive_public_key_batch(_p(want), _p(np.ascontiguousarray(sk[idx])), len(idx), _gen.NTHREADS)
+    assert (pk[idx] == want).all()
+    xs = sk[:, :56].copy()
+    pub, st = ga.x448_batch(xs)
+    assert (st == -1).all()
+    w = (C.c_uint8 * 56)()
+    for i in [0, 8 * lanes - 1, 8 * lanes, n - 1]:
+        O.orc_x448_derive_public_key(w, xs[i].ctypes.data)
+        assert bytes(w) == pub[i].tobytes(), i
