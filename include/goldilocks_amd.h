@@ -140,6 +140,18 @@ GOLDILOCKS_AMD_API void goldilocks_448_point_sub(goldilocks_448_point_p diff,
         const goldilocks_448_point_p a, const goldilocks_448_point_p b);
 GOLDILOCKS_AMD_API void goldilocks_448_point_double(goldilocks_448_point_p two_a,
         const goldilocks_448_point_p a);
+/* nega = -a.  ref: point_448.h:343-346, src/goldilocks.c:260-268 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_negate(goldilocks_448_point_p nega,
+        const goldilocks_448_point_p a);
+/* Memory-only helpers of the reference API (no field arithmetic, so nothing to launch):
+ * copy (ref: point_448.h:273-278), constant-time select between two points, pick_b nonzero -> b
+ * (ref: point_448.h:558-563, src/goldilocks.c:879-886), secure erase (ref: point_448.h:734-745,
+ * src/goldilocks.c:1332-1342). */
+static inline void goldilocks_448_point_copy(goldilocks_448_point_p a, const goldilocks_448_point_p b) { *a = *b; }
+GOLDILOCKS_AMD_API void goldilocks_448_point_cond_sel(goldilocks_448_point_p out,
+        const goldilocks_448_point_p a, const goldilocks_448_point_p b, goldilocks_word_t pick_b);
+GOLDILOCKS_AMD_API void goldilocks_448_point_destroy(goldilocks_448_point_p point);
+GOLDILOCKS_AMD_API void goldilocks_448_precomputed_destroy(goldilocks_448_precomputed_s *pre);
 
 /* RFC 8032 Ed448 verification.  ref: ed448.h:157-165, src/eddsa.c:253-306 */
 GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_ed448_verify(
@@ -284,7 +296,7 @@ GOLDILOCKS_AMD_API int goldilocks_amd_point_encode_eddsa_dev(void *enc /* n*57 B
         void *stream);
 GOLDILOCKS_AMD_API int goldilocks_amd_point_decode_eddsa_dev(void *pt, void *status /* int32[n] */,
         const void *enc, size_t n, void *stream);
-/* op: 0 add, 1 sub, 2 double (b ignored); out/a/b: point_s[n] */
+/* op: 0 add, 1 sub, 2 double, 3 negate (b ignored); out/a/b: point_s[n] */
 GOLDILOCKS_AMD_API int goldilocks_amd_point_op_dev(void *out, const void *a, const void *b, int op, size_t n,
         void *stream);
 /* op: 0 eq(a,b), 1 valid(a); status: int32[n] (-1 / 0) */

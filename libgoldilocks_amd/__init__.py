@@ -45,6 +45,10 @@ FUNCTIONS = {
     "goldilocks_448_point_add": (None, "ppp"),
     "goldilocks_448_point_sub": (None, "ppp"),
     "goldilocks_448_point_double": (None, "pp"),
+    "goldilocks_448_point_negate": (None, "pp"),
+    "goldilocks_448_point_cond_sel": (None, "pppQ"),
+    "goldilocks_448_point_destroy": (None, "p"),
+    "goldilocks_448_precomputed_destroy": (None, "p"),
     "goldilocks_ed448_verify": (C.c_int, "pppzBpB"),
     "goldilocks_ed448_derive_public_key": (None, "pp"),
     "goldilocks_448_point_dual_scalarmul": (None, "ppppp"),

@@ -54,6 +54,8 @@ GD_KERNEL k_point_op(uint64_t *__restrict__ out, const uint64_t *__restrict__ a,
         pt p = pt_load_abi(a + 32 * (size_t)i);
         if (op == 2) {
             pt_double(p, true);
+        } else if (op == 3) {
+            p = pt_negate(p);
         } else {
             pt q = pt_load_abi(b + 32 * (size_t)i);
             p = pt_add(p, q, op == 1);

@@ -121,3 +121,32 @@ def test_scalar_edge_identities(ga, world):
     assert (enc(out.cpu().numpy().view(np.uint64)) == 0).all()        # p + (-p) = identity
     # q*p = identity: scalars are taken mod q, Q itself reduces to 0 in the callers' encoding
     assert (enc(ga.precomputed_scalarmul_batch(zero)) == 0).all()
+
+
+def test_negate_cond_sel_destroy(ga, world):
+    """point_negate on the GPU ((q-1)*P == -P, P + (-P) == identity) and the memory-only helpers."""
+    import ctypes as C
+    x, y, p, q = world
+    L = ga.lib()
+    qm1 = _gen.scalars_from_ints([Q - 1] * N)
+    want = ga.point_scalarmul_batch(p, qm1)
+    ident = ga.point_identity()
+    for i in range(0, N, 37):
+        neg = np.empty(32, np.uint64)
+        L.goldilocks_448_point_negate(neg.ctypes.data, p[i].ctypes.data)
+        assert L.goldilocks_448_point_eq(neg.ctypes.data, want[i].ctypes.data)
+        s = np.empty(32, np.uint64)
+        L.goldilocks_448_point_add(s.ctypes.data, neg.ctypes.data, p[i].ctypes.data)
+        assert L.goldilocks_448_point_eq(s.ctypes.data, ident.ctypes.data)
+        L.goldilocks_448_point_negate(neg.ctypes.data, neg.ctypes.data)          # in place
+        assert L.goldilocks_448_point_eq(neg.ctypes.data, p[i].ctypes.data)
+    out = np.empty(32, np.uint64)
+    L.goldilocks_448_point_cond_sel(out.ctypes.data, p[0].ctypes.data, q[0].ctypes.data, 0)
+    assert (out == p[0]).all()
+    L.goldilocks_448_point_cond_sel(out.ctypes.data, p[0].ctypes.data, q[0].ctypes.data, 1 << 40)
+    assert (out == q[0]).all()
+    L.goldilocks_448_point_destroy(out.ctypes.data)
+    assert not out.any()
+    tab = ga.precompute(p[0]).copy()
+    L.goldilocks_448_precomputed_destroy(tab.ctypes.data)
+    assert not tab.any()
