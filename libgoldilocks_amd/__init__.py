@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GOLDILOCKS_AMD_LIB selects an experimental build variant (tools/gpu_probe.py); default: the in-tree product.
+# GOLDILOCKS_AMD_LIB selects an experimental build variant (tests/gpu_probe.py); default: the in-tree product.
 LIB_PATH = os.environ.get("GOLDILOCKS_AMD_LIB") or os.path.join(_HERE, "libgoldilocks_amd.so")
 
 GOLDILOCKS_SUCCESS = -1
