@@ -1,5 +1,6 @@
 """Larger randomized differential runs of every kernel against the oracle (rare-carry hunting):
-32768 lanes per kernel, bit-exact on encodings / bytes / status."""
+32768 lanes per kernel, bit-exact on encodings / bytes / status.  GOLDILOCKS_SOAK_SEED=<text> draws a
+different input stream (used for extended soaks on the GPU box; the default stream is fixed)."""
 import ctypes as C
 
 import numpy as np
@@ -10,6 +11,8 @@ from _libs import Q
 
 pytestmark = pytest.mark.gpu
 N = 1 << 15
+import os
+SEED = os.environ.get("GOLDILOCKS_SOAK_SEED", "").encode()
 
 
 def _p(a):
@@ -17,8 +20,8 @@ def _p(a):
 
 
 def test_soak_scalarmuls(ga, O):
-    k = _gen.stream_scalars(N, b"soak/base")
-    s = _gen.stream_scalars(N, b"soak/scalar")
+    k = _gen.stream_scalars(N, SEED + b"soak/base")
+    s = _gen.stream_scalars(N, SEED + b"soak/scalar")
     bases = ga.precomputed_scalarmul_batch(k)                                     # 8-bit window table
     assert (ga.point_encode_batch(bases) == _gen.oracle_encode(_gen.oracle_fixed(O, k))).all()
     comb = ga.precomputed_scalarmul_batch(k, table=ga.precomputed_base())         # LDS comb
@@ -33,12 +36,12 @@ def test_soak_scalarmuls(ga, O):
 
 
 def test_soak_sign_verify(ga, O):
-    sk = np.frombuffer(_gen.stream(b"soak/sk", 57 * N), np.uint8).reshape(N, 57).copy()
+    sk = np.frombuffer(_gen.stream(SEED + b"soak/sk", 57 * N), np.uint8).reshape(N, 57).copy()
     pk = ga.ed448_derive_public_key_batch(sk)
     want_pk = np.empty_like(pk)
     O.orc_ed448_derive_public_key_batch(_p(want_pk), _p(sk), N, _gen.NTHREADS)
     assert (pk == want_pk).all()
-    msg = np.frombuffer(_gen.stream(b"soak/msg", 48 * N), np.uint8).reshape(N, 48).copy()
+    msg = np.frombuffer(_gen.stream(SEED + b"soak/msg", 48 * N), np.uint8).reshape(N, 48).copy()
     msgs = [m.tobytes() for m in msg]
     sig = ga.ed448_sign_batch(sk, pk, msgs, context=b"soak")
     want = np.empty_like(sig)
@@ -58,7 +61,7 @@ def test_soak_sign_verify(ga, O):
 def test_soak_x448_and_elligator(ga, O):
     from _libs import Point
     n = N // 4
-    sc = np.frombuffer(_gen.stream(b"soak/x448-s", 56 * n), np.uint8).reshape(n, 56).copy()
+    sc = np.frombuffer(_gen.stream(SEED + b"soak/x448-s", 56 * n), np.uint8).reshape(n, 56).copy()
     pub, _ = ga.x448_batch(sc)
     peer = np.roll(pub, 1, axis=0)
     got, st = ga.x448_batch(sc, peer)
@@ -68,7 +71,7 @@ def test_soak_x448_and_elligator(ga, O):
     # DH symmetry over the whole batch: x448(a_i, pub_{i-1}) == x448(a_{i-1}, pub_i)
     other, _ = ga.x448_batch(np.roll(sc, 1, axis=0), pub)
     assert (got == other).all()
-    h = np.frombuffer(_gen.stream(b"soak/elligator", 112 * n), np.uint8).reshape(n, 112).copy()
+    h = np.frombuffer(_gen.stream(SEED + b"soak/elligator", 112 * n), np.uint8).reshape(n, 112).copy()
     pts = ga.point_from_hash_batch(h, uniform=True)
     w = np.empty((n, 32), np.uint64)
     for i in range(0, n, 5):
