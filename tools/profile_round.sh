@@ -18,6 +18,10 @@ for wl in varbase fixed base verify sign x448; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- \
         python3 "$BENCH" --workload $wl --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/stats_$wl.log" 2>&1
 done
+for wl in sign base; do   # the index-independent (LDS comb + shuffle gather) variants, bench line only
+    python3 "$BENCH" --workload $wl --table-access index-independent --no-cpu-baseline \
+        > "$ROOT/gpurun_out/profiles_$ROUND/bench_${wl}_index_independent.json" 2> "$OUT/bench_${wl}_ii.err"
+done
 for wl in varbase fixed verify; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
         rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc_${ctr}_$wl" -- \
