@@ -85,3 +85,29 @@ def test_product_sources_do_not_reference_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "gold_oracle" not in text and "liboracle" not in text and "hostsim" not in text.replace(
                     "tests/hostsim", ""), f
+
+
+def test_void_drop_in_functions_abort_loudly_without_gpu(L):
+    """The reference's void functions cannot report errors; without a device ours abort with a
+    message instead of returning garbage or computing on the CPU."""
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    code = ("import numpy as np, libgoldilocks_amd as ga\n"
+            "ga.point_scalarmul(np.zeros(32, np.uint64), np.zeros(7, np.uint64))\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT)
+    assert r.returncode == -6, r.returncode                     # SIGABRT
+    assert "no CPU path" in r.stderr and "goldilocks_448_point_scalarmul" in r.stderr
+
+
+def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
+    import ast
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    tree = ast.parse(src)
+    for node in tree.body:
+        if isinstance(node, ast.FunctionDef) and node.name != "cpu_baseline":
+            seg = ast.get_source_segment(src, node)
+            code_lines = [l.split("#")[0] for l in seg.splitlines()]
+            code = "\n".join(l for l in code_lines if not l.strip().startswith(('"', "'")))
+            assert "_libs" not in code and "oracle(" not in code and "oracle_" not in code, node.name
