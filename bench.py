@@ -267,11 +267,11 @@ def main():
         if os.path.exists(pmc):
             traffic = json.load(open(pmc)).get(kernel)
         line = {
-            "metric": {"varbase": "Ed448 variable-base scalarmuls/sec, batch=2^20",
-                       "fixed": "Ed448 fixed-base scalarmuls/sec, batch=2^20",
-                       "base": "Ed448 base-point scalarmuls/sec, batch=2^20",
-                       "verify": "Ed448 verifies/sec, batch=2^20", "sign": "Ed448 signatures/sec, batch=2^20",
-                       "x448": "X448 shared secrets/sec, batch=2^20"}[args.workload],
+            "metric": {"varbase": "Ed448 variable-base scalarmuls/sec, batch=2^%d" % args.log2_batch,
+                       "fixed": "Ed448 fixed-base scalarmuls/sec, batch=2^%d" % args.log2_batch,
+                       "base": "Ed448 base-point scalarmuls/sec, batch=2^%d" % args.log2_batch,
+                       "verify": "Ed448 verifies/sec, batch=2^%d" % args.log2_batch, "sign": "Ed448 signatures/sec, batch=2^%d" % args.log2_batch,
+                       "x448": "X448 shared secrets/sec, batch=2^%d" % args.log2_batch}[args.workload],
             "value": value, "unit": {"varbase": "scalarmuls/s", "fixed": "scalarmuls/s", "base": "scalarmuls/s", "verify": "verifies/s",
                                      "sign": "signatures/s", "x448": "shared secrets/s"}[args.workload],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
