@@ -9,8 +9,11 @@
 //   * the per-lane window table of a variable base (16 projective niels = 4 KiB) cannot
 //     fit LDS (64 lanes x 4 KiB = 256 KiB per wave), so it lives in an HBM workspace,
 //     lane-contiguous, sized by RESIDENT lanes (grid-stride), read 256 B per window.
-//   * shared read-only tables (base-point comb / window table) sit in one small global
-//     buffer that stays L1/L2 resident.
+//   * shared read-only tables: a comb (15 KiB) is staged in LDS and gathered with wavefront
+//     shuffles; the base point's 16-entry window table (4 KiB) and its 56 x 128 8-bit window table
+//     (1.3 MiB) are global buffers that stay L1/L2 resident.
+//   * kernels that end in a field inversion park per-operation state in the workspace and share
+//     one inversion between the operations of a lane (fixed_bodies.hpp).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -133,17 +136,6 @@ struct SharedTable {  // read-only 16-entry table shared by all lanes (base poin
         e.b = fe_load(q + 4);
         e.cn = fe_load(q + 8);
         e.z = fe_load(q + 12);
-        return e;
-    }
-};
-struct SharedComb {  // 80 affine niels, 12 uint4 each, our limb/sign convention
-    const uint4 *p;
-    __device__ __forceinline__ niels load(int j, uint32_t idx) const {
-        const uint4 *q = p + 12 * (16 * j + idx);
-        niels e;
-        e.a = fe_load(q);
-        e.b = fe_load(q + 4);
-        e.cn = fe_load(q + 8);
         return e;
     }
 };
