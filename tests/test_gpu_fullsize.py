@@ -252,3 +252,14 @@ def test_sub_batched_launches_beyond_eight_operations_per_lane(ga, O):
     for i in [0, 8 * lanes - 1, 8 * lanes, n - 1]:
         O.orc_x448_derive_public_key(w, xs[i].ctypes.data)
         assert bytes(w) == pub[i].tobytes(), i
+
+
+def test_shutdown_releases_and_next_call_rebuilds(ga, O):
+    """goldilocks_amd_shutdown frees the device context; the next call builds it again lazily."""
+    k = _gen.stream_scalars(100, b"shutdown")
+    before = ga.point_encode_batch(ga.precomputed_scalarmul_batch(k))
+    assert ga.device_info()["workspace_bytes"] > 0
+    ga.lib().goldilocks_amd_shutdown()
+    assert ga.device_info()["workspace_bytes"] == 0            # fresh context, nothing staged yet
+    after = ga.point_encode_batch(ga.precomputed_scalarmul_batch(k))
+    assert (before == after).all() and (after == _gen.oracle_encode(_gen.oracle_fixed(O, k))).all()
