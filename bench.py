@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="varbase", choices=["varbase", "fixed", "base", "verify", "sign", "x448"])
+    ap.add_argument("--workload", default="varbase", choices=["varbase", "fixed", "base", "verify", "sign", "x448", "direct"])
     ap.add_argument("--table-access", default="fast", choices=["fast", "index-independent"],
                     help="goldilocks_amd_set_table_access: how base-point tables are read for secret scalars "
                          "(affects the base and sign workloads)")
@@ -142,6 +142,14 @@ def main():
     elif args.workload == "base":      # the built-in base point: 8-bit window table (no doublings)
         step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
         bytes_per_op, kernel = 312, ("k_precomputed_scalarmul" if args.table_access == "index-independent" else "k_base_scalarmul")
+    elif args.workload == "direct":    # wire format in and out: 56-byte encodings, decode + ladder + encode fused
+        enc_in = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+        ga.dev("point_encode", enc_in.data_ptr(), bases.data_ptr(), n, None)
+        enc_out = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+        st_direct = torch.empty(n, dtype=torch.int32, device="cuda")
+        step = lambda: ga.dev("direct_scalarmul", enc_out.data_ptr(), st_direct.data_ptr(), enc_in.data_ptr(),
+                              scalars.data_ptr(), 0, 0, n, stream)
+        bytes_per_op, kernel = 56 + 56 + 56 + 4, "k_direct_scalarmul"
     elif args.workload in ("sign", "x448"):
         import _gen
         nb = 57 if args.workload == "sign" else 56
@@ -223,6 +231,13 @@ def main():
         pairs = shared.view(n // 2, 2, 56)
         ok = bool((pairs[:, 0] == pairs[:, 1]).all()) and int((st448 == -1).sum()) == n
         check = "Diffie-Hellman symmetry: X448(a, pub_b) == X448(b, pub_a) for every neighbour pair"
+    elif rank == 0 and args.workload == "direct":
+        ref = torch.empty_like(bases)
+        ga.dev("point_scalarmul", ref.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, None)
+        ref_enc = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+        ga.dev("point_encode", ref_enc.data_ptr(), ref.data_ptr(), n, None)
+        ok = bool((ref_enc == enc_out).all()) and int((st_direct == -1).sum()) == n
+        check = "every output equals encode(point_scalarmul(decode(input))) computed by the separate kernels"
     elif rank == 0 and args.workload in ("fixed", "base"):
         m = 1 << 14
         base_pt = torch.from_numpy(np.repeat(ga.point_base().reshape(1, 32), m, axis=0).view(np.int64)).cuda()
@@ -271,9 +286,10 @@ def main():
                        "fixed": "Ed448 fixed-base scalarmuls/sec, batch=2^%d" % args.log2_batch,
                        "base": "Ed448 base-point scalarmuls/sec, batch=2^%d" % args.log2_batch,
                        "verify": "Ed448 verifies/sec, batch=2^%d" % args.log2_batch, "sign": "Ed448 signatures/sec, batch=2^%d" % args.log2_batch,
-                       "x448": "X448 shared secrets/sec, batch=2^%d" % args.log2_batch}[args.workload],
+                       "x448": "X448 shared secrets/sec, batch=2^%d" % args.log2_batch,
+                       "direct": "Ed448 wire-format scalarmuls/sec, batch=2^%d" % args.log2_batch}[args.workload],
             "value": value, "unit": {"varbase": "scalarmuls/s", "fixed": "scalarmuls/s", "base": "scalarmuls/s", "verify": "verifies/s",
-                                     "sign": "signatures/s", "x448": "shared secrets/s"}[args.workload],
+                                     "sign": "signatures/s", "x448": "shared secrets/s", "direct": "scalarmuls/s"}[args.workload],
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
@@ -282,7 +298,8 @@ def main():
                                     "base": "goldilocks_448_precomputed_scalarmul(precomputed_base), 8-bit window table",
                                     "verify": "goldilocks_ed448_verify, 32-byte messages, 1% corrupted",
                                     "sign": "goldilocks_ed448_sign, 32-byte messages, no context",
-                                    "x448": "goldilocks_x448, random peer public keys"}[args.workload],
+                                    "x448": "goldilocks_x448, random peer public keys",
+                                    "direct": "goldilocks_448_direct_scalarmul, 56-byte encodings in and out"}[args.workload],
                        "batch_per_gpu": n, "table_access": args.table_access,
                        "sharding": "independent batch per GPU, no data-path collective",
                        "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],

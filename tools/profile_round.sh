@@ -13,7 +13,7 @@ rm -rf "$OUT" "$ROOT/gpurun_out/profiles_$ROUND"
 mkdir -p "$OUT" "$ROOT/gpurun_out/profiles_$ROUND"
 cd /tmp && export TMPDIR=/tmp
 BENCH="$ROOT/bench.py"
-for wl in varbase fixed base verify sign x448; do
+for wl in varbase fixed base verify sign x448 direct; do
     python3 "$BENCH" --workload $wl > "$ROOT/gpurun_out/profiles_$ROUND/bench_$wl.json" 2> "$OUT/bench_$wl.err"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- \
         python3 "$BENCH" --workload $wl --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/stats_$wl.log" 2>&1
