@@ -263,3 +263,19 @@ def test_shutdown_releases_and_next_call_rebuilds(ga, O):
     assert ga.device_info()["workspace_bytes"] == 0            # fresh context, nothing staged yet
     after = ga.point_encode_batch(ga.precomputed_scalarmul_batch(k))
     assert (before == after).all() and (after == _gen.oracle_encode(_gen.oracle_fixed(O, k))).all()
+
+
+def test_batch_output_may_alias_the_base_array(ga, O):
+    """The reference lets outputs alias inputs (point_448.h:295-297); for the batch entry point that means
+    scaled == base, also when the batch is large enough to be pipelined in chunks."""
+    n = 2 * 131072 + 4321
+    k = _gen.stream_scalars(n, b"alias/base")
+    s = _gen.stream_scalars(n, b"alias/scalar")
+    bases = ga.precomputed_scalarmul_batch(k)
+    want = ga.point_scalarmul_batch(bases, s)
+    buf = bases.copy()
+    rc = ga.lib().goldilocks_448_point_scalarmul_batch(buf.ctypes.data, buf.ctypes.data, s.ctypes.data, n)
+    assert rc == 0 and (buf == want).all()
+    small = bases[:100].copy()
+    assert ga.lib().goldilocks_448_point_scalarmul_batch(small.ctypes.data, small.ctypes.data, s.ctypes.data, 100) == 0
+    assert (small == want[:100]).all()
