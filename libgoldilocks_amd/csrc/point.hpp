@@ -8,7 +8,7 @@
 //   full addition     src/goldilocks.c:205-230
 //   niels conversions src/goldilocks.c:271-312
 // but with their own lazy-reduction schedule for 28-bit limbs (see the magnitude
-// contract in gf28.hpp): every product below has mag(a)*mag(b) <= 4.
+// contract in gf28.hpp): every product below has mag(a)*mag(b) <= 6 (limit 6.7).
 //
 // Sign convention: our (p)niels keep cn = -c_ref = +2*39082*T (so no negation is
 // needed when a table entry is built); entries imported from reference-format
