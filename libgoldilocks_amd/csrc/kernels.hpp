@@ -1,9 +1,10 @@
 // kernels.hpp -- HIP kernels for gfx950: one Ed448 operation per wavefront lane.
 //
 // Memory plan:
-//   * I/O arrays are the reference's AoS structs (256-B points, 56-B scalars); each lane
-//     moves its own struct with 16-byte vector accesses, every byte of every fetched
-//     line is used.  I/O is ~568 B per ~4000 field multiplications: not the bound.
+//   * I/O arrays are the reference's AoS structs (256-B points, 56-B scalars); a wave moves the
+//     contiguous block of its 64 operations with fully coalesced 16-byte-per-lane instructions and
+//     transposes it through LDS (wave_load_points / wave_store_points below).  I/O is ~568 B per
+//     ~4000 field multiplications: not the bound.
 //   * recoded scalars live in LDS, word-major ([word][lane]): window/comb bit positions
 //     are wave-uniform, so every LDS read is conflict-free.
 //   * the per-lane window table of a variable base (16 projective niels = 4 KiB) cannot
@@ -93,6 +94,64 @@ __device__ __forceinline__ sc sc_load_abi(const uint64_t *p) {
 #pragma unroll
     for (int i = 0; i < 7; i++) l[i] = p[i];
     return sc_from_abi(l);
+}
+
+// ---------------------------------------------------------------- wave-cooperative coalesced I/O
+// The reference's arrays are arrays of structs.  A lane that fetched its own 256-byte point directly
+// would issue 16-byte accesses 256 bytes apart from its neighbours': every byte of every line is
+// used, but each instruction touches 64 lines.  The headline kernels instead move a wave's
+// contiguous block (64 points = 16 KiB, 64 scalars = 3.5 KiB) with fully coalesced instructions --
+// lane l takes the l-th 16 (points) or 8 (scalars, only 8-byte aligned) bytes of every row -- and
+// transpose through a per-wave LDS buffer, 32 points at a time.  i0 = the wave's first operation,
+// m = how many of its 64 operations exist (both wave-uniform); every lane of the wave must call.
+constexpr int WAVE_STAGE_U4 = 512;   // 8 KiB of LDS per wave
+__device__ __forceinline__ void wave_sync() {   // LDS writes of this wave before, LDS reads after
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ pt wave_load_points(uint4 *stage, const uint64_t *base, uint32_t i0, uint32_t m, uint32_t l) {
+    const uint4 *g = reinterpret_cast<const uint4 *>(base) + (size_t)i0 * 16;
+    pt r = pt_identity();
+#pragma unroll 1
+    for (uint32_t half = 0; half < 2; half++) {
+        wave_sync();
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t idx = half * 512 + k * 64 + l;
+            if (idx < m * 16) stage[k * 64 + l] = g[idx];
+        }
+        wave_sync();
+        if ((l >> 5) == half && l < m) r = pt_load_abi(reinterpret_cast<const uint64_t *>(stage + (l & 31) * 16));
+    }
+    return r;
+}
+__device__ __forceinline__ void wave_store_points(uint4 *stage, uint64_t *out, uint32_t i0, uint32_t m, uint32_t l,
+                                                  const pt &r) {
+    uint4 *g = reinterpret_cast<uint4 *>(out) + (size_t)i0 * 16;
+#pragma unroll 1
+    for (uint32_t half = 0; half < 2; half++) {
+        wave_sync();
+        if ((l >> 5) == half && l < m) pt_store_abi(reinterpret_cast<uint64_t *>(stage + (l & 31) * 16), r);
+        wave_sync();
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t idx = half * 512 + k * 64 + l;
+            if (idx < m * 16) g[idx] = stage[k * 64 + l];
+        }
+    }
+}
+__device__ __forceinline__ sc wave_load_scalars(uint4 *stage, const uint64_t *scalar, uint32_t i0, uint32_t m, uint32_t l) {
+    const uint64_t *g = scalar + (size_t)i0 * 7;
+    uint64_t *s64 = reinterpret_cast<uint64_t *>(stage);
+    wave_sync();
+#pragma unroll
+    for (uint32_t k = 0; k < 7; k++) {
+        const uint32_t idx = k * 64 + l;
+        if (idx < m * 7) s64[idx] = g[idx];
+    }
+    wave_sync();
+    return l < m ? sc_load_abi(s64 + l * 7) : sc_zero();
 }
 
 // ---------------------------------------------------------------- policies

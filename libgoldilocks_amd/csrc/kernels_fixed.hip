@@ -8,19 +8,21 @@ GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__res
                                   const uint64_t *__restrict__ scalar, uint32_t n) {
     __shared__ uint32_t s_bits[15 * BLOCK];
     __shared__ uint32_t s_comb[COMB_LDS_WORDS];
+    __shared__ uint4 s_stage[(BLOCK / 64) * WAVE_STAGE_U4];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t l = threadIdx.x & 63u;
+    uint4 *stage = s_stage + (threadIdx.x >> 6) * WAVE_STAGE_U4;
     stage_comb_lds(s_comb, comb);
-    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
-    // every lane of a wave must take part in the shuffles: iterate wave-uniformly and clamp
-    const uint32_t rounds = (n + stride - 1) / stride;
-    for (uint32_t r = 0; r < rounds; r++) {
-        const uint32_t i_raw = lane + r * stride;
-        const bool live = i_raw < n;
-        const uint32_t i = live ? i_raw : n - 1;
-        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(scalar + 7 * (size_t)i)));
+    LdsShuffleComb tab{s_comb, l};
+    // every lane of a wave must take part in the shuffles: the loop is wave-uniform and lanes past
+    // the end multiply by a zero scalar (their result is not stored)
+    for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {
+        const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
+        const sc k = wave_load_scalars(stage, scalar, i0, m, l);
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(k));
         pt res = ladder_comb(bits, tab);
-        if (live) pt_store_abi(out + 32 * (size_t)i, res);
+        wave_store_points(stage, out, i0, m, l, res);
     }
 }
 
@@ -28,12 +30,21 @@ GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__res
 GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ bwt,
                            const uint64_t *__restrict__ scalar, uint32_t n) {
     __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint4 s_stage[(BLOCK / 64) * WAVE_STAGE_U4];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t l = threadIdx.x & 63u;
+    uint4 *stage = s_stage + (threadIdx.x >> 6) * WAVE_STAGE_U4;
     GlobalBwt tab{bwt};
-    for (uint32_t i = lane; i < n; i += stride) {
-        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed8(sc_load_abi(scalar + 7 * (size_t)i)));
-        pt_store_abi(out + 32 * (size_t)i, ladder_bwt(bits, tab));
+    for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {
+        const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
+        const sc k = wave_load_scalars(stage, scalar, i0, m, l);
+        pt res = pt_identity();
+        if (l < m) {
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed8(k));
+            res = ladder_bwt(bits, tab);
+        }
+        wave_store_points(stage, out, i0, m, l, res);
     }
 }
 

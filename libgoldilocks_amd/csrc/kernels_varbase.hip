@@ -7,15 +7,24 @@ namespace gd {
 GD_KERNEL k_point_scalarmul(uint64_t *__restrict__ out, const uint64_t *__restrict__ base,
                             const uint64_t *__restrict__ scalar, uint32_t n, uint4 *__restrict__ workspace) {
     __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint4 s_stage[(BLOCK / 64) * WAVE_STAGE_U4];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t l = threadIdx.x & 63u;
+    uint4 *stage = s_stage + (threadIdx.x >> 6) * WAVE_STAGE_U4;
     LaneTable tab{workspace + (size_t)lane * TABLE_U4};
-    for (uint32_t i = lane; i < n; i += stride) {
-        pt b = pt_load_abi(base + 32 * (size_t)i);
-        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(scalar + 7 * (size_t)i)));
-        build_window_table(tab, b);
-        pt r = ladder_varbase(bits, tab);
-        pt_store_abi(out + 32 * (size_t)i, r);
+    // wave-uniform loop: the 64 lanes of a wave own 64 consecutive operations per round
+    for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {
+        const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
+        pt b = wave_load_points(stage, base, i0, m, l);
+        const sc k = wave_load_scalars(stage, scalar, i0, m, l);
+        pt r = b;
+        if (l < m) {
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(k));
+            build_window_table(tab, b);
+            r = ladder_varbase(bits, tab);
+        }
+        wave_store_points(stage, out, i0, m, l, r);
     }
 }
 
