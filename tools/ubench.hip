@@ -97,6 +97,12 @@ ALL8(k_add_co_u32, uint32_t, "v_add_co_u32_e32 ", P_ADDCO)
 ALL8(k_addc_co_u32, uint32_t, "v_addc_co_u32_e32 ", P_ADDC)
 ALL8(k_fma_f32, uint32_t, "v_fma_f32 ", P_FMA)
 ALL8(k_mov_b32, uint32_t, "v_mov_b32_e32 ", P_MOV)
+// the same simple ops carrying a 32-bit literal (8-byte encoding), as the limb masks and subtraction
+// biases of the field arithmetic do
+#define P_LIT_MASK(r) ", 0xfffffff, " r
+#define P_LIT_BIAS(r) ", 0x3ffffffc, " r
+ALL8(k_and_b32_literal, uint32_t, "v_and_b32_e32 ", P_LIT_MASK)
+ALL8(k_add_u32_literal, uint32_t, "v_add_u32_e32 ", P_LIT_BIAS)
 
 // instruction mixes of the Ed448 ladder: MAC:simple = 1:1 and the doubling's measured histogram
 DEF_KERNEL(k_mix_mac_add, uint64_t, "v_mad_u64_u32 %0, vcc, %8, %9, %0", "v_add_u32_e32 %8, %9, %8",
@@ -136,9 +142,17 @@ DEF_KERNEL(k_mix_mac_lshladd, uint64_t, "v_mad_u64_u32 %0, vcc, %8, %9, %0", "v_
 #define S1 "v_and_b32_e32 %5, %9, %5\n"
 #define S2 "v_add_u32_e32 %6, %8, %6\n"
 #define S3 "v_lshrrev_b32_e32 %7, 1, %7\n"
+// a 1:1 mix whose simple ops carry literals / whose simple ops read the MAC result just written
+#define L0 "v_add_u32_e32 %4, 0x3ffffffc, %4\n"
+#define L1 "v_and_b32_e32 %5, 0xfffffff, %5\n"
+#define L2 "v_add_u32_e32 %6, 0x3ffffffc, %6\n"
+#define L3 "v_and_b32_e32 %7, 0xfffffff, %7\n"
+MIXK(k_mix_runs4_literal, ".rept 4\n" M0 M1 M2 M3 L0 L1 L2 L3 "\n.endr")
 MIXK(k_ord_alternating, ".rept 4\n" M0 S0 M1 S1 M2 S2 M3 S3 "\n.endr")
 MIXK(k_ord_runs_of_4, ".rept 4\n" M0 M1 M2 M3 S0 S1 S2 S3 "\n.endr")
 MIXK(k_ord_runs_of_16, ".rept 4\n" M0 M1 M2 M3 "\n.endr\n.rept 4\n" S0 S1 S2 S3 "\n.endr")
+MIXK(k_ord_runs_of_64, ".rept 16\n" M0 M1 M2 M3 "\n.endr\n.rept 16\n" S0 S1 S2 S3 "\n.endr")
+MIXK(k_ord_runs_of_256, ".rept 64\n" M0 M1 M2 M3 "\n.endr\n.rept 64\n" S0 S1 S2 S3 "\n.endr")
 MIXK(k_ord_mac_only16, ".rept 4\n" M0 M1 M2 M3 "\n.endr")
 MIXK(k_ord_simple_only16, ".rept 4\n" S0 S1 S2 S3 "\n.endr")
 
@@ -161,7 +175,8 @@ int main(int argc, char **argv) {
                     ENT(k_add_co_u32), ENT(k_addc_co_u32), ENT(k_mov_b32), ENT(k_lshl_add_u64), ENT(k_lshrrev_b64),
                     ENT(k_fma_f32), ENT(k_pk_fma_f32), ENT(k_fma_f64), ENT(k_mix_mac_add), ENT(k_mix_mac3_add),
                     ENT(k_mix_mac_lshladd), ENT(k_ord_alternating), ENT(k_ord_runs_of_4),
-                    ENT(k_ord_runs_of_16), ENT(k_ord_mac_only16), ENT(k_ord_simple_only16)};
+                    ENT(k_ord_runs_of_16), ENT(k_ord_mac_only16), ENT(k_ord_simple_only16),
+                    ENT(k_ord_runs_of_64), ENT(k_ord_runs_of_256), ENT(k_and_b32_literal), ENT(k_add_u32_literal), ENT(k_mix_runs4_literal)};
     uint64_t *out;
     unsigned long long *cyc;
     const int max_blocks = cus * 8;
