@@ -161,8 +161,10 @@ typedef void (*kern_t)(uint64_t *, uint32_t, uint32_t, unsigned long long *);
 struct Entry {
     const char *name;
     kern_t k1, k8;
+    int insts;   // instructions per loop iteration
 };
-#define ENT(n) {#n, n<1>, n<8>}
+#define ENT(n) {#n, n<1>, n<8>, UNROLL}
+#define ENTN(n, k) {#n, n<1>, n<8>, k}
 
 int main(int argc, char **argv) {
     hipDeviceProp_t prop;
@@ -175,8 +177,8 @@ int main(int argc, char **argv) {
                     ENT(k_add_co_u32), ENT(k_addc_co_u32), ENT(k_mov_b32), ENT(k_lshl_add_u64), ENT(k_lshrrev_b64),
                     ENT(k_fma_f32), ENT(k_pk_fma_f32), ENT(k_fma_f64), ENT(k_mix_mac_add), ENT(k_mix_mac3_add),
                     ENT(k_mix_mac_lshladd), ENT(k_ord_alternating), ENT(k_ord_runs_of_4),
-                    ENT(k_ord_runs_of_16), ENT(k_ord_mac_only16), ENT(k_ord_simple_only16),
-                    ENT(k_ord_runs_of_64), ENT(k_ord_runs_of_256), ENT(k_and_b32_literal), ENT(k_add_u32_literal), ENT(k_mix_runs4_literal)};
+                    ENT(k_ord_runs_of_16), ENTN(k_ord_mac_only16, 16), ENTN(k_ord_simple_only16, 16),
+                    ENTN(k_ord_runs_of_64, 128), ENTN(k_ord_runs_of_256, 512), ENT(k_and_b32_literal), ENT(k_add_u32_literal), ENT(k_mix_runs4_literal)};
     uint64_t *out;
     unsigned long long *cyc;
     const int max_blocks = cus * 8;
@@ -208,7 +210,7 @@ int main(int argc, char **argv) {
                 double avg = 0;
                 for (int b = 0; b < blocks; b++) avg += (double)hcyc[b];
                 avg /= blocks;
-                double insts_per_wave = (double)ITERS * UNROLL;
+                double insts_per_wave = (double)ITERS * e.insts;
                 // a SIMD hosts `wps` waves; cycles the SIMD spends per wave-instruction:
                 double cyc_per_inst = avg / insts_per_wave / wps;
                 double total_wave_insts = insts_per_wave * blocks * 4.0 * reps;
