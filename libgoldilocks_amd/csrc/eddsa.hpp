@@ -24,6 +24,69 @@ GD_CONST uint64_t KECCAK_RC[24] = {
     0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
     0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
 
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950 form of one round on 32-bit halves: the 5-input column parities and chi are three-input
+// boolean functions, one v_bitop3_b32 each (truth tables in the a = 0xF0, b = 0xCC, c = 0xAA
+// convention: a^b^c = 0x96, a ^ (~b & c) = 0xD2); rotations are v_alignbit_b32 pairs.  About 190
+// instructions per round where the generic form below compiles to about 310.
+struct k32 {
+    uint32_t lo, hi;
+};
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+template <int R>
+__device__ __forceinline__ k32 rotl_k32(k32 v) {   // rotate the 64-bit value {hi, lo} left by R
+    if (R == 0) return v;
+    if (R == 32) return k32{v.hi, v.lo};
+    if (R < 32) return k32{__builtin_amdgcn_alignbit(v.lo, v.hi, 32 - R), __builtin_amdgcn_alignbit(v.hi, v.lo, 32 - R)};
+    return k32{__builtin_amdgcn_alignbit(v.hi, v.lo, 64 - R), __builtin_amdgcn_alignbit(v.lo, v.hi, 64 - R)};
+}
+template <int X, int Y>
+__device__ __forceinline__ void keccak_rho_pi(k32 (&b)[25], const uint64_t (&a)[25], const k32 (&d)[5]) {
+    constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43,
+                             25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    const k32 t{(uint32_t)a[X + 5 * Y] ^ d[X].lo, (uint32_t)(a[X + 5 * Y] >> 32) ^ d[X].hi};
+    b[Y + 5 * ((2 * X + 3 * Y) % 5)] = rotl_k32<RHO[X + 5 * Y]>(t);
+}
+template <int X>
+__device__ __forceinline__ void keccak_rho_pi_column(k32 (&b)[25], const uint64_t (&a)[25], const k32 (&d)[5]) {
+    keccak_rho_pi<X, 0>(b, a, d);
+    keccak_rho_pi<X, 1>(b, a, d);
+    keccak_rho_pi<X, 2>(b, a, d);
+    keccak_rho_pi<X, 3>(b, a, d);
+    keccak_rho_pi<X, 4>(b, a, d);
+}
+GD_FN void keccak_round(uint64_t (&a)[25], uint64_t rc) {
+    k32 c[5], d[5], b[25];
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        c[x].lo = xor3(xor3((uint32_t)a[x], (uint32_t)a[x + 5], (uint32_t)a[x + 10]), (uint32_t)a[x + 15],
+                       (uint32_t)a[x + 20]);
+        c[x].hi = xor3(xor3((uint32_t)(a[x] >> 32), (uint32_t)(a[x + 5] >> 32), (uint32_t)(a[x + 10] >> 32)),
+                       (uint32_t)(a[x + 15] >> 32), (uint32_t)(a[x + 20] >> 32));
+    }
+#pragma unroll
+    for (int x = 0; x < 5; x++) {
+        const k32 r = rotl_k32<1>(c[(x + 1) % 5]);
+        d[x].lo = c[(x + 4) % 5].lo ^ r.lo;
+        d[x].hi = c[(x + 4) % 5].hi ^ r.hi;
+    }
+    keccak_rho_pi_column<0>(b, a, d);
+    keccak_rho_pi_column<1>(b, a, d);
+    keccak_rho_pi_column<2>(b, a, d);
+    keccak_rho_pi_column<3>(b, a, d);
+    keccak_rho_pi_column<4>(b, a, d);
+#pragma unroll
+    for (int y = 0; y < 25; y += 5)
+#pragma unroll
+        for (int x = 0; x < 5; x++) {
+            const k32 b0 = b[y + x], b1 = b[y + (x + 1) % 5], b2 = b[y + (x + 2) % 5];
+            const uint32_t lo = __builtin_amdgcn_bitop3_b32(b0.lo, b1.lo, b2.lo, 0xd2);
+            const uint32_t hi = __builtin_amdgcn_bitop3_b32(b0.hi, b1.hi, b2.hi, 0xd2);
+            a[y + x] = (uint64_t)lo | (uint64_t)hi << 32;
+        }
+    a[0] ^= rc;
+}
+#else
 GD_FN void keccak_round(uint64_t (&a)[25], uint64_t rc) {
     constexpr int RHO[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43,
                              25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
@@ -46,6 +109,7 @@ GD_FN void keccak_round(uint64_t (&a)[25], uint64_t rc) {
         for (int x = 0; x < 5; x++) a[y + x] = b[y + x] ^ (~b[y + (x + 1) % 5] & b[y + (x + 2) % 5]);
     a[0] ^= rc;
 }
+#endif
 GD_FN void keccak_f1600(uint64_t (&a)[25]) {
 #pragma unroll 1
     for (int r = 0; r < 24; r++) keccak_round(a, KECCAK_RC[r]);
