@@ -139,7 +139,7 @@ def main():
         comb_tab = torch.from_numpy(ga.precomputed_base().view(np.int64)).cuda()
         step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), comb_tab.data_ptr(), scalars.data_ptr(), n, stream)
         bytes_per_op, kernel = 312, "k_precomputed_scalarmul"
-    elif args.workload == "base":      # the built-in base point: 8-bit window table (no doublings)
+    elif args.workload == "base":      # the built-in base point: 16-bit window table (no doublings)
         step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
         bytes_per_op, kernel = 312, ("k_precomputed_scalarmul" if args.table_access == "index-independent" else "k_base_scalarmul")
     elif args.workload == "direct":    # wire format in and out: 56-byte encodings, decode + ladder + encode fused
@@ -295,7 +295,7 @@ def main():
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": {"varbase": "goldilocks_448_point_scalarmul, variable base, random scalars",
                                     "fixed": "goldilocks_448_precomputed_scalarmul, 5x5x18 comb table staged in LDS",
-                                    "base": "goldilocks_448_precomputed_scalarmul(precomputed_base), 8-bit window table",
+                                    "base": "goldilocks_448_precomputed_scalarmul(precomputed_base), 16-bit window table",
                                     "verify": "goldilocks_ed448_verify, 32-byte messages, 1% corrupted",
                                     "sign": "goldilocks_ed448_sign, 32-byte messages, no context",
                                     "x448": "goldilocks_x448, random peer public keys",

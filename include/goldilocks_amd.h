@@ -264,7 +264,7 @@ GOLDILOCKS_AMD_API const char *goldilocks_amd_last_error(void);
 GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count);
 /* Table-access policy for multiplications of the built-in base point by a SECRET scalar (key
  * derivation, signing nonces, X448 key generation, precomputed_scalarmul on
- * goldilocks_448_precomputed_base).  FAST (default): the 8-bit window table in global memory; the
+ * goldilocks_448_precomputed_base).  FAST (default): the 16-bit window table in global memory; the
  * address of each lookup depends on the digit.  INDEX_INDEPENDENT: the reference's 5x5x18 comb
  * staged in LDS, every lookup a wavefront-shuffle gather whose addresses and timing do not depend on
  * the digit -- the counterpart of the reference's constant_time_lookup (src/include/

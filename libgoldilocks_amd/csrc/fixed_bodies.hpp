@@ -6,7 +6,7 @@
 
 namespace gd {
 
-// ---- fixed-base policy of the kernels below.  CT = false: the base point's 8-bit window table in
+// ---- fixed-base policy of the kernels below.  CT = false: the base point's 16-bit window table in
 // global memory (fast, table addresses depend on the digit).  CT = true: the 5x5x18 comb staged in
 // LDS with the wavefront-shuffle gather (addresses and timing independent of the secret digit --
 // the counterpart of the reference's constant_time_lookup, constant_time.h:61-362).  The shuffle
@@ -236,7 +236,7 @@ __device__ __forceinline__ void x448_body(uint8_t *shared, int32_t *status, cons
             den = p.x;
         } else {
             GlobalBwt tab{table};
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed8(x448_public_scalar(w)));
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(x448_public_scalar(w)));
             const pt p = ladder_bwt(bits, tab);
             num = p.y;
             den = p.x;

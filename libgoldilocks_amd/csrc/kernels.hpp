@@ -11,8 +11,8 @@
 //     fit LDS (64 lanes x 4 KiB = 256 KiB per wave), so it lives in an HBM workspace,
 //     lane-contiguous, sized by RESIDENT lanes (grid-stride), read 256 B per window.
 //   * shared read-only tables: a comb (15 KiB) is staged in LDS and gathered with wavefront
-//     shuffles; the base point's 16-entry window table (4 KiB) and its 56 x 128 8-bit window table
-//     (1.3 MiB) are global buffers that stay L1/L2 resident.
+//     shuffles; the base point's 16-entry window table (4 KiB) and its 28 x 32768 16-bit window table
+//     (168 MiB, Infinity-Cache resident) are global buffers.
 //   * kernels that end in a field inversion park per-operation state in the workspace and share
 //     one inversion between the operations of a lane (fixed_bodies.hpp).
 #pragma once
@@ -238,14 +238,14 @@ __device__ __forceinline__ void stage_comb_lds(uint32_t *lds, const uint4 *comb)
     __syncthreads();
 }
 
-// Fixed-base window table of the base point: 56 x 128 affine niels (12 uint4 each), 1.3 MiB in
-// global memory, built once per device (k_build_bwt) and L2-resident: every lane gathers one
-// contiguous 192-byte entry per digit.
-constexpr int BWT_ENTRIES = 56 * 128;
+// Fixed-base window table of the base point: BWT_WINDOWS x BWT_PER_WINDOW affine niels (12 uint4 each) in
+// global memory, built once per device (k_build_bwt), cache-resident (L2 / Infinity Cache): every lane
+// gathers one contiguous 192-byte entry per digit.
+constexpr int BWT_ENTRIES = BWT_WINDOWS * BWT_PER_WINDOW;   // 28 x 32768 with 16-bit digits
 struct GlobalBwt {
     const uint4 *p;
     __device__ __forceinline__ niels load(int i, uint32_t idx) const {
-        const uint4 *q = p + 12 * (128 * i + idx);
+        const uint4 *q = p + 12 * (BWT_PER_WINDOW * i + idx);
         niels e;
         e.a = fe_load(q);
         e.b = fe_load(q + 4);

@@ -26,7 +26,7 @@ GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__res
     }
 }
 
-// scaled[i] = scalar[i] * B for the built-in base point, through the 8-bit window table
+// scaled[i] = scalar[i] * B for the built-in base point, through the window table
 GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ bwt,
                            const uint64_t *__restrict__ scalar, uint32_t n) {
     __shared__ uint32_t s_bits[15 * BLOCK];
@@ -41,33 +41,41 @@ GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__
         const sc k = wave_load_scalars(stage, scalar, i0, m, l);
         pt res = pt_identity();
         if (l < m) {
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed8(k));
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(k));
             res = ladder_bwt(bits, tab);
         }
         wave_store_points(stage, out, i0, m, l, res);
     }
 }
 
-// T_i[k] = (2k+1) * 256^i * B as affine niels ((Y-X)/2Z, (Y+X)/2Z, 78164 T/2Z), one entry per lane.
-// Launch with exactly BWT_ENTRIES lanes (28 blocks): the comb gather needs full waves.
+// T_i[k] = (2k+1) * 2^(BWT_BITS*i) * B as affine niels ((Y-X)/2Z, (Y+X)/2Z, 78164 T/2Z), one entry per lane.
+// Launch with exactly BWT_ENTRIES lanes (a multiple of the block size): the comb gather needs full waves.
 GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) {
     __shared__ uint32_t s_bits[15 * BLOCK];
     __shared__ uint32_t s_comb[COMB_LDS_WORDS];
     stage_comb_lds(s_comb, comb);
     LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
     const uint32_t e = blockIdx.x * BLOCK + threadIdx.x;   // < BWT_ENTRIES by construction
-    const uint32_t i = e >> 7, kk = e & 127;
+    const uint32_t i = e / BWT_PER_WINDOW, kk = e % BWT_PER_WINDOW;
+    // the scalar (2k+1) * 2^(BWT_BITS*i) mod q: shift as far as 448 bits allow, reduce, double the rest
     sc v = sc_zero();
-    const uint32_t m = 2 * kk + 1;
-    const uint32_t bit = 8 * i, wd = bit >> 5, sh = bit & 31;
+    const uint32_t m = 2 * kk + 1;               // < 2^BWT_BITS
+    uint32_t bit = BWT_BITS * i, extra = 0;
+    if (bit + BWT_BITS > 448) {
+        extra = bit + BWT_BITS - 448;
+        bit -= extra;
+    }
+    const uint32_t wd = bit >> 5, sh = bit & 31;
 #pragma unroll
     for (int w = 0; w < 14; w++) {
         uint32_t x = 0;
         if ((uint32_t)w == wd) x = m << sh;
-        if ((uint32_t)w == wd + 1 && sh > 23) x = m >> (32 - sh);
+        if ((uint32_t)w == wd + 1 && sh + BWT_BITS > 32) x = m >> (32 - sh);
         v.w[w] = x;
     }
-    LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_reduce(v)));
+    v = sc_reduce(v);
+    for (uint32_t k = 0; k < extra; k++) v = sc_add(v, v);
+    LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(v));
     pt p = ladder_comb(bits, tab);
     fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
     uint4 *q = dst + 12 * (size_t)e;

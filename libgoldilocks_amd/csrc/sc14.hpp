@@ -26,6 +26,9 @@ GD_CONST uint32_t SC_ADJ[14] = {0x4a7bb0cfu, 0xc873d6d5u, 0x23a70aadu, 0xe933d8d
 // (2^448 - 1) mod q: the same recoding for 56 signed 8-bit windows (fixed-base window table)
 GD_CONST uint32_t SC_ADJ8[14] = {0x529eec33u, 0x721cf5b5u, 0xc8e9c2abu, 0x7a4cf635u, 0x44a725bfu,
                                  0xeec492d9u, 0x0cd77058u, 0x00000002u, 0, 0, 0, 0, 0, 0};
+// (2^456 - 1) mod q: the same for 38 signed 12-bit windows (experiment, -DGD_BWT_BITS=12)
+GD_CONST uint32_t SC_ADJ12[14] = {0x9eec33ffu, 0x1cf5b552u, 0xe9c2ab72u, 0x4cf635c8u, 0xa725bf7au,
+                                  0xc492d944u, 0xd77058eeu, 0x0000020cu, 0, 0, 0, 0, 0, 0};
 // -q^-1 mod 2^32 (low word of src/scalar.c:17 MONTGOMERY_FACTOR)
 constexpr uint32_t SC_MONT32 = 0xae918bc5u;
 
@@ -142,5 +145,6 @@ GD_FN sc sc_recode_signed(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_A
 // W = (s + 2^448 - 1)/2 mod q: its 56 bytes w_i encode s = sum (2 w_i - 255) 256^i, odd digits in
 // [-255, 255] (same derivation as above with 8-bit windows: sum 255*256^i = 2^448 - 1).
 GD_FN sc sc_recode_signed8(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_ADJ8))); }
+GD_FN sc sc_recode_signed12(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_ADJ12))); }
 
 }  // namespace gd

@@ -36,10 +36,6 @@ struct HostComb {
     niels e[80];
     niels load(int j, uint32_t idx) const { return e[16 * j + idx]; }
 };
-struct HostBwt {
-    niels *e;  // 56 * 128
-    niels load(int i, uint32_t idx) const { return e[128 * i + idx]; }
-};
 // affine niels of a point in our convention: ((Y-X)/(2Z), (Y+X)/(2Z), 78164*T/(2Z))
 niels host_affine_niels(const pt &p) {
     fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
@@ -222,28 +218,33 @@ void hs_x448_derive_public_key(uint8_t *out, const uint8_t *scalar, const uint64
     words_to_bytes(out, o, 56);
 }
 
-// s*B through the 56 x 128 window table, the table being built here from the comb (slow; test only)
+// s*B through the BWT_WINDOWS x BWT_PER_WINDOW window table.  The device builds the whole table
+// (k_build_bwt); the checker computes just the entries a ladder asks for, with the same recipe:
+// T_i[k] = ((2k+1) * 2^(BWT_BITS*i) mod q) * B from the comb, as affine niels.
+struct HostBwt {
+    const HostComb *comb;
+    niels load(int i, uint32_t k) const {
+        sc v = sc_zero();
+        uint32_t m = 2 * k + 1;
+        int bit = BWT_BITS * i, extra = 0;
+        if (bit + BWT_BITS > 448) {
+            extra = bit + BWT_BITS - 448;
+            bit -= extra;
+        }
+        v.w[bit >> 5] |= m << (bit & 31);
+        if ((bit & 31) + BWT_BITS > 32 && (bit >> 5) + 1 < 14) v.w[(bit >> 5) + 1] |= m >> (32 - (bit & 31));
+        v = sc_reduce(v);
+        for (int d = 0; d < extra; d++) v = sc_add(v, v);
+        HostBits b = make_bits(v);
+        return host_affine_niels(ladder_comb(b, *comb));
+    }
+};
 void hs_bwt_scalarmul(uint64_t *out, const uint64_t *comb_table, const uint64_t *scalars, int n) {
     static HostComb comb;
     for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
-    static niels tab[56 * 128];
-    static bool built = false;
-    if (!built) {
-        for (int i = 0; i < 56; i++)
-            for (int k = 0; k < 128; k++) {
-                sc v = sc_zero();
-                uint32_t m = 2 * k + 1;               // (2k+1) << 8i as a 448-bit value
-                int bit = 8 * i;
-                v.w[bit >> 5] |= m << (bit & 31);
-                if ((bit & 31) > 23 && (bit >> 5) + 1 < 14) v.w[(bit >> 5) + 1] |= m >> (32 - (bit & 31));
-                HostBits b = make_bits(sc_reduce(v));
-                tab[128 * i + k] = host_affine_niels(ladder_comb(b, comb));
-            }
-        built = true;
-    }
-    HostBwt bwt{tab};
+    HostBwt bwt{&comb};
     for (int j = 0; j < n; j++) {
-        sc r = sc_recode_signed8(sc_from_abi(scalars + 7 * j));
+        sc r = sc_recode_bwt(sc_from_abi(scalars + 7 * j));
         HostBits b;
         for (int i = 0; i < 14; i++) b.w[i] = r.w[i];
         b.w[14] = 0;
