@@ -12,6 +12,8 @@ Everything written here is DATA: seeded inputs and the reference's outputs.
                     unreduced-limb inputs
   f5_constants.json base point limbs, SHA-256 of the comb table, sizeof/alignof
   f6_bench_digest.json  SHAKE256 digests over the 2^k outputs of the benchmark input stream
+  f7_verify_torsion.json  48 verify cases whose R / public key carry 2- or 4-torsion components or are
+                    small-order points themselves, with the reference's verdict
 """
 import ctypes as C
 import hashlib
@@ -199,8 +201,100 @@ def f6():
               open(os.path.join(HERE, "f6_bench_digest.json"), "w"), indent=1)
 
 
+# ---------------------------------------------------------------------------------------------------
+# f7: small-order (torsion) malleability.  Signatures whose R (or whose public key) carries a
+# 2- or 4-torsion component satisfy the verification equation only up to that component; whether they
+# are accepted is a property of the reference's point comparison (X1*Y2 == Y1*X2 on the isogenous
+# curve), so the reference's verdict is captured as data.  The signatures are made with independent
+# Python big-integer Ed448 arithmetic (RFC 8032 section 5.2), not with any library under test.
+ED_D = -39081
+ED_BX = 224580040295924300187604334099896036246789641632564134246125461686950415467406032909029192869357953282578032075146446173674602635247710
+ED_BY = 298819210078481492676017930443930673437544040154080242095928241372331506189835876003536878655418784733982303233503462500531545062832660
+
+
+def ed_add(P1, P2):
+    (x1, y1), (x2, y2) = P1, P2
+    t = ED_D * x1 * x2 * y1 * y2 % P
+    return ((x1 * y2 + y1 * x2) * pow(1 + t, P - 2, P) % P, (y1 * y2 - x1 * x2) * pow(1 - t, P - 2, P) % P)
+
+
+def ed_mul(k, Pt):
+    acc = (0, 1)
+    while k:
+        if k & 1:
+            acc = ed_add(acc, Pt)
+        Pt = ed_add(Pt, Pt)
+        k >>= 1
+    return acc
+
+
+def ed_enc(Pt):
+    x, y = Pt
+    return y.to_bytes(56, "little") + bytes([0x80 if x & 1 else 0])
+
+
+def shake114(*parts):
+    return hashlib.shake_256(b"".join(parts)).digest(114)
+
+
+def f7():
+    assert (ED_BX * ED_BX + ED_BY * ED_BY - 1 - ED_D * ED_BX * ED_BX * ED_BY * ED_BY) % P == 0
+    B = (ED_BX, ED_BY)
+    torsion = {"none": (0, 1), "T2": (0, P - 1), "T4": (1, 0), "T4neg": (P - 1, 0)}
+    cases = []
+    for i in range(40):
+        sk = _gen.stream(b"golden/f7/sk%d" % (i % 8), 57)
+        msg = _gen.stream(b"golden/f7/msg%d" % i, 40)[:[0, 7, 40][i % 3]]
+        ctx = b"" if i % 2 else b"f7"
+        h = shake114(sk)
+        a_bytes = bytearray(h[:57]); a_bytes[0] &= 0xfc; a_bytes[55] |= 0x80; a_bytes[56] = 0
+        a = int.from_bytes(a_bytes, "little")
+        A = ed_mul(a, B)
+        pk_ref = (C.c_uint8 * 57)()
+        R.goldilocks_ed448_derive_public_key(pk_ref, (C.c_uint8 * 57).from_buffer_copy(sk))
+        assert bytes(pk_ref) == ed_enc(A), "python Ed448 disagrees with the reference's derive_public_key"
+        kind_R, kind_A = [("none", "none"), ("T2", "none"), ("T4", "none"), ("T4neg", "none"), ("none", "T2"),
+                          ("none", "T4"), ("T2", "T2"), ("T4", "T4neg")][i % 8]
+        dom = b"SigEd448" + bytes([0, len(ctx)]) + ctx
+        r = int.from_bytes(shake114(dom, h[57:], msg), "little") % Q
+        A_pub = ed_add(A, torsion[kind_A])                # the key the verifier is given
+        R_pub = ed_add(ed_mul(r, B), torsion[kind_R])     # the R the verifier is given
+        hh = int.from_bytes(shake114(dom, ed_enc(R_pub), ed_enc(A_pub), msg), "little") % Q
+        S = (r + hh * a) % Q
+        sig = ed_enc(R_pub) + S.to_bytes(57, "little")
+        if kind_R == "none" and kind_A == "none":         # sanity: this is exactly RFC 8032 signing
+            ref_sig = (C.c_uint8 * 114)()
+            R.goldilocks_ed448_sign(ref_sig, (C.c_uint8 * 57).from_buffer_copy(sk), pk_ref,
+                                    (C.c_uint8 * max(1, len(msg))).from_buffer_copy(msg or b"\0"), len(msg), 0,
+                                    (C.c_uint8 * max(1, len(ctx))).from_buffer_copy(ctx or b"\0"), len(ctx))
+            assert bytes(ref_sig) == sig, "python Ed448 signing disagrees with the reference"
+        v = R.goldilocks_ed448_verify((C.c_uint8 * 114).from_buffer_copy(sig), (C.c_uint8 * 57).from_buffer_copy(ed_enc(A_pub)),
+                                      (C.c_uint8 * max(1, len(msg))).from_buffer_copy(msg or b"\0"), len(msg), 0,
+                                      (C.c_uint8 * max(1, len(ctx))).from_buffer_copy(ctx or b"\0"), len(ctx))
+        cases.append({"sig": sig.hex(), "pk": ed_enc(A_pub).hex(), "msg": msg.hex(), "ctx": ctx.hex(), "prehashed": 0,
+                      "verdict": v, "kind": "R+%s,A+%s" % (kind_R, kind_A)})
+    # degenerate encodings as keys / R: identity, order 2, order 4
+    base_case = cases[0]
+    for name, pt in torsion.items():
+        for where in ("R", "pk"):
+            sig, pk = bytearray.fromhex(base_case["sig"]), bytearray.fromhex(base_case["pk"])
+            if where == "R":
+                sig[:57] = ed_enc(pt)
+            else:
+                pk[:] = ed_enc(pt)
+            msg, ctx = bytes.fromhex(base_case["msg"]), bytes.fromhex(base_case["ctx"])
+            v = R.goldilocks_ed448_verify((C.c_uint8 * 114).from_buffer_copy(sig), (C.c_uint8 * 57).from_buffer_copy(pk),
+                                          (C.c_uint8 * max(1, len(msg))).from_buffer_copy(msg or b"\0"), len(msg), 0,
+                                          (C.c_uint8 * max(1, len(ctx))).from_buffer_copy(ctx or b"\0"), len(ctx))
+            cases.append({"sig": bytes(sig).hex(), "pk": bytes(pk).hex(), "msg": msg.hex(), "ctx": ctx.hex(), "prehashed": 0,
+                          "verdict": v, "kind": "%s=%s" % (where, name)})
+    json.dump({"cases": cases}, open(os.path.join(HERE, "f7_verify_torsion.json"), "w"), indent=0)
+    kinds = sorted(set(c["kind"] for c in cases))
+    print("f7 verdicts:", {k: sorted(set(c["verdict"] for c in cases if c["kind"] == k)) for k in kinds})
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6"]
+    which = sys.argv[1:] or ["f1", "f2", "f3", "f4", "f5", "f6", "f7"]
     for w in which:
         print("generating", w, flush=True)
         globals()[w]()

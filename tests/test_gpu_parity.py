@@ -324,6 +324,21 @@ def test_golden_f3_verify(ga):
     assert checked == 256
 
 
+def test_golden_f7_verify_torsion(ga):
+    """Torsion-malleable signatures and small-order R / keys: same verdicts as the real reference."""
+    cases = json.load(open(os.path.join(GOLD, "f7_verify_torsion.json")))["cases"]
+    groups = {}
+    for c in cases:
+        groups.setdefault(c["ctx"], []).append(c)
+    for ctx, cs in groups.items():
+        sigs = np.array([np.frombuffer(bytes.fromhex(c["sig"]), np.uint8) for c in cs])
+        pks = np.array([np.frombuffer(bytes.fromhex(c["pk"]), np.uint8) for c in cs])
+        msgs = [bytes.fromhex(c["msg"]) for c in cs]
+        got = ga.ed448_verify_batch(sigs, pks, msgs, context=bytes.fromhex(ctx))
+        assert list(got) == [c["verdict"] for c in cs], [c["kind"] for c in cs]
+    assert sum(len(v) for v in groups.values()) == 48
+
+
 def test_rfc8032_vectors_through_the_abi(ga):
     kats = json.load(open(os.path.join(GOLD, "kats.json")))
     for c in kats["rfc8032_ed448"]:

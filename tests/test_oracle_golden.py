@@ -101,6 +101,20 @@ def test_f3_verify(O):
     assert ("valid", -1) in seen and ("S_plus_q", -1) in seen and ("flip_R", 0) in seen
 
 
+def test_f7_verify_torsion(O):
+    """Signatures / keys with 2- and 4-torsion components (accepted by the reference) and small-order
+    points as R or as the key (rejected): the verdicts of the real reference, captured as data."""
+    cases = json.load(open(os.path.join(G, "f7_verify_torsion.json")))["cases"]
+    assert len(cases) == 48
+    for c in cases:
+        sig, pk, msg, ctx = (bytes.fromhex(c[k]) for k in ("sig", "pk", "msg", "ctx"))
+        v = O.orc_ed448_verify(buf(sig), buf(pk), buf(msg) if msg else None, len(msg), 0,
+                               buf(ctx) if ctx else None, len(ctx))
+        assert v == c["verdict"], c["kind"]
+    kinds = {c["kind"]: c["verdict"] for c in cases}
+    assert kinds["R+T2,A+none"] == -1 and kinds["R+none,A+T4"] == -1 and kinds["R=T2"] == 0 and kinds["pk=none"] == 0
+
+
 def test_f4_field(O):
     d = np.load(os.path.join(G, "f4_field.npz"))
     ser = (C.c_uint8 * 56)()
