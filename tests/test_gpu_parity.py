@@ -452,6 +452,8 @@ def test_x448_vs_oracle_and_rfc7748(ga, O):
     bs[0] = 0                     # low-order input: result must be zero -> FAILURE
     bs[1] = 0xff
     bs[2] = 0; bs[2, 0] = 1
+    for row, val in zip(range(4, 9), (P - 1, P, P + 1, 2, 5)):        # more low-order / non-canonical u
+        bs[row] = np.frombuffer(val.to_bytes(56, "little"), np.uint8)
     got, st = ga.x448_batch(sc, bs)
     pub, _ = ga.x448_batch(sc)
     for i in range(n):
