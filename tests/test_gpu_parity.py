@@ -139,6 +139,9 @@ def test_decode_encode_and_rejects(ga, O):
     rnd[0] = 0                       # identity encoding
     rnd[1] = 0xff                    # >= p
     rnd[2] = ser[2]; rnd[2, 0] |= 1  # "negative" s
+    special = [1, 2, 3, 4, 5, P - 1, P - 2, P, P + 1, 2**447, (P - 1) // 2, (P + 1) // 2]
+    for row, v in enumerate(special, start=3):                       # hand-picked encodings
+        rnd[row] = np.frombuffer(v.to_bytes(56, "little"), np.uint8)
     _, st0 = ga.point_decode_batch(rnd, allow_identity=False)
     _, st1 = ga.point_decode_batch(rnd, allow_identity=True)
     for i in range(n):

@@ -71,6 +71,31 @@ def test_differential(O):
             O.orc_ed448_verify(buf(bad), pk1, m, len(msg), it & 1, c, len(ctx))
 
 
+def test_decode_special_encodings_differential(O):
+    """Decaf and EdDSA decoding of hand-picked encodings (identity, 1, p-1, values >= p, small even and
+    odd values, set high bits): status and, when accepted, the raw output limbs match the reference."""
+    from _libs import P
+    R = ref()
+    vals = [0, 1, 2, 3, 4, 5, P - 1, P - 2, P, P + 1, 2**447, 2**448 - 1, (P - 1) // 2, (P + 1) // 2]
+    for v in vals:
+        enc = v.to_bytes(56, "little")
+        for allow in (0, 1):
+            d1, d2 = Point(), Point()
+            r1 = R.goldilocks_448_point_decode(C.byref(d1), buf(enc), allow)
+            r2 = O.orc_point_decode(C.byref(d2), buf(enc), allow)
+            assert r1 == r2, (v, allow)
+            if r1 == -1:
+                assert bytes(d1) == bytes(d2), (v, allow)
+        for last in (0x00, 0x80, 0x01, 0x7f):
+            e57 = enc + bytes([last])
+            d1, d2 = Point(), Point()
+            r1 = R.goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio(C.byref(d1), buf(e57))
+            r2 = O.orc_point_decode_like_eddsa(C.byref(d2), buf(e57))
+            assert r1 == r2, (v, last)
+            if r1 == -1:
+                assert bytes(d1) == bytes(d2), (v, last)
+
+
 def test_precompute_matches_reference(O):
     from _libs import Precomputed
     R = ref()
