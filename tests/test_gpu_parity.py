@@ -171,10 +171,18 @@ def test_eddsa_encode_decode(ga, O):
     assert (st == 0).all()
     rnd = np.frombuffer(_gen.stream(b"t-eddsa-rnd", 57 * n), dtype=np.uint8).reshape(n, 57).copy()
     rnd[:, 56] &= 0x80
-    _, st = ga.point_decode_like_eddsa_batch(rnd)
+    special = [0, 1, 2, 3, P - 1, P - 2, P, P + 1, 2**447, 2**448 - 1, (P - 1) // 2, (P + 1) // 2]
+    for k, v in enumerate(special):                                  # hand-picked y, both sign bits
+        for sgn in (0, 1):
+            rnd[2 * k + sgn, :56] = np.frombuffer(v.to_bytes(56, "little"), np.uint8)
+            rnd[2 * k + sgn, 56] = 0x80 * sgn
+    got, st = ga.point_decode_like_eddsa_batch(rnd)
     for i in range(n):
         p = Point()
-        assert O.orc_point_decode_like_eddsa(C.byref(p), (C.c_uint8 * 57).from_buffer_copy(rnd[i].tobytes())) == st[i]
+        assert O.orc_point_decode_like_eddsa(C.byref(p), (C.c_uint8 * 57).from_buffer_copy(rnd[i].tobytes())) == st[i], i
+        if st[i] == -1 and i < 2 * len(special):
+            w = np.frombuffer(bytes(p), np.uint64).reshape(1, 32)
+            assert (enc(ga, got[i:i + 1]) == _gen.oracle_encode(w)).all(), i
 
 
 def test_group_ops(ga, O):
