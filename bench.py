@@ -2,28 +2,40 @@
 """bench.py -- Ed448 variable-base scalarmuls/s, batch 2^20 per GPU (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1:  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-One "step" = one pass of goldilocks_448_point_scalarmul over a batch of 2^20 independent
-(point, scalar) pairs that are already resident in HBM (AoS reference structs), i.e. one launch
-of k_point_scalarmul through the C ABI (goldilocks_amd_point_scalarmul_dev).  Ranks own
-independent batches (weak scaling, no collective on the data path); the only collectives are the
-timing barrier and the MAX over ranks.  Rank 0 prints ONE JSON line.
+N > 1 works both ways: launched as `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...` (RANK/LOCAL_RANK/WORLD_SIZE in the environment), or plainly as `python bench.py --gpus
+N`: then this process starts N fresh child processes, one per rank, before it has touched a GPU
+(libgoldilocks_amd/shard.py: it never imports torch itself) and forwards rank 0's JSON line.  Ranks map
+to the visible devices modulo their count; RCCL carries the barrier/MAX when every rank has its own
+GPU, gloo when ranks share one (a 2-rank run on a 1-GPU box).
 
-Extra objects on the line:
-  roofline      HBM roofline of the dominant kernel: algorithmic bytes (568 B/op: 256 B point +
-                56 B scalar in, 256 B point out) / average launch duration measured
-                with HIP events on the launch stream, against 8 TB/s.  The path is integer-VALU
-                bound, so this fraction is tiny by construction; "valu" carries the honest
-                ceiling: achieved VALU wave-instructions/s vs the measured issue peak of the
-                ladder's instruction mix, and 32x32->64 MAC/s vs the measured v_mad_u64_u32 peak.
-  cpu_baseline  the REAL reference (arch_x86_64 path, oracle/_ref, built for generic x86-64) --
-                or the oracle port if that .so did not travel -- timed on the host cores over a
-                bounded sample of the same workload.
+One "step" = one pass of the hot path over a batch that is already resident in HBM, i.e. one kernel
+launch through the C ABI (goldilocks_amd_*_dev).  Ranks own independent batches (weak scaling, no
+collective on the data path), or contiguous slices of one global batch with --global-log2-batch
+(BASELINE config 5:  --workload verify --global-log2-batch 24 --gpus 8  -> 2^21 per GPU).
+Rank 0 prints ONE JSON line.
+
+Objects on the line besides the driver's contract:
+  per_gpu       each rank's own throughput, device and average kernel time (config 5 asks for it)
+  roofline      HBM roofline of the timed kernel: algorithmic bytes per op x ops per
+                launch / average launch duration from HIP events on the launch stream, against 8 TB/s.
+                The path is integer-multiply bound, so this fraction is tiny by construction;
+                "mac" carries the honest ceiling: 32x32->64 MAC/s against the measured
+                v_mad_u64_u32 peak (profiles/r01/ubench.txt).
+  configs       (default N = 1 run only) the other BASELINE configs timed for a few steps each in
+                the same process: fixed-base comb in LDS (config 3), the base-point window table,
+                verify (config 4), and the index-independent variable-base mode.
+  cpu_baseline  the REAL reference (arch_x86_64 path, oracle/_ref, built for generic x86-64) -- or
+                the oracle port if that .so did not travel -- on the host cores: a single-thread
+                figure by the reference's own benchmark method (test/bench_goldilocks.cxx:73-143:
+                50 samples x 20 iterations, 2 + 2 trimmed, mean; its :190 "Point scalarmul" line)
+                and a short thread sweep over a bounded sample of the same batch.
 """
 import argparse
 import ctypes as C
 import json
+import math
 import os
 import sys
 import time
@@ -33,61 +45,244 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 LOG2_BATCH = 20
-BYTES_PER_OP = 568          # algorithmic: 256 (point in) + 56 (scalar in) + 256 (point out)
-MACS_PER_OP = 680_584       # 2279 M x 192 + 1785 S x 136 + 16 mulw x 16 MACs per op
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_MAC_PEAK = 36.0e12     # measured: 560-576 G v_mad_u64_u32 wave-instr/s x 64 lanes (profiles/r01/ubench.txt)
-VALU_INSTR_PER_OP = 1.092e6 # VALU wave-instructions per op: SQ_INSTS_VALU / wave-ops (profiles/r01/rocprofv3_pmc_summary.json)
-VALU_ISSUE_PEAK = 600e9     # measured: wave-instr/s of a 1:1 MAC:simple mix at 2+ waves/SIMD (ubench mix_mac_add)
+
+# Per-workload figures.  bytes: algorithmic I/O per op.  macs: 32x32->64 multiply-
+# accumulates per op, counted by the host checker build of the same lane code
+# (tests/test_hostsim.py::test_mac_counts_match_bench keeps these in step with the code).
+WORKLOADS = {
+    "varbase": dict(metric="Ed448 variable-base scalarmuls/sec", unit="scalarmuls/s", bytes=568, macs=660_632,
+                    desc="goldilocks_448_point_scalarmul, variable base, random scalars"),
+    "fixed": dict(metric="Ed448 fixed-base scalarmuls/sec", unit="scalarmuls/s", bytes=312, macs=123_024,
+                  desc="goldilocks_448_precomputed_scalarmul, 5x5x18 comb table staged in LDS"),
+    "base": dict(metric="Ed448 base-point scalarmuls/sec", unit="scalarmuls/s", bytes=312, macs=36_672,
+                 desc="goldilocks_448_precomputed_scalarmul(precomputed_base), 16-bit window table"),
+    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=836_280,
+                   desc="goldilocks_ed448_verify, 32-byte messages, 1% corrupted"),
+    "sign": dict(metric="Ed448 signatures/sec", unit="signatures/s", bytes=260, macs=None,
+                 desc="goldilocks_ed448_sign, 32-byte messages, no context"),
+    "x448": dict(metric="X448 shared secrets/sec", unit="shared secrets/s", bytes=172, macs=None,
+                 desc="goldilocks_x448, random peer public keys"),
+    "direct": dict(metric="Ed448 wire-format scalarmuls/sec", unit="scalarmuls/s", bytes=172, macs=None,
+                   desc="goldilocks_448_direct_scalarmul, 56-byte encodings in and out"),
+}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH)
+    ap.add_argument("--log2-batch", type=int, default=LOG2_BATCH, help="operations per GPU (weak scaling)")
+    ap.add_argument("--global-log2-batch", type=int, default=None,
+                    help="one global batch of 2^G operations cut into contiguous per-rank slices (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", default="varbase", choices=["varbase", "fixed", "base", "verify", "sign", "x448", "direct"])
+    ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs on the default run")
+    ap.add_argument("--workload", default="varbase", choices=sorted(WORKLOADS))
     ap.add_argument("--table-access", default="fast", choices=["fast", "index-independent"],
-                    help="goldilocks_amd_set_table_access: how base-point tables are read for secret scalars "
-                         "(affects the base and sign workloads)")
-    return ap.parse_args()
+                    help="goldilocks_amd_set_table_access: how tables are read for (possibly secret) scalars; "
+                         "the library's default is index-independent, the headline metric is quoted on fast")
+    ap.add_argument("--stub-step-ms", type=float, default=None,
+                    help="launcher/timing self-test without a GPU: a step sleeps this long (tests only)")
+    return ap.parse_args(argv)
 
 
-def make_inputs(ga, np, torch, n, rank):
-    """Synthetic batch from the SHAKE256 stream "bench_varbase_v1/<rank>/..." (tests/_gen.py):
-    scalars uniform below 2^446; base points = k*B for stream scalars k (all distinct), computed
-    on the device by the fixed-base kernel.  Rank 0's batch is the one whose outputs are pinned
-    by tests/golden/f6_bench_digest.json (computed with the real reference)."""
+# ---------------------------------------------------------------------------------------- workloads
+
+class Ctx(object):
+    """What a workload needs: the binding, torch, the rank's batch size and launch stream."""
+
+    def __init__(self, ga, np, torch, n, rank, table_access):
+        self.ga, self.np, self.torch, self.n, self.rank, self.table_access = ga, np, torch, n, rank, table_access
+        self.stream = torch.cuda.current_stream().cuda_stream
+        self._pairs = None
+
+    def pairs(self):
+        """Synthetic (point, scalar) batch from the SHAKE256 stream "bench_varbase_v1/<rank>/..."
+        (tests/_gen.py): scalars uniform below 2^446; base points = k*B for stream scalars k (all
+        distinct), computed on the device by the fixed-base kernel.  Rank 0's 2^20 batch is the one
+        whose outputs are pinned by tests/golden/f6_bench_digest.json (made with the real reference)."""
+        if self._pairs is None:
+            import _gen
+            torch, np, n = self.torch, self.np, self.n
+
+            def stream_scalars(what):
+                s = _gen.stream_scalars(n, b"bench_varbase_v1/%d/%s" % (self.rank, what))
+                return torch.from_numpy(s.view(np.int64)).cuda()
+
+            scalars, k = stream_scalars(b"scalar"), stream_scalars(b"base")
+            bases = torch.empty((n, 32), dtype=torch.int64, device="cuda")
+            self.ga.dev("precomputed_scalarmul", bases.data_ptr(), None, k.data_ptr(), n, None)
+            torch.cuda.synchronize()
+            self._pairs = (bases, scalars)
+        return self._pairs
+
+
+def make_workload(name, cx):
+    """-> dict(step, kernel, check() -> (ok, text), keep=[tensors])"""
+    ga, np, torch, n, stream = cx.ga, cx.np, cx.torch, cx.n, cx.stream
+    ct = cx.table_access == "index-independent"
+    if name == "varbase":
+        bases, scalars = cx.pairs()
+        out = torch.empty_like(bases)
+        step = lambda: ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, stream)
+
+        def check():
+            stv = torch.empty(n, dtype=torch.int32, device="cuda")
+            ga.dev("point_pred", stv.data_ptr(), out.data_ptr(), None, 1, n, None)
+            ok = int((stv == -1).sum()) == n
+            text, extra = "every output is a valid point", {}
+            dig_path = os.path.join(ROOT, "tests", "golden", "f6_bench_digest.json")
+            known = json.load(open(dig_path))["digest_shake256_32"] if os.path.exists(dig_path) else {}
+            log2 = n.bit_length() - 1
+            if cx.rank == 0 and (1 << log2) == n and str(log2) in known:
+                import hashlib
+                ser = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+                ga.dev("point_encode", ser.data_ptr(), out.data_ptr(), n, None)
+                digest = hashlib.shake_256(ser.cpu().numpy().tobytes()).hexdigest(32)
+                match = digest == known[str(log2)]
+                ok = ok and match
+                text += "; SHAKE256 digest of all outputs equals the reference's (golden F6)"
+                extra["full_batch_digest"] = {"shake256_32": digest, "matches_reference_fixture": match}
+            return ok, text, extra
+        return dict(step=step, kernel="k_point_scalarmul_ct" if ct else "k_point_scalarmul", check=check, out=out)
+    if name in ("fixed", "base"):
+        _, scalars = cx.pairs()
+        out = torch.empty((n, 32), dtype=torch.int64, device="cuda")
+        if name == "fixed":    # BASELINE config 3: a caller's precomputed_s -> the 5x5x18 comb staged in LDS
+            tab = torch.from_numpy(ga.precomputed_base().view(np.int64)).cuda()
+            step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), tab.data_ptr(), scalars.data_ptr(), n, stream)
+            kernel = "k_precomputed_scalarmul"
+        else:                  # the built-in base point: 16-bit window table (LDS comb when index-independent)
+            tab = None
+            step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
+            kernel = "k_precomputed_scalarmul" if ct else "k_base_scalarmul"
+
+        def check():
+            m = min(n, 1 << 14)
+            base_pt = torch.from_numpy(np.repeat(ga.point_base().reshape(1, 32), m, axis=0).view(np.int64)).cuda()
+            alt = torch.empty((m, 32), dtype=torch.int64, device="cuda")
+            ga.dev("point_scalarmul", alt.data_ptr(), base_pt.data_ptr(), scalars.data_ptr(), m, None)
+            st = torch.empty(m, dtype=torch.int32, device="cuda")
+            ga.dev("point_pred", st.data_ptr(), alt.data_ptr(), out.data_ptr(), 0, m, None)
+            return int((st == -1).sum()) == m, "first %d results equal the variable-base ladder applied to the base point" % m, {}
+        return dict(step=step, kernel=kernel, check=check, keep=[tab])
+    if name == "direct":       # wire format in and out: 56-byte encodings, decode + ladder + encode fused
+        bases, scalars = cx.pairs()
+        enc_in = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+        ga.dev("point_encode", enc_in.data_ptr(), bases.data_ptr(), n, None)
+        enc_out = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+        st_direct = torch.empty(n, dtype=torch.int32, device="cuda")
+        step = lambda: ga.dev("direct_scalarmul", enc_out.data_ptr(), st_direct.data_ptr(), enc_in.data_ptr(),
+                              scalars.data_ptr(), 0, 0, n, stream)
+
+        def check():
+            ref = torch.empty_like(bases)
+            ga.dev("point_scalarmul", ref.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, None)
+            ref_enc = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+            ga.dev("point_encode", ref_enc.data_ptr(), ref.data_ptr(), n, None)
+            ok = bool((ref_enc == enc_out).all()) and int((st_direct == -1).sum()) == n
+            return ok, "every output equals encode(point_scalarmul(decode(input))) computed by the separate kernels", {}
+        return dict(step=step, kernel="k_direct_scalarmul_ct" if ct else "k_direct_scalarmul", check=check)
     import _gen
+    if name in ("sign", "x448"):
+        nb = 57 if name == "sign" else 56
+        sk = torch.from_numpy(np.frombuffer(_gen.stream(b"bench_%s_v1/%d/sk" % (name.encode(), cx.rank), nb * n),
+                                            np.uint8).reshape(n, nb).copy()).cuda()
+        if name == "sign":
+            pk = torch.empty((n, 57), dtype=torch.uint8, device="cuda")
+            ga.dev("ed448_derive_public_key", pk.data_ptr(), sk.data_ptr(), n, None)
+            msg = torch.from_numpy(np.frombuffer(_gen.stream(b"bench_sign_v1/%d/msg" % cx.rank, 32 * n), np.uint8)
+                                   .reshape(n, 32).copy()).cuda()
+            sig_out = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
+            step = lambda: ga.dev("ed448_sign", sig_out.data_ptr(), sk.data_ptr(), pk.data_ptr(), msg.data_ptr(), None,
+                                  32, 0, None, 0, n, stream)
 
-    def stream_scalars(what):
-        s = _gen.stream_scalars(n, b"bench_varbase_v1/%d/%s" % (rank, what))
-        return torch.from_numpy(s.view(np.int64)).cuda()
+            def check():
+                st = torch.empty(n, dtype=torch.int32, device="cuda")
+                ga.dev("ed448_verify", st.data_ptr(), sig_out.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0,
+                       None, 0, n, None)
+                return int((st == -1).sum()) == n, "every signature verifies (ed448_verify kernel)", {}
+            return dict(step=step, kernel="k_ed448_sign_ct" if ct else "k_ed448_sign", check=check)
+        pub = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+        ga.dev("x448", pub.data_ptr(), None, None, sk.data_ptr(), n, None)
+        peer = pub.view(n // 2, 2, 56).flip(1).reshape(n, 56).contiguous()      # lane i meets lane i^1's public key
+        shared = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+        st448 = torch.empty(n, dtype=torch.int32, device="cuda")
+        step = lambda: ga.dev("x448", shared.data_ptr(), st448.data_ptr(), peer.data_ptr(), sk.data_ptr(), n, stream)
 
-    scalars, k = stream_scalars(b"scalar"), stream_scalars(b"base")
-    bases = torch.empty((n, 32), dtype=torch.int64, device="cuda")
-    ga.dev("precomputed_scalarmul", bases.data_ptr(), None, k.data_ptr(), n, None)
-    torch.cuda.synchronize()
-    return bases, scalars, k
+        def check():
+            pairs = shared.view(n // 2, 2, 56)
+            ok = bool((pairs[:, 0] == pairs[:, 1]).all()) and int((st448 == -1).sum()) == n
+            return ok, "Diffie-Hellman symmetry: X448(a, pub_b) == X448(b, pub_a) for every neighbour pair", {}
+        return dict(step=step, kernel="k_x448", check=check)
+    # verify: signatures over 32-byte messages from 1024 distinct keys (SURVEY 8d config 4), produced by the
+    # library's own derive/sign kernels (bit-exact vs the reference: tests/test_gpu_parity.py); 1 % corrupted
+    nk, nsig = 1024, 4096
+    sk_k = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/sk" % cx.rank, 57 * nk), np.uint8).reshape(nk, 57)
+    pk_k = ga.ed448_derive_public_key_batch(sk_k)
+    key_of = np.arange(nsig) % nk
+    msg_h = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/msg" % cx.rank, 32 * nsig), np.uint8).reshape(nsig, 32)
+    sigs = ga.ed448_sign_batch(sk_k[key_of], pk_k[key_of], [m.tobytes() for m in msg_h])
+    pks = pk_k[key_of]
+    idx = np.random.default_rng(cx.rank).integers(0, nsig, n)
+    bad = np.random.default_rng(cx.rank + 99).random(n) < 0.01
+    sig_h = sigs[idx]
+    sig_h[bad, 5] ^= 0x20
+    d_sig, d_pk = torch.from_numpy(sig_h).cuda(), torch.from_numpy(pks[idx]).cuda()
+    d_msg = torch.from_numpy(msg_h[idx].copy()).cuda()
+    status = torch.empty(n, dtype=torch.int32, device="cuda")
+    step = lambda: ga.dev("ed448_verify", status.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(),
+                          None, 32, 0, None, 0, n, stream)
+
+    def check():
+        got = (status == -1).cpu().numpy()
+        return bool((got == ~bad).all()), "accepted lanes == uncorrupted lanes (signatures made by the sign kernel)", {}
+    return dict(step=step, kernel="k_ed448_verify", check=check)
 
 
-def cpu_baseline(np, bases_h, scalars_h):
-    """Time the reference's CPU path on the host cores over a bounded sample.  The only place in this
-    file that touches oracle/ (test infrastructure): it returns the canonical encodings of the first
-    256 reference results so that the caller can check the GPU's against them."""
+# ---------------------------------------------------------------------------------------- CPU baseline
+
+def host_cores():
+    """Cores this process may really use: scheduler affinity capped by the cgroup CPU quota."""
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / period
+        except (OSError, ValueError):
+            pass
+    usable = affinity if quota is None else max(1, min(affinity, int(math.ceil(quota))))
+    return usable, affinity, quota
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(np, bases_h, scalars_h, budget_s=9.0):
+    """Time the reference's CPU path on the host cores.  The only place in this file that touches
+    oracle/ (test infrastructure).  Returns the object for the JSON line and the canonical encodings of
+    the first 256 reference results so that the caller can check the GPU's against them."""
     from _libs import oracle, REF_X86_SO
+    import _gen
     O = oracle()
-    cores = os.cpu_count() or 1
-    threads = min(cores, 256)
-    m = min(len(scalars_h), threads * 8192)
-    b = np.ascontiguousarray(bases_h[:m])
-    s = np.ascontiguousarray(scalars_h[:m])
-    out = np.empty((m, 32), dtype=np.uint64)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    kind, what = "port", "oracle/gold_oracle.c (ref64-shaped restatement)"
-    fn = None
+    kind, what, fn = "port", "oracle/gold_oracle.c (ref64-shaped restatement, gcc -O3)", None
     if os.path.exists(REF_X86_SO):
         try:
             R = C.CDLL(REF_X86_SO)
@@ -95,235 +290,203 @@ def cpu_baseline(np, bases_h, scalars_h):
             kind, what = "reference", "reference arch_x86_64 path (oracle/_ref, gcc -O2 generic x86-64)"
         except OSError:
             fn = None
-    run = (lambda: O.orc_extern_scalarmul_batch(fn, p(out), p(b), p(s), m, threads)) if fn else \
-          (lambda: O.orc_point_scalarmul_batch(p(out), p(b), p(s), m, threads))
-    O.orc_point_scalarmul_batch(p(out), p(b), p(s), min(m, threads), threads)  # warm tables/threads
-    t0 = time.perf_counter()
-    run()
-    dt = time.perf_counter() - t0
-    import _gen
-    return {"value": m / dt, "unit": "scalarmuls/s", "cores": threads, "kind": kind,
-            "sample": "%d of the 2^20 (point, scalar) pairs, %d threads, %.1f s; %s" % (m, threads, dt, what)}, \
-        _gen.oracle_encode(out[:256])
+    usable, affinity, quota = host_cores()
+    n = len(scalars_h)
 
+    # (1) one thread, the reference's Benchmark method: 50 samples x 20 calls, drop 2 + 2, mean
+    nsamples, ntests, discard = 50, 20, 2
+    m1 = min(n, nsamples * ntests)
+    b1, s1 = np.ascontiguousarray(bases_h[:m1]), np.ascontiguousarray(scalars_h[:m1])
+    times = np.zeros(nsamples, dtype=np.float64)
+    O.orc_bench_extern_scalarmul(fn, p(b1), p(s1), m1, 3, ntests, p(times))          # warm tables and caches
+    O.orc_bench_extern_scalarmul(fn, p(b1), p(s1), m1, nsamples, ntests, p(times))
+    trimmed = np.sort(times)[discard:nsamples - discard]
+    us_per_op = float(trimmed.mean()) / ntests * 1e6
+    single = {"us_per_op": us_per_op, "value": 1e6 / us_per_op,
+              "method": "50 samples x 20 iterations, 2 low + 2 high dropped, mean (test/bench_goldilocks.cxx:73-143, :190)"}
 
-def main():
-    args = parse()
-    import numpy as np
-    import torch
-    import libgoldilocks_amd as ga
-    ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT if args.table_access == "index-independent" else ga.TABLES_FAST)
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or os.environ.get("GOLDILOCKS_BENCH_FORCE_DIST"):   # the env knob lets a 1-GPU box exercise the RCCL path
-        import torch.distributed as dist
-        os.environ.setdefault("NCCL_DEBUG", "WARN")    # keep RCCL's banner off stdout: one JSON line only
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    ga.lib()
-    info = ga.device_info()
-
-    n = 1 << args.log2_batch
-    bases, scalars, _ = make_inputs(ga, np, torch, n, rank)
-    out = torch.empty_like(bases)
-    stream = torch.cuda.current_stream().cuda_stream
-
-    if args.workload == "varbase":
-        step = lambda: ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, stream)
-        bytes_per_op, kernel = BYTES_PER_OP, "k_point_scalarmul"
-    elif args.workload == "fixed":     # BASELINE config 3: caller's precomputed_s -> the 5x5x18 comb staged in LDS
-        comb_tab = torch.from_numpy(ga.precomputed_base().view(np.int64)).cuda()
-        step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), comb_tab.data_ptr(), scalars.data_ptr(), n, stream)
-        bytes_per_op, kernel = 312, "k_precomputed_scalarmul"
-    elif args.workload == "base":      # the built-in base point: 16-bit window table (no doublings)
-        step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
-        bytes_per_op, kernel = 312, ("k_precomputed_scalarmul" if args.table_access == "index-independent" else "k_base_scalarmul")
-    elif args.workload == "direct":    # wire format in and out: 56-byte encodings, decode + ladder + encode fused
-        enc_in = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
-        ga.dev("point_encode", enc_in.data_ptr(), bases.data_ptr(), n, None)
-        enc_out = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
-        st_direct = torch.empty(n, dtype=torch.int32, device="cuda")
-        step = lambda: ga.dev("direct_scalarmul", enc_out.data_ptr(), st_direct.data_ptr(), enc_in.data_ptr(),
-                              scalars.data_ptr(), 0, 0, n, stream)
-        bytes_per_op, kernel = 56 + 56 + 56 + 4, "k_direct_scalarmul"
-    elif args.workload in ("sign", "x448"):
-        import _gen
-        nb = 57 if args.workload == "sign" else 56
-        sk = torch.from_numpy(np.frombuffer(_gen.stream(b"bench_%s_v1/%d/sk" % (args.workload.encode(), rank), nb * n),
-                                            np.uint8).reshape(n, nb).copy()).cuda()
-        if args.workload == "sign":
-            pk = torch.empty((n, 57), dtype=torch.uint8, device="cuda")
-            ga.dev("ed448_derive_public_key", pk.data_ptr(), sk.data_ptr(), n, None)
-            msg = torch.from_numpy(np.frombuffer(_gen.stream(b"bench_sign_v1/%d/msg" % rank, 32 * n), np.uint8)
-                                   .reshape(n, 32).copy()).cuda()
-            sig_out = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
-            step = lambda: ga.dev("ed448_sign", sig_out.data_ptr(), sk.data_ptr(), pk.data_ptr(), msg.data_ptr(), None,
-                                  32, 0, None, 0, n, stream)
-            bytes_per_op, kernel = 57 + 57 + 32 + 114, ("k_ed448_sign_ct" if args.table_access == "index-independent" else "k_ed448_sign")
+    # (2) thread sweep over a bounded sample of the same batch; every point about budget/4 seconds
+    per_point = max(0.5, (budget_s - 1.0) / 3.0)
+    sweep, first = [], None
+    for t in sorted({1, max(1, usable // 2), usable}):
+        t = min(t, 256)                                    # the harness has 256 thread slots
+        m = int(min(n, max(t * 64, per_point * t * single["value"])))
+        b, s = np.ascontiguousarray(bases_h[:m]), np.ascontiguousarray(scalars_h[:m])
+        out = np.empty((m, 32), dtype=np.uint64)
+        t0 = time.perf_counter()
+        if fn:
+            O.orc_extern_scalarmul_batch(fn, p(out), p(b), p(s), m, t)
         else:
-            pub = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
-            ga.dev("x448", pub.data_ptr(), None, None, sk.data_ptr(), n, None)
-            peer = pub.view(n // 2, 2, 56).flip(1).reshape(n, 56).contiguous()      # lane i meets lane i^1's public key
-            shared = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
-            st448 = torch.empty(n, dtype=torch.int32, device="cuda")
-            step = lambda: ga.dev("x448", shared.data_ptr(), st448.data_ptr(), peer.data_ptr(), sk.data_ptr(), n, stream)
-            bytes_per_op, kernel = 56 * 3 + 4, "k_x448"
-    else:
-        # 2^20 signatures over 32-byte messages from 1024 distinct keys, produced by
-        # the library's own derive/sign kernels (bit-exact vs the reference: tests/test_gpu_parity.py)
-        import _gen
-        nk, nsig = 1024, 4096
-        sk_k = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/sk" % rank, 57 * nk), np.uint8).reshape(nk, 57)
-        pk_k = ga.ed448_derive_public_key_batch(sk_k)
-        key_of = np.arange(nsig) % nk
-        msg_h = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/msg" % rank, 32 * nsig), np.uint8).reshape(nsig, 32)
-        sigs = ga.ed448_sign_batch(sk_k[key_of], pk_k[key_of], [m.tobytes() for m in msg_h])
-        pks = pk_k[key_of]
-        idx = np.random.default_rng(rank).integers(0, nsig, n)
-        bad = np.random.default_rng(rank + 99).random(n) < 0.01           # 1 % corrupted signatures
-        sig_h = sigs[idx]
-        sig_h[bad, 5] ^= 0x20
-        d_sig, d_pk = torch.from_numpy(sig_h).cuda(), torch.from_numpy(pks[idx]).cuda()
-        d_msg = torch.from_numpy(msg_h[idx].copy()).cuda()
-        status = torch.empty(n, dtype=torch.int32, device="cuda")
-        step = lambda: ga.dev("ed448_verify", status.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(),
-                              None, 32, 0, None, 0, n, stream)
-        bytes_per_op, kernel = 175 + 32, "k_ed448_verify"
+            O.orc_point_scalarmul_batch(p(out), p(b), p(s), m, t)
+        dt = time.perf_counter() - t0
+        sweep.append({"threads": t, "ops": m, "seconds": dt, "value": m / dt})
+        if first is None or len(out) > len(first):
+            first = out
+    best = max(sweep, key=lambda r: r["value"])
+    res = {"value": best["value"], "unit": "scalarmuls/s", "cores": best["threads"], "kind": kind,
+           "sample": "best of a thread sweep %s over the first %d of this batch's (point, scalar) pairs; %s" %
+                     ([r["threads"] for r in sweep], best["ops"], what),
+           "single_thread": single, "sweep": sweep, "cpu_model": cpu_model(), "affinity_cores": affinity,
+           "cgroup_quota_cores": quota, "usable_cores": usable}
+    return res, _gen.oracle_encode(first[:256])
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record()
-    for i in range(args.steps):
-        step()
-        ev[i + 1].record()
-    barrier()
-    dt = time.perf_counter() - t0
-    kernel_ms = [ev[i].elapsed_time(ev[i + 1]) for i in range(args.steps)]   # HIP events on the launch stream
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+# ---------------------------------------------------------------------------------------- one rank
 
-    # Check of what was just timed (not in the timed region).  No oracle here: size-independent
-    # properties on the device, the reference's digest fixture for the headline batch, and -- inside
-    # the cpu_baseline leg only -- the reference's own outputs on its sample.
-    ok = True
-    check = "n/a"
-    extra = {}
-    if rank == 0 and args.workload == "sign":
-        st = torch.empty(n, dtype=torch.int32, device="cuda")
-        ga.dev("ed448_verify", st.data_ptr(), sig_out.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0, None, 0, n, None)
-        ok = int((st == -1).sum()) == n
-        check = "every signature verifies (ed448_verify kernel)"
-    elif rank == 0 and args.workload == "x448":
-        pairs = shared.view(n // 2, 2, 56)
-        ok = bool((pairs[:, 0] == pairs[:, 1]).all()) and int((st448 == -1).sum()) == n
-        check = "Diffie-Hellman symmetry: X448(a, pub_b) == X448(b, pub_a) for every neighbour pair"
-    elif rank == 0 and args.workload == "direct":
-        ref = torch.empty_like(bases)
-        ga.dev("point_scalarmul", ref.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, None)
-        ref_enc = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
-        ga.dev("point_encode", ref_enc.data_ptr(), ref.data_ptr(), n, None)
-        ok = bool((ref_enc == enc_out).all()) and int((st_direct == -1).sum()) == n
-        check = "every output equals encode(point_scalarmul(decode(input))) computed by the separate kernels"
-    elif rank == 0 and args.workload in ("fixed", "base"):
-        m = 1 << 14
-        base_pt = torch.from_numpy(np.repeat(ga.point_base().reshape(1, 32), m, axis=0).view(np.int64)).cuda()
-        alt = torch.empty((m, 32), dtype=torch.int64, device="cuda")
-        ga.dev("point_scalarmul", alt.data_ptr(), base_pt.data_ptr(), scalars.data_ptr(), m, None)
-        st = torch.empty(m, dtype=torch.int32, device="cuda")
-        ga.dev("point_pred", st.data_ptr(), alt.data_ptr(), out.data_ptr(), 0, m, None)
-        ok = int((st == -1).sum()) == m
-        check = "first 2^14 results equal the variable-base ladder applied to the base point"
-    elif rank == 0 and args.workload == "varbase":
-        b_h, s_h = bases.cpu().numpy().view(np.uint64), scalars.cpu().numpy().view(np.uint64)
-        stv = torch.empty(n, dtype=torch.int32, device="cuda")
-        ga.dev("point_pred", stv.data_ptr(), out.data_ptr(), None, 1, n, None)
-        ok = int((stv == -1).sum()) == n
-        check = "every output is a valid point"
-        dig_path = os.path.join(ROOT, "tests", "golden", "f6_bench_digest.json")
-        if os.path.exists(dig_path) and str(args.log2_batch) in json.load(open(dig_path))["digest_shake256_32"]:
-            import hashlib
-            ser = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
-            ga.dev("point_encode", ser.data_ptr(), out.data_ptr(), n, None)
-            digest = hashlib.shake_256(ser.cpu().numpy().tobytes()).hexdigest(32)
-            match = digest == json.load(open(dig_path))["digest_shake256_32"][str(args.log2_batch)]
-            ok = ok and match
-            check += "; SHAKE256 digest of all outputs equals the reference's (golden F6)"
-            extra["full_batch_digest"] = {"shake256_32": digest, "matches_reference_fixture": match}
-        if not args.no_cpu_baseline and world == 1:   # rank 0 at N=1 only
-            extra["cpu_baseline"], ref_enc = cpu_baseline(np, b_h, s_h)
-            same = bool((ga.point_encode_batch(out[:256].cpu().numpy().view(np.uint64)) == ref_enc).all())
-            ok = ok and same
-            check += "; first 256 results bit-exact vs the CPU baseline's outputs"
-    elif rank == 0:
-        ok = abs(int((status == -1).sum()) - int((~bad).sum())) == 0
-        check = "accepted == uncorrupted lanes (signatures made by the sign kernel)"
+def time_workload(torch, shard, w, steps, warmup, dist, backend):
+    """-> (seconds of this rank, MAX over ranks, per-step kernel ms from HIP events on the launch stream)."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+    mine, worst = shard.timed_region(w["step"], steps, warmup, torch.cuda.synchronize, dist, backend,
+                                     after_step=lambda i: ev[i + 1].record())
+    return mine, worst, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
+
+def pmc_traffic(kernel):
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(path):
+        return json.load(open(path)).get(kernel)
+    return None
+
+
+def roofline(name, kernel, n, avg_ms):
+    spec = WORKLOADS[name]
+    achieved = spec["bytes"] * n / (avg_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "traffic": pmc_traffic(kernel), "kernel": kernel, "kernel_ms_avg": avg_ms, "bytes_per_op": spec["bytes"],
+         "note": "integer-multiply bound by construction (SURVEY 8d); the ceiling that matters is mac"}
+    if spec["macs"]:
+        macs = spec["macs"] * n / (avg_ms * 1e-3)
+        r["mac"] = {"achieved": macs / 1e12, "peak": VALU_MAC_PEAK / 1e12, "unit": "T MAC/s",
+                    "frac": macs / VALU_MAC_PEAK, "macs_per_op": spec["macs"]}
+    return r
+
+
+def run_stub(args, shard, rank, world):
+    """Launcher / process-group / timing path without a GPU (tests/test_bench_launcher.py)."""
+    dist, backend = shard.init_group(world, rank, 0, use_gpu=False)
+    n = 1 << args.log2_batch
+    step = lambda: time.sleep(args.stub_step_ms * 1e-3 * (1 + rank))
+    mine, worst = shard.timed_region(step, args.steps, args.warmup, lambda: None, dist, backend)
+    rows = shard.gather_over_ranks([rank, -1, n * args.steps / mine, mine / args.steps * 1e3], dist, backend)
     if rank == 0:
-        total_ops = n * args.steps * world
-        value = total_ops / dt
-        avg_ms = sum(kernel_ms) / len(kernel_ms)
-        achieved = bytes_per_op * n / (avg_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get(kernel)
-        line = {
-            "metric": {"varbase": "Ed448 variable-base scalarmuls/sec, batch=2^%d" % args.log2_batch,
-                       "fixed": "Ed448 fixed-base scalarmuls/sec, batch=2^%d" % args.log2_batch,
-                       "base": "Ed448 base-point scalarmuls/sec, batch=2^%d" % args.log2_batch,
-                       "verify": "Ed448 verifies/sec, batch=2^%d" % args.log2_batch, "sign": "Ed448 signatures/sec, batch=2^%d" % args.log2_batch,
-                       "x448": "X448 shared secrets/sec, batch=2^%d" % args.log2_batch,
-                       "direct": "Ed448 wire-format scalarmuls/sec, batch=2^%d" % args.log2_batch}[args.workload],
-            "value": value, "unit": {"varbase": "scalarmuls/s", "fixed": "scalarmuls/s", "base": "scalarmuls/s", "verify": "verifies/s",
-                                     "sign": "signatures/s", "x448": "shared secrets/s", "direct": "scalarmuls/s"}[args.workload],
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": {"varbase": "goldilocks_448_point_scalarmul, variable base, random scalars",
-                                    "fixed": "goldilocks_448_precomputed_scalarmul, 5x5x18 comb table staged in LDS",
-                                    "base": "goldilocks_448_precomputed_scalarmul(precomputed_base), 16-bit window table",
-                                    "verify": "goldilocks_ed448_verify, 32-byte messages, 1% corrupted",
-                                    "sign": "goldilocks_ed448_sign, 32-byte messages, no context",
-                                    "x448": "goldilocks_x448, random peer public keys",
-                                    "direct": "goldilocks_448_direct_scalarmul, 56-byte encodings in and out"}[args.workload],
-                       "batch_per_gpu": n, "table_access": args.table_access,
-                       "sharding": "independent batch per GPU, no data-path collective",
-                       "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],
-                       "parity_spot_check": "ok" if ok else "FAILED", "check": check},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel,
-                         "kernel_ms_avg": avg_ms, "bytes_per_op": bytes_per_op,
-                         "note": "integer-VALU bound by construction; see valu"},
-        }
-        if args.workload == "varbase":
-            macs = MACS_PER_OP * n / (avg_ms * 1e-3)
-            issue = VALU_INSTR_PER_OP * n / 64 / (avg_ms * 1e-3)
-            line["valu"] = {"bound": "VALU issue (every VALU op costs ~4 SIMD-cycles once interleaved with MACs)",
-                            "achieved": issue / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instr/s",
-                            "frac": issue / VALU_ISSUE_PEAK,
-                            "mac": {"achieved": macs / 1e12, "peak": VALU_MAC_PEAK / 1e12, "unit": "T MAC/s",
-                                    "frac": macs / VALU_MAC_PEAK}}
-        line.update(extra)
-        print(json.dumps(line), flush=True)
-        if not ok:
-            sys.exit(2)
+        print(json.dumps({
+            "metric": "stub steps", "value": n * args.steps * world / worst, "unit": "ops/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": worst / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
+            "config": {"workload": "stub", "backend": backend},
+            "per_gpu": [{"rank": int(r[0]), "device": int(r[1]), "value": r[2], "ms_per_step": r[3]} for r in rows]}),
+            flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def run_rank(args):
+    from libgoldilocks_amd import shard
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.stub_step_ms is not None:
+        return run_stub(args, shard, rank, world)
+    import numpy as np
+    import torch
+    import libgoldilocks_amd as ga
+    visible = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    device = shard.device_for_rank(local_rank, visible)
+    torch.cuda.set_device(device)
+    dist, backend = shard.init_group(world, rank, visible)
+    ga.lib()
+    ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT if args.table_access == "index-independent" else ga.TABLES_FAST)
+    info = ga.device_info()
+
+    if args.global_log2_batch is not None:
+        lo, hi = shard.shard_range(1 << args.global_log2_batch, rank, world)
+        n, scaling = hi - lo, "strong"
+    else:
+        n, scaling = 1 << args.log2_batch, "weak"
+    name = args.workload
+    spec = WORKLOADS[name]
+    cx = Ctx(ga, np, torch, n, rank, args.table_access)
+    w = make_workload(name, cx)
+    mine, worst, kernel_ms = time_workload(torch, shard, w, args.steps, args.warmup, dist, backend)
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    rows = shard.gather_over_ranks([rank, device, n * args.steps / mine, avg_ms, n], dist, backend)
+    ok, check, extra = w["check"]() if rank == 0 else (True, "n/a", {})
+
+    line = None
+    if rank == 0:
+        total_ops = sum(int(r[4]) for r in rows) * args.steps
+        batch_txt = ("2^%d" % (n.bit_length() - 1)) if n & (n - 1) == 0 else str(n)
+        line = {
+            "metric": "%s, batch=%s" % (spec["metric"], batch_txt), "value": total_ops / worst, "unit": spec["unit"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": worst / args.steps * 1e3,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": spec["desc"], "batch_per_gpu": n, "table_access": args.table_access,
+                       "sharding": ("contiguous slices of one global batch of 2^%d" % args.global_log2_batch
+                                    if args.global_log2_batch is not None else "independent batch per GPU")
+                                   + ", no data-path collective", "control_plane": backend or "single process",
+                       "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],
+                       "parity_spot_check": "ok" if ok else "FAILED", "check": check},
+            "per_gpu": [{"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
+                         "kernel_ms_avg": r[3], "batch": int(r[4])} for r in rows],
+            "roofline": roofline(name, w["kernel"], n, avg_ms),
+        }
+        line.update(extra)
+
+    # the other BASELINE configs, a few steps each (default single-GPU run of the headline only)
+    if rank == 0 and world == 1 and name == "varbase" and args.table_access == "fast" and not args.no_configs \
+            and args.global_log2_batch is None:
+        configs = {}
+        for cname, access in (("fixed", "fast"), ("base", "fast"), ("verify", "fast"), ("varbase", "index-independent")):
+            ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT if access == "index-independent" else ga.TABLES_FAST)
+            cx.table_access = access
+            cw = make_workload(cname, cx)
+            _, cworst, cms = time_workload(torch, shard, cw, 5, 1, None, None)
+            cok, ctext, _ = cw["check"]()
+            cavg = sum(cms) / len(cms)
+            r = roofline(cname, cw["kernel"], n, cavg)
+            key = cname if access == "fast" else cname + "_index_independent"
+            configs[key] = {"value": n * 5 / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
+                            "table_access": access, "steps": 5, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
+                            "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit")},
+                            "mac_frac": r["mac"]["frac"] if "mac" in r else None, "check": ctext,
+                            "parity_spot_check": "ok" if cok else "FAILED"}
+            ok = ok and cok
+            del cw
+        ga.set_table_access(ga.TABLES_FAST)
+        cx.table_access = "fast"
+        line["configs"] = configs
+
+    if rank == 0 and world == 1 and name == "varbase" and not args.no_cpu_baseline:   # rank 0 at N = 1 only
+        bases, scalars = cx.pairs()
+        b_h, s_h = bases.cpu().numpy().view(np.uint64), scalars.cpu().numpy().view(np.uint64)
+        line["cpu_baseline"], ref_enc = cpu_baseline(np, b_h, s_h)
+        same = bool((ga.point_encode_batch(w["out"][:256].cpu().numpy().view(np.uint64)) == ref_enc).all())
+        ok = ok and same
+        line["config"]["check"] += "; first 256 results bit-exact vs the CPU baseline's outputs"
+        line["config"]["parity_spot_check"] = "ok" if ok else "FAILED"
+
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and not ok:
+        sys.exit(2)
+
+
+def main(argv=None):
+    args = parse(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: one fresh process per rank, started before this process has
+        # touched a GPU (it never does: shard.py imports neither torch nor HIP)
+        from libgoldilocks_amd import shard
+        code = shard.launch_ranks([os.path.abspath(__file__)] + list(sys.argv[1:] if argv is None else argv), args.gpus)
+        print(json.dumps({"launcher": {"ranks": args.gpus, "exit_code": code,
+                                       "torch_imported_by_launcher": any(m == "torch" or m.startswith("torch.")
+                                                                         for m in sys.modules)}}), file=sys.stderr)
+        sys.exit(code)
+    run_rank(args)
 
 
 if __name__ == "__main__":

@@ -41,23 +41,37 @@ extern "C" {
 
 /* ------------------------------------------------------------------ ABI types */
 
-#define GOLDILOCKS_448_SER_BYTES 56            /* ref: point_448.h:40 */
-#define GOLDILOCKS_448_SCALAR_BYTES 56         /* ref: point_448.h:48 */
-#define GOLDILOCKS_448_SCALAR_LIMBS 7          /* ref: point_448.h:23 */
-#define GOLDILOCKS_EDDSA_448_PUBLIC_BYTES 57   /* ref: ed448.h:24 */
-#define GOLDILOCKS_EDDSA_448_PRIVATE_BYTES 57  /* ref: ed448.h:27 */
-#define GOLDILOCKS_EDDSA_448_SIGNATURE_BYTES 114 /* ref: ed448.h:30 */
-
+/* This header can be included next to the reference's own <goldilocks.h> (include that one FIRST):
+ * every type, macro and inline function the reference already declares is skipped here, and the
+ * prototypes below are then plain re-declarations of the reference's (same types). */
+#ifndef __GOLDILOCKS_COMMON_H__
 typedef uint64_t goldilocks_word_t;  /* ref: common.h:60 */
 typedef uint64_t goldilocks_bool_t;  /* all-ones / zero mask; ref: common.h:62 */
 typedef enum {                       /* ref: common.h:82-85 */
     GOLDILOCKS_SUCCESS = -1,
     GOLDILOCKS_FAILURE = 0
 } goldilocks_error_t;
+#endif
 
+#ifndef __GOLDILOCKS_ED448_H__
+#define GOLDILOCKS_EDDSA_448_PUBLIC_BYTES 57   /* ref: ed448.h:24 */
+#define GOLDILOCKS_EDDSA_448_PRIVATE_BYTES 57  /* ref: ed448.h:27 */
+#define GOLDILOCKS_EDDSA_448_SIGNATURE_BYTES 114 /* ref: ed448.h:30 */
+#endif
+
+#ifndef __GOLDILOCKS_POINT_448_H__
+#define GOLDILOCKS_448_SER_BYTES 56            /* ref: point_448.h:40 */
+#define GOLDILOCKS_448_SCALAR_BYTES 56         /* ref: point_448.h:48 */
+#define GOLDILOCKS_448_SCALAR_LIMBS 7          /* ref: point_448.h:23 */
+#define GOLDILOCKS_X448_PUBLIC_BYTES 56        /* ref: point_448.h:60 */
+#define GOLDILOCKS_X448_PRIVATE_BYTES 56       /* ref: point_448.h:63 */
+
+#ifndef __GOLDILOCKS_448_GF_DEFINED__
+#define __GOLDILOCKS_448_GF_DEFINED__ 1
 typedef struct gf_448_s {            /* ref: point_448.h:33-35 */
     goldilocks_word_t limb[8];
 } __attribute__((aligned(32))) gf_448_s, gf_448_p[1];
+#endif
 
 typedef struct goldilocks_448_point_s {   /* ref: point_448.h:66-70 */
     gf_448_p x, y, z, t;
@@ -68,10 +82,18 @@ typedef struct goldilocks_448_scalar_s {  /* ref: point_448.h:82-86 */
 } goldilocks_448_scalar_s, goldilocks_448_scalar_p[1];
 
 /* Opaque, caller-allocated, goldilocks_448_sizeof_precomputed_s bytes (15360),
- * goldilocks_448_alignof_precomputed_s alignment.  ref: point_448.h:73-79.
+ * goldilocks_448_alignof_precomputed_s alignment (32: what the reference's widest build exports;
+ * this library itself needs 16).  ref: point_448.h:73-79.
  * Contents are bit-compatible with the reference's (80 affine niels, canonical limbs). */
 struct goldilocks_448_precomputed_s;
 typedef struct goldilocks_448_precomputed_s goldilocks_448_precomputed_s;
+
+/* ref: point_448.h:273-278 */
+static inline void goldilocks_448_point_copy(goldilocks_448_point_p a, const goldilocks_448_point_p b) { *a = *b; }
+#else
+/* the reference names the scalar struct only by its tag; the batch prototypes below use this name */
+typedef struct goldilocks_448_scalar_s goldilocks_448_scalar_s;
+#endif /* __GOLDILOCKS_POINT_448_H__ */
 
 /* ------------------------------------------------------------------ exported constants */
 
@@ -144,10 +166,9 @@ GOLDILOCKS_AMD_API void goldilocks_448_point_double(goldilocks_448_point_p two_a
 GOLDILOCKS_AMD_API void goldilocks_448_point_negate(goldilocks_448_point_p nega,
         const goldilocks_448_point_p a);
 /* Memory-only helpers of the reference API (no field arithmetic, so nothing to launch):
- * copy (ref: point_448.h:273-278), constant-time select between two points, pick_b nonzero -> b
- * (ref: point_448.h:558-563, src/goldilocks.c:879-886), secure erase (ref: point_448.h:734-745,
- * src/goldilocks.c:1332-1342). */
-static inline void goldilocks_448_point_copy(goldilocks_448_point_p a, const goldilocks_448_point_p b) { *a = *b; }
+ * constant-time select between two points, pick_b nonzero -> b (ref: point_448.h:558-563,
+ * src/goldilocks.c:879-886), secure erase (ref: point_448.h:734-745, src/goldilocks.c:1332-1342);
+ * goldilocks_448_point_copy is the inline above. */
 GOLDILOCKS_AMD_API void goldilocks_448_point_cond_sel(goldilocks_448_point_p out,
         const goldilocks_448_point_p a, const goldilocks_448_point_p b, goldilocks_word_t pick_b);
 GOLDILOCKS_AMD_API void goldilocks_448_point_destroy(goldilocks_448_point_p point);
@@ -187,8 +208,6 @@ GOLDILOCKS_AMD_API void goldilocks_448_point_from_hash_uniform(goldilocks_448_po
         const unsigned char hashed_data[2 * GOLDILOCKS_448_SER_BYTES]);
 
 /* --- "next" row f3: X448 (RFC 7748) --- */
-#define GOLDILOCKS_X448_PUBLIC_BYTES 56   /* ref: point_448.h:60 */
-#define GOLDILOCKS_X448_PRIVATE_BYTES 56  /* ref: point_448.h:63 */
 /* shared = X448(scalar, base); FAILURE iff the result is all zero.  ref: point_448.h:398-402, src/goldilocks.c:1006-1076 */
 GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_x448(uint8_t shared[GOLDILOCKS_X448_PUBLIC_BYTES],
         const uint8_t base[GOLDILOCKS_X448_PUBLIC_BYTES], const uint8_t scalar[GOLDILOCKS_X448_PRIVATE_BYTES]);
@@ -247,7 +266,9 @@ GOLDILOCKS_AMD_API int goldilocks_x448_batch(uint8_t *shared /* n*56 */, goldilo
 /* ------------------------------------------------------------------ (3) device-array API
  * Pointers are device pointers (hipMalloc / torch.Tensor.data_ptr()); `stream` is a
  * hipStream_t (NULL = default stream).  Calls are asynchronous on that stream and use a
- * per-device workspace owned by the library: issue them from one stream at a time per device. */
+ * per-device workspace owned by the library; a call on a different stream than the previous
+ * workspace user first waits (on the device, hipStreamWaitEvent) for that one to finish, so calls
+ * from several streams are safe and simply serialize where they share the workspace. */
 
 /* Bind this process to a device and build the device-resident tables.  Optional (every
  * entry point initialises lazily on the current HIP device).  Returns 0 on success. */
@@ -262,18 +283,31 @@ GOLDILOCKS_AMD_API const char *goldilocks_amd_last_error(void);
  * devices 0..count-1.  A device may be listed more than once (its shards then run one after the
  * other).  Returns 0 on success. */
 GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count);
-/* Table-access policy for multiplications of the built-in base point by a SECRET scalar (key
- * derivation, signing nonces, X448 key generation, precomputed_scalarmul on
- * goldilocks_448_precomputed_base).  FAST (default): the 16-bit window table in global memory; the
- * address of each lookup depends on the digit.  INDEX_INDEPENDENT: the reference's 5x5x18 comb
- * staged in LDS, every lookup a wavefront-shuffle gather whose addresses and timing do not depend on
- * the digit -- the counterpart of the reference's constant_time_lookup (src/include/
- * constant_time.h:61-362), at about half the fixed-base throughput.  Process-wide; returns 0, or
- * nonzero for an unknown mode.  Verification and caller-supplied precomputed_s tables are not
- * affected (the latter always use the comb). */
+/* Table-access policy for every multiplication whose scalar may be SECRET.  The reference reads its
+ * window and comb tables with constant_time_lookup (src/include/constant_time.h:134-183; contract in its
+ * README.md:92-97: no secret-dependent branches or memory addresses) in point_scalarmul,
+ * point_double_scalarmul, point_dual_scalarmul, direct_scalarmul, precomputed_scalarmul and through
+ * them derive_public_key, sign and x448_derive_public_key.  This library keeps that contract BY DEFAULT:
+ *
+ *   GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT (default)
+ *     - base-point multiplications (derive, sign, X448 key generation, precomputed_scalarmul): the
+ *       reference's 5x5x18 comb staged in LDS, every lookup a wavefront-shuffle gather whose
+ *       addresses and timing do not depend on the digit;
+ *     - variable-base multiplications (point_scalarmul, direct_scalarmul, double_scalarmul,
+ *       dual_scalarmul): 4-bit signed windows, every lookup reads all 8 entries of the lane's table
+ *       and keeps the wanted one with a select.
+ *   GOLDILOCKS_AMD_TABLES_FAST (opt-in, for PUBLIC scalars only)
+ *     - each lookup reads only the digit's entry (the address depends on the digit): the base point's
+ *       16-bit window table in global memory, 5-bit windows for a variable base.
+ *
+ * Not affected: verification and base_double_scalarmul_non_secret (public by contract: always the
+ * fast tables), goldilocks_x448 with a peer's point (a Montgomery ladder with selects, no table),
+ * caller-supplied precomputed_s tables (always the LDS comb).  Process-wide; returns 0, or nonzero
+ * for an unknown mode. */
 #define GOLDILOCKS_AMD_TABLES_FAST 0
 #define GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT 1
 GOLDILOCKS_AMD_API int goldilocks_amd_set_table_access(int mode);
+GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the mode in force */
 /* "gfx950", number of CUs, workspace bytes currently held */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
         size_t *workspace_bytes);
@@ -307,7 +341,11 @@ GOLDILOCKS_AMD_API int goldilocks_amd_precompute_dev(void *table /* precomputed_
 /* Messages: if msg_offsets != NULL, message i is msgs[msg_offsets[i] .. msg_offsets[i+1])
  * (uint64 offsets, n+1 entries, device memory); otherwise every message is msg_len bytes at
  * msgs + i*msg_len.  ctx: device pointer to ctx_len bytes (may be NULL when ctx_len == 0).
- * status: int32[n], -1 = GOLDILOCKS_SUCCESS, 0 = GOLDILOCKS_FAILURE. */
+ * status: int32[n], -1 = GOLDILOCKS_SUCCESS, 0 = GOLDILOCKS_FAILURE.
+ * Every message must be shorter than GOLDILOCKS_AMD_MAX_MESSAGE_BYTES: the host-array calls and the
+ * fixed-length form return an error for longer ones; a longer message behind device-resident offsets
+ * makes that lane FAIL verification (and signing writes an all-zero signature for it). */
+#define GOLDILOCKS_AMD_MAX_MESSAGE_BYTES 0x7fffff00ull
 GOLDILOCKS_AMD_API int goldilocks_amd_ed448_verify_dev(void *status, const void *sig, const void *pk,
         const void *msgs, const void *msg_offsets, size_t msg_len, uint8_t prehashed,
         const void *ctx, uint8_t ctx_len, size_t n, void *stream);
@@ -331,9 +369,17 @@ GOLDILOCKS_AMD_API int goldilocks_amd_point_from_hash_dev(void *pt, const void *
 GOLDILOCKS_AMD_API int goldilocks_amd_x448_dev(void *shared /* n*56 */, void *status, const void *base,
         const void *scalar /* n*56 */, size_t n, void *stream);
 
-/* Field-level test hook (parity tests for gf_mul / gf_sqr / gf_isr, ref: src/f_field.h:76-79):
- * op 0: out = a*b, 1: out = a^2, 2: out = isr(a) (status = mask), 3: out = strong_reduce(a).
- * a, b, out: gf_448_s[n] in the ABI limb form. */
+/* Field-level test hook (parity tests for SURVEY 8a rows a2-a7; ref: src/f_field.h:76-79,
+ * src/arch_ref64/f_impl.h:10-38, src/f_generic.c:19-131).  a, b, out: gf_448_s[n] in the ABI limb form.
+ * op & 0xff:  0 out = a*b   1 out = a^2   2 out = isr(a), status = mask   3 out = strong_reduce(a), raw limbs
+ *             4 out = a*w, w = low 32 bits of b[i].limb[0] (gf_mulw_unsigned)
+ *             5 out = gf_add(a, b)   6 out = gf_sub(a, b)   7 out = weak_reduce(a)   (inputs taken as
+ *               given, unreduced limbs included; outputs raw limbs)
+ *             8 status = gf_eq(a, b)   9 status = gf_lobit(a)
+ *            10 out = the 56 serialized bytes (limbs 0..6)   11 a = 56 bytes, out = limbs, status = value < p
+ *            12 out = (ma*a)*(mb*b), 13 out = (ma*a)^2 with the multiples formed limb-wise without
+ *               reduction, ma = (op >> 8) & 0xff, mb = (op >> 16) & 0xff: operands at the limits of the
+ *               device arithmetic's magnitude contract. */
 GOLDILOCKS_AMD_API int goldilocks_amd_field_op_dev(void *out, void *status, const void *a, const void *b,
         int op, size_t n, void *stream);
 

@@ -79,6 +79,7 @@ FUNCTIONS = {
     "goldilocks_amd_device_info": (C.c_int, "pzpp"),
     "goldilocks_amd_use_devices": (C.c_int, "pi"),
     "goldilocks_amd_set_table_access": (C.c_int, "i"),
+    "goldilocks_amd_get_table_access": (C.c_int, ""),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -391,10 +392,14 @@ TABLES_FAST, TABLES_INDEX_INDEPENDENT = 0, 1
 
 
 def set_table_access(mode):
-    """TABLES_FAST (default) or TABLES_INDEX_INDEPENDENT: how the kernels that multiply the base point
-    by a secret scalar (derive, sign, X448 keygen, precomputed_scalarmul on the built-in table) look
-    up their table -- see include/goldilocks_amd.h."""
+    """TABLES_INDEX_INDEPENDENT (the library's default, the reference's constant-time contract) or
+    TABLES_FAST (opt-in for public scalars): how every kernel whose scalar may be secret looks up its
+    window / comb table -- see include/goldilocks_amd.h."""
     _check(lib().goldilocks_amd_set_table_access(int(mode)))
+
+
+def get_table_access():
+    return lib().goldilocks_amd_get_table_access()
 
 
 def device_info():

@@ -135,6 +135,9 @@ __device__ __forceinline__ void derive_body(uint8_t *pk, const uint8_t *sk, uint
         st.yn = fe_load(slot + 4);
         ed448_derive_finish(pk + 57 * (size_t)i, st, zi);
     });
+    // SHAKE256(sk) blocks and the recoded secret scalar do not stay behind in LDS
+    lds_wipe_lane(s_stage + threadIdx.x, 34);
+    lds_wipe_lane(s_bits + threadIdx.x, 15);
 }
 
 // "next" row f1: sig[i] = sign(sk[i], pk[i], msg[i])   (ref: goldilocks_ed448_sign)
@@ -152,9 +155,14 @@ __device__ __forceinline__ void sign_body(uint8_t *sig, const uint8_t *sk, const
     LdsMkBits mk{s_bits + threadIdx.x};
     uint8_t *scratch = reinterpret_cast<uint8_t *>(ws + (size_t)SIGN_SLOT_U4 * n) +
                        (size_t)(blockIdx.x * BLOCK + threadIdx.x) * 64;
-    auto message = [&](uint32_t i, const uint8_t *&msg, uint32_t &mlen) {
+    // -> false for a message the 32-bit byte counters cannot hold (GOLDILOCKS_AMD_MAX_MESSAGE_BYTES):
+    // the lane then signs the empty message and its signature is overwritten with zeros
+    auto message = [&](uint32_t i, const uint8_t *&msg, uint32_t &mlen) -> bool {
         msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
-        mlen = msg_offsets ? (uint32_t)(msg_offsets[i + 1] - msg_offsets[i]) : msg_len;
+        const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
+        const bool fits = len64 < MAX_MESSAGE_BYTES;
+        mlen = fits ? (uint32_t)len64 : 0u;
+        return fits;
     };
     InvChain ch;
     ch.begin();
@@ -193,13 +201,25 @@ __device__ __forceinline__ void sign_body(uint8_t *sig, const uint8_t *sk, const
         st.secret = sc_load_u4(slot + 20);
         const uint8_t *msg;
         uint32_t mlen;
-        message(i, msg, mlen);
+        const bool fits = message(i, msg, mlen);
         ed448_sign_finish(sig + 114 * (size_t)i, st, zi, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx, ctx_len, stage);
+        if (!fits)
+            for (int k = 0; k < 114; k++) sig[114 * (size_t)i + k] = 0;
         // the nonce and the secret scalar do not stay behind in the workspace
         const uint4 z4 = make_uint4(0, 0, 0, 0);
 #pragma unroll
         for (int k = 16; k < 24; k++) slot[k] = z4;
     });
+    // neither does the hashed-key seed (with a message it gives the nonce, with the nonce and a
+    // signature the secret scalar), nor the SHAKE256(sk) blocks and recoded scalars in LDS
+    {
+        uint4 *seed = reinterpret_cast<uint4 *>(scratch);
+        const uint4 z4 = make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) seed[k] = z4;
+    }
+    lds_wipe_lane(s_stage + threadIdx.x, 34);
+    lds_wipe_lane(s_bits + threadIdx.x, 15);
 }
 
 // "next" row f3: X448.  base == nullptr: derive_public_key through the fixed-base table
@@ -262,6 +282,7 @@ __device__ __forceinline__ void x448_body(uint8_t *shared, int32_t *status, cons
 #pragma unroll
         for (int k = 0; k < 4; k++) slot[k] = z4;
     });
+    lds_wipe_lane(s_bits + threadIdx.x, 15);   // nor the private scalar in LDS
 }
 
 }  // namespace gd

@@ -36,6 +36,7 @@ constexpr int PRECOMP_U4 = 80 * 20 + 64;  // uint4 per lane for k_precompute: 80
 // (fixed_bodies.hpp): numerator(s) | denominator | prefix product [| nonce | secret scalar]
 constexpr int DERIVE_SLOT_U4 = 16, SIGN_SLOT_U4 = 24, X448_SLOT_U4 = 12;
 constexpr int SHARED_INV_OPS_PER_LANE = 8;   // a launch covers at most this many operations per resident lane
+constexpr uint64_t MAX_MESSAGE_BYTES = 0x7fffff00ull;   // GOLDILOCKS_AMD_MAX_MESSAGE_BYTES: byte counters are 32-bit
 
 // ---------------------------------------------------------------- register <-> memory
 
@@ -166,38 +167,100 @@ __device__ __forceinline__ LdsBits lds_put_bits(uint32_t *slot, const sc &s) {
     slot[14 * BLOCK] = 0;
     return LdsBits{slot};
 }
+// Secret scalars do not stay behind in LDS when a kernel ends (the reference zeroizes its
+// temporaries, src/goldilocks.c:461-464): every lane clears its own slot(s).
+__device__ __forceinline__ void lds_wipe_lane(uint32_t *slot, int words) {
+#pragma unroll 1
+    for (int k = 0; k < words; k++) slot[k * BLOCK] = 0;
+}
 
-struct LaneTable {  // this lane's 16-entry window table in the HBM workspace
+__device__ __forceinline__ void pniels_store(uint4 *q, const pniels &e) {
+    fe_store(q, e.a);
+    fe_store(q + 4, e.b);
+    fe_store(q + 8, e.cn);
+    fe_store(q + 12, e.z);
+}
+__device__ __forceinline__ pniels pniels_load(const uint4 *q) {
+    pniels e;
+    e.a = fe_load(q);
+    e.b = fe_load(q + 4);
+    e.cn = fe_load(q + 8);
+    e.z = fe_load(q + 12);
+    return e;
+}
+struct LaneTable {  // this lane's window table in the HBM workspace, lane-contiguous; the digit picks the address
     uint4 *p;
-    __device__ __forceinline__ void store(int k, const pniels &e) const {
-        uint4 *q = p + 16 * k;
-        fe_store(q, e.a);
-        fe_store(q + 4, e.b);
-        fe_store(q + 8, e.cn);
-        fe_store(q + 12, e.z);
-    }
-    __device__ __forceinline__ pniels load(uint32_t k) const {
-        const uint4 *q = p + 16 * k;
-        pniels e;
-        e.a = fe_load(q);
-        e.b = fe_load(q + 4);
-        e.cn = fe_load(q + 8);
-        e.z = fe_load(q + 12);
-        return e;
-    }
+    __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
+    __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
+    __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
 };
-struct SharedTable {  // read-only 16-entry table shared by all lanes (base point)
+struct SharedTable {  // read-only 16-entry table shared by all lanes (base point; public scalars only)
     const uint4 *p;
-    __device__ __forceinline__ pniels load(uint32_t k) const {
-        const uint4 *q = p + 16 * k;
+    __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
+    __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
+};
+// The index-independent window table: the counterpart of the reference's constant_time_lookup
+// (src/include/constant_time.h:134-183, used at src/goldilocks.c:440): every lookup reads EVERY entry
+// and keeps the wanted one with v_cndmask, so neither the addresses issued nor the number of
+// transactions depend on the (secret) digit.  The table is private to a lane, so there is nothing for
+// a wavefront shuffle to share; instead the wave's 64 tables are interleaved [entry][uint4][lane] --
+// each of the ENTRIES x 16 loads of a scan is one fully coalesced 1-KiB row.  With W = 4 the
+// resident tables (8 x 256 B per lane) stay inside the 256-MiB Infinity Cache.
+template <int ENTRIES>
+struct ScanTable {
+    uint4 *p;   // the wave's region + lane: element (k, q) of this lane at p[(16 * k + q) * 64]
+    __device__ __forceinline__ void store(int k, const pniels &e) const {
+        uint4 *q = p + (size_t)(16 * k) * 64;
+        const fe *f[4] = {&e.a, &e.b, &e.cn, &e.z};
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const fe &a = *f[c];
+            q[(4 * c + 0) * 64] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
+            q[(4 * c + 1) * 64] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
+            q[(4 * c + 2) * 64] = make_uint4(a.v[8], a.v[9], a.v[10], a.v[11]);
+            q[(4 * c + 3) * 64] = make_uint4(a.v[12], a.v[13], a.v[14], a.v[15]);
+        }
+    }
+    __device__ __forceinline__ void load_raw(uint4 (&w)[16], int k) const {
+        const uint4 *q = p + (size_t)(16 * k) * 64;
+#pragma unroll
+        for (int i = 0; i < 16; i++) w[i] = q[i * 64];
+    }
+    __device__ __forceinline__ static pniels from_raw(const uint4 (&w)[16]) {
         pniels e;
-        e.a = fe_load(q);
-        e.b = fe_load(q + 4);
-        e.cn = fe_load(q + 8);
-        e.z = fe_load(q + 12);
+        e.a = fe_from_u4(w[0], w[1], w[2], w[3]);
+        e.b = fe_from_u4(w[4], w[5], w[6], w[7]);
+        e.cn = fe_from_u4(w[8], w[9], w[10], w[11]);
+        e.z = fe_from_u4(w[12], w[13], w[14], w[15]);
         return e;
     }
+    __device__ __forceinline__ pniels load(uint32_t k) const {   // table building only (k is public)
+        uint4 w[16];
+        load_raw(w, (int)k);
+        return from_raw(w);
+    }
+    __device__ __forceinline__ pniels lookup(uint32_t idx) const {
+        uint4 r[16];
+        load_raw(r, 0);
+#pragma unroll 1
+        for (int k = 1; k < ENTRIES; k++) {
+            uint4 w[16];
+            load_raw(w, k);
+            const bool take = idx == (uint32_t)k;
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                r[i].x = take ? w[i].x : r[i].x;
+                r[i].y = take ? w[i].y : r[i].y;
+                r[i].z = take ? w[i].z : r[i].z;
+                r[i].w = take ? w[i].w : r[i].w;
+            }
+        }
+        return from_raw(r);
+    }
 };
+// uint4 per WAVE of a scan table: (ENTRIES + 1 build slot) x 16 uint4 x 64 lanes
+template <int ENTRIES>
+constexpr int scan_table_wave_u4() { return (ENTRIES + 1) * 16 * 64; }
 // The comb staged in LDS and gathered with wavefront shuffles.  Entry e occupies words
 // [49e, 49e+48) (stride 49 keeps the fill reads below conflict-free).  For comb j every lane
 // first reads 12 words with a LANE-dependent, index-INDEPENDENT address: lane l takes words
@@ -271,20 +334,32 @@ struct LdsMkBits {
 };
 
 #define GD_KERNEL extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+// the index-independent variable-base kernels: resident blocks per CU chosen separately, because what
+// bounds them is how much table the resident lanes keep in the Infinity Cache
+#ifndef GD_CT_WAVES_PER_SIMD
+#define GD_CT_WAVES_PER_SIMD 2
+#endif
+constexpr int CT_WAVES_PER_SIMD = GD_CT_WAVES_PER_SIMD;
+#define GD_KERNEL_CT extern "C" __global__ void __launch_bounds__(BLOCK, CT_WAVES_PER_SIMD)
 
 // ---------------------------------------------------------------- kernel prototypes
 // Definitions live in kernels_{varbase,verify,fixed,misc}.hip (separate translation units so the
 // build compiles them in parallel); the host runtime (goldilocks_amd.hip) launches them.
-GD_KERNEL k_point_scalarmul(uint64_t *__restrict__ out, const uint64_t *__restrict__ base,
-                            const uint64_t *__restrict__ scalar, uint32_t n, uint4 *__restrict__ workspace);
+// (no __restrict__ on an output the host runtime aliases with an input: out/base, out/b2, out1/base, out/a)
+GD_KERNEL k_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar, uint32_t n,
+                            uint4 *__restrict__ workspace);
+GD_KERNEL_CT k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
+                                  uint32_t n, uint4 *__restrict__ workspace);
 GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ comb,
                                   const uint64_t *__restrict__ scalar, uint32_t n);
 GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ bwt,
                            const uint64_t *__restrict__ scalar, uint32_t n);
-GD_KERNEL k_double_scalarmul(uint64_t *__restrict__ out, const uint64_t *__restrict__ b1,
-                             const uint64_t *__restrict__ s1, const uint64_t *__restrict__ b2,
-                             const uint64_t *__restrict__ s2, uint32_t n, uint4 *__restrict__ workspace,
-                             const uint4 *__restrict__ base_tab);
+GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+                             const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
+                             uint4 *__restrict__ workspace, const uint4 *__restrict__ base_tab);
+GD_KERNEL_CT k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+                                   const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
+                                   uint4 *__restrict__ workspace);
 GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
                          const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                          const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
@@ -310,9 +385,16 @@ GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__
                              const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
                              int allow_identity, int short_circuit, uint4 *__restrict__ workspace,
                              const uint64_t *__restrict__ point_base_abi);
-GD_KERNEL k_point_dual_scalarmul(uint64_t *__restrict__ out1, uint64_t *__restrict__ out2,
-                                 const uint64_t *__restrict__ base, const uint64_t *__restrict__ s1,
-                                 const uint64_t *__restrict__ s2, uint32_t n, uint4 *__restrict__ workspace);
+GD_KERNEL_CT k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                                   const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
+                                   int allow_identity, int short_circuit, uint4 *__restrict__ workspace,
+                                   const uint64_t *__restrict__ point_base_abi);
+GD_KERNEL k_point_dual_scalarmul(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
+                                 const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
+                                 uint4 *__restrict__ workspace);
+GD_KERNEL_CT k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
+                                       const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
+                                       uint4 *__restrict__ workspace);
 GD_KERNEL k_point_from_hash(uint64_t *__restrict__ out, const uint8_t *__restrict__ hash, uint32_t n, int uniform);
 GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
                  const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt,
@@ -320,12 +402,12 @@ GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, con
 GD_KERNEL k_point_encode(uint8_t *__restrict__ ser, const uint64_t *__restrict__ pts, uint32_t n, int eddsa);
 GD_KERNEL k_point_decode(uint64_t *__restrict__ pts, int32_t *__restrict__ status,
                          const uint8_t *__restrict__ ser, uint32_t n, int eddsa, int allow_identity);
-GD_KERNEL k_point_op(uint64_t *__restrict__ out, const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+GD_KERNEL k_point_op(uint64_t *out, const uint64_t *a, const uint64_t *__restrict__ b,
                      uint32_t n, int op);
 GD_KERNEL k_point_pred(int32_t *__restrict__ status, const uint64_t *__restrict__ a,
                        const uint64_t *__restrict__ b, uint32_t n, int op);
 GD_KERNEL k_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, const uint64_t *__restrict__ a,
-                     const uint64_t *__restrict__ b, uint32_t n, int op);
+                     const uint64_t *__restrict__ b, uint32_t n, int op, uint32_t aux);
 GD_KERNEL k_import_comb(uint4 *__restrict__ dst, const uint64_t *__restrict__ src, uint32_t ntables);
 GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb);
 GD_KERNEL k_build_shared_table(uint4 *__restrict__ dst, const uint64_t *__restrict__ point);

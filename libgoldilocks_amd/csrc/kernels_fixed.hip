@@ -24,6 +24,10 @@ GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__res
         pt res = ladder_comb(bits, tab);
         wave_store_points(stage, out, i0, m, l, res);
     }
+    // the scalar may have been secret: neither its recoding nor its staged copy stays in LDS
+    lds_wipe_lane(s_bits + threadIdx.x, 15);
+    wave_sync();
+    for (int k = 0; k < WAVE_STAGE_U4 / 64; k++) stage[k * 64 + l] = make_uint4(0, 0, 0, 0);
 }
 
 // scaled[i] = scalar[i] * B for the built-in base point, through the window table

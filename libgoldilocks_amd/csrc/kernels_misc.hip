@@ -47,7 +47,7 @@ GD_KERNEL k_point_decode(uint64_t *__restrict__ pts, int32_t *__restrict__ statu
     }
 }
 
-GD_KERNEL k_point_op(uint64_t *__restrict__ out, const uint64_t *__restrict__ a, const uint64_t *__restrict__ b,
+GD_KERNEL k_point_op(uint64_t *out, const uint64_t *a, const uint64_t *__restrict__ b,
                      uint32_t n, int op) {
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
@@ -76,22 +76,82 @@ GD_KERNEL k_point_pred(int32_t *__restrict__ status, const uint64_t *__restrict_
     }
 }
 
+// Field-level operations for the parity tests, one element per lane:
+//   0 mul  1 sqr  2 isr (+mask)  3 strong_reduce (canonical limbs, stored raw)
+//   4 mulw (w = low 32 bits of b's limb 0; src/arch_ref64/f_impl.c:168-190)
+//   5 add, 6 sub: the reference's gf_add / gf_sub = RAW op (+ bias) + weak_reduce (src/field.h:40-55,
+//     arch_ref64/f_impl.h:10-38)          7 weak_reduce alone
+//   8 eq (mask), 9 lobit (mask)           (src/f_generic.c:107-131)
+//   10 serialize: 56 bytes in the first 7 words of out; 11 deserialize: a holds 56 bytes, status =
+//      "value < p" mask, out = limbs (src/f_generic.c:19-68)
+//   12 mul at magnitudes: (ma*a) * (mb*b) with the limb-wise multiples formed WITHOUT reduction
+//      (ma = aux & 0xff, mb = aux >> 8): the worst cases of the magnitude contract in gf28.hpp go
+//      through the device build of fe_mul this way;  13 sqr at magnitude ma
+// Inputs are loaded WITHOUT a weak pass for ops 5-7 so that unreduced limbs reach the device code as given.
+__device__ __forceinline__ fe fe_load_abi_raw(const uint64_t *p) {
+    uint64_t l[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) l[k] = p[k];
+    return fe_from_limbs56(l);
+}
+__device__ __forceinline__ void fe_store_limbs_raw(uint64_t *dst, const fe &r) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) dst[k] = (uint64_t)r.v[2 * k] + ((uint64_t)r.v[2 * k + 1] << 28);
+}
 GD_KERNEL k_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, const uint64_t *__restrict__ a,
-                     const uint64_t *__restrict__ b, uint32_t n, int op) {
+                     const uint64_t *__restrict__ b, uint32_t n, int op, uint32_t aux) {
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        fe x = fe_load_abi(a + 8 * (size_t)i), r;
+        const uint64_t *pa = a + 8 * (size_t)i, *pb = b ? b + 8 * (size_t)i : nullptr;
+        uint64_t *dst = out ? out + 8 * (size_t)i : nullptr;
         bool ok = true;
-        if (op == 0) r = fe_mul(x, fe_load_abi(b + 8 * (size_t)i));
-        else if (op == 1) r = fe_sqr(x);
-        else if (op == 2) r = fe_isr(x, &ok);
-        else r = fe_strong(x);
-        if (op == 3) {  // canonical limbs, no weak pass on store
-            uint64_t *dst = out + 8 * (size_t)i;
+        if (op <= 3) {
+            fe x = fe_load_abi(pa), r;
+            if (op == 0) r = fe_mul(x, fe_load_abi(pb));
+            else if (op == 1) r = fe_sqr(x);
+            else if (op == 2) r = fe_isr(x, &ok);
+            else r = fe_strong(x);
+            if (op == 3) fe_store_limbs_raw(dst, r);   // canonical limbs, no weak pass on store
+            else fe_store_abi(dst, r);
+        } else if (op == 4) {
+            fe_store_abi(dst, fe_mulw(fe_load_abi(pa), (uint32_t)pb[0]));
+        } else if (op == 5) {
+            fe_store_limbs_raw(dst, fe_weak(fe_add(fe_load_abi_raw(pa), fe_load_abi_raw(pb))));
+        } else if (op == 6) {
+            fe_store_limbs_raw(dst, fe_weak(fe_sub<2>(fe_load_abi_raw(pa), fe_weak(fe_load_abi_raw(pb)))));
+        } else if (op == 7) {
+            fe_store_limbs_raw(dst, fe_weak(fe_load_abi_raw(pa)));
+        } else if (op == 8) {
+            ok = fe_eq(fe_load_abi(pa), fe_load_abi(pb));
+        } else if (op == 9) {
+            ok = fe_lobit(fe_load_abi(pa));
+        } else if (op == 10) {
+            uint32_t w[14];
+            fe_serialize_words(w, fe_load_abi(pa));
 #pragma unroll
-            for (int k = 0; k < 8; k++) dst[k] = (uint64_t)r.v[2 * k] | (uint64_t)r.v[2 * k + 1] << 28;
+            for (int k = 0; k < 7; k++) dst[k] = (uint64_t)w[2 * k] | (uint64_t)w[2 * k + 1] << 32;
+            dst[7] = 0;
+        } else if (op == 11) {
+            uint32_t w[14];
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                w[2 * k] = (uint32_t)pa[k];
+                w[2 * k + 1] = (uint32_t)(pa[k] >> 32);
+            }
+            fe x;
+            ok = fe_deserialize_words(x, w);
+            fe_store_limbs_raw(dst, x);
         } else {
-            fe_store_abi(out + 8 * (size_t)i, r);
+            const int ma = (int)(aux & 0xff), mb = (int)(aux >> 8);
+            fe x = fe_load_abi(pa), xs = fe_zero();
+            for (int k = 0; k < ma; k++) xs = fe_add(xs, x);
+            if (op == 12) {
+                fe y = fe_load_abi(pb), ys = fe_zero();
+                for (int k = 0; k < mb; k++) ys = fe_add(ys, y);
+                fe_store_abi(dst, fe_mul(xs, ys));
+            } else {
+                fe_store_abi(dst, fe_sqr(xs));
+            }
         }
         if (status) status[i] = ok ? -1 : 0;
     }

@@ -1,32 +1,13 @@
 // kernels_verify.hip -- kernel definitions (see kernels.hpp for the memory plan and policies).
-#include "kernels.hpp"
+#include "varbase_bodies.hpp"
 
 namespace gd {
 
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i]; b1 == nullptr: b1 is the base point (shared table)
-GD_KERNEL k_double_scalarmul(uint64_t *__restrict__ out, const uint64_t *__restrict__ b1,
-                             const uint64_t *__restrict__ s1, const uint64_t *__restrict__ b2,
-                             const uint64_t *__restrict__ s2, uint32_t n, uint4 *__restrict__ workspace,
-                             const uint4 *__restrict__ base_tab) {
-    __shared__ uint32_t s_bits[30 * BLOCK];
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    LaneTable t2{workspace + (size_t)lane * 2 * TABLE_U4};
-    LaneTable t1{workspace + (size_t)lane * 2 * TABLE_U4 + TABLE_U4};
-    for (uint32_t i = lane; i < n; i += stride) {
-        LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(s1 + 7 * (size_t)i)));
-        LdsBits bits2 =
-            lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_signed(sc_load_abi(s2 + 7 * (size_t)i)));
-        build_window_table(t2, pt_load_abi(b2 + 32 * (size_t)i));
-        pt r;
-        if (b1) {  // uniform
-            build_window_table(t1, pt_load_abi(b1 + 32 * (size_t)i));
-            r = ladder_double(bits1, t1, bits2, t2);
-        } else {
-            r = ladder_double(bits1, SharedTable{base_tab}, bits2, t2);
-        }
-        pt_store_abi(out + 32 * (size_t)i, r);
-    }
+GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+                             const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
+                             uint4 *__restrict__ workspace, const uint4 *__restrict__ base_tab) {
+    double_scalarmul_body<false>(out, b1, s1, b2, s2, n, workspace, base_tab);
 }
 
 // config 4: status[i] = ed448_verify(sig[i], pk[i], msg[i])   (ref: goldilocks_ed448_verify)
@@ -46,11 +27,13 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
     LdsMkBits mk{s_bits + threadIdx.x};
     for (uint32_t i = lane; i < n; i += stride) {
         const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
-        const uint32_t mlen = msg_offsets ? (uint32_t)(msg_offsets[i + 1] - msg_offsets[i]) : msg_len;
+        const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
+        const bool fits = len64 < MAX_MESSAGE_BYTES;   // longer than the 32-bit byte counters hold: the lane fails
+        const uint32_t mlen = fits ? (uint32_t)len64 : 0u;
         Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx,
                                             ctx_len);
         bool ok = ed448_verify_core(m, b_tab, a_tab, stage, mk);
-        status[i] = ok ? -1 : 0;
+        status[i] = ok && fits ? -1 : 0;
     }
 }
 

@@ -11,74 +11,105 @@
 // (a) instantiated by the HIP kernels with HBM/LDS-backed storage and (b) run on
 // the host by tests/hostsim with plain arrays (checker only, never shipped):
 //   BITS  : bits.word(k) -> k-th 32-bit word of s' (k < 15, word 14 is zero)
-//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table (17 slots:
-//           16 entries + one scratch slot used while the table is built)
+//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table (ENTRIES + 1 slots:
+//           the entries + one scratch slot used while the table is built); table.lookup(idx) is the
+//           read of a digit's entry -- direct, or index-independent (a scan of every entry)
 #pragma once
 #include "point.hpp"
 #include "sc14.hpp"
 
 namespace gd {
 
-// 5-bit window of s' whose least significant bit is bit `pos` (pos <= 445).
-template <class BITS>
-GD_FN uint32_t window5(const BITS &bits, int pos) {
+// W-bit window of s' whose least significant bit is bit `pos` (pos + W <= 450).
+template <int W, class BITS>
+GD_FN uint32_t window_w(const BITS &bits, int pos) {
     const int k = pos >> 5, sh = pos & 31;
     uint32_t lo = bits.word(k) >> sh;
-    uint32_t hi = sh > 27 ? bits.word(k + 1) << (32 - sh) : 0u;  // sh > 27: window straddles
-    return (lo | hi) & 31u;
+    uint32_t hi = sh > 32 - W ? bits.word(k + 1) << (32 - sh) : 0u;  // the window straddles two words
+    return (lo | hi) & ((1u << W) - 1);
 }
+template <class BITS>
+GD_FN uint32_t window5(const BITS &bits, int pos) { return window_w<5>(bits, pos); }
 
-// digit w -> (table index, negate): index (w^inv)&15 with inv = (w>>4)-1; entry
-// holds (2*idx+1)*B; negate iff w < 16  (src/goldilocks.c:437-442).
-GD_FN void signed_digit(uint32_t w, uint32_t &idx, bool &neg) {
-    neg = w < 16;
-    idx = (neg ? ~w : w) & 15u;
+// digit w -> (table index, negate): index (w^inv)&(2^(W-1)-1) with inv = (w>>(W-1))-1; the entry
+// holds (2*idx+1)*B; negate iff w < 2^(W-1)  (src/goldilocks.c:437-442 with W = 5).
+template <int W>
+GD_FN void signed_digit_w(uint32_t w, uint32_t &idx, bool &neg) {
+    neg = w < (1u << (W - 1));
+    idx = (neg ? ~w : w) & ((1u << (W - 1)) - 1);
 }
+GD_FN void signed_digit(uint32_t w, uint32_t &idx, bool &neg) { signed_digit_w<5>(w, idx, neg); }
 
-// multiples[k] = (2k+1)*B, k < 16, as projective niels (src/goldilocks.c:382-403).
-// The step 2B is parked in slot 16 of the lane's table memory and re-read every iteration, as the
+// The variable-base ladder comes in two widths.  W = 5 is the reference's (90 windows, 16 table
+// entries, src/goldilocks.c:405-465).  W = 4 (112 windows, 8 entries) costs 22 more additions and
+// saves 8 table entries -- about 4 % more field multiplications -- but halves the table, which is
+// what the index-independent lookup (every entry read for every digit, constant_time.h:134-183)
+// pays for: see ScanTable in kernels.hpp.  Both walk s' = (s + 2^(W*NW) - 1)/2 mod q.
+template <int W>
+struct window_plan {
+    static_assert(W == 4 || W == 5, "recoding constants exist for 4- and 5-bit windows");
+    static constexpr int ENTRIES = 1 << (W - 1);
+    static constexpr int WINDOWS = (446 + W - 1) / W;            // 112 or 90
+    static constexpr int TOP = W * (WINDOWS - 1);                 // 444 or 445
+};
+template <int W>
+GD_FN sc sc_recode_window(const sc &s) { return W == 5 ? sc_recode_signed(s) : sc_recode_signed8(s); }
+
+// multiples[k] = (2k+1)*B, k < 2^(W-1), as projective niels (src/goldilocks.c:382-403).
+// The step 2B is parked in the lane's table memory (slot ENTRIES) and re-read every iteration, as the
 // ladder re-reads its entries: holding it in registers next to the accumulator spills.
-template <class TABLE>
-GD_FN void build_window_table(TABLE &table, const pt &b) {
+template <int W, class TABLE>
+GD_FN void build_window_table_w(TABLE &table, const pt &b) {
+    constexpr int E = window_plan<W>::ENTRIES;
     pt twice = b;
     pt_double(twice, true);
-    table.store(16, pt_to_pniels(twice));
+    table.store(E, pt_to_pniels(twice));
     table.store(0, pt_to_pniels(b));
     pt acc = b;
 #pragma unroll 1
-    for (int k = 1; k < 16; k++) {
-        pt_add_pniels(acc, table.load(16), false, true);
+    for (int k = 1; k < E; k++) {
+        pt_add_pniels(acc, table.load(E), false, true);
         table.store(k, pt_to_pniels(acc));
     }
 }
+template <class TABLE>
+GD_FN void build_window_table(TABLE &table, const pt &b) { build_window_table_w<5>(table, b); }
 
 // out = s * B with the window table already built and s' readable through `bits`.
-template <class BITS, class TABLE>
-GD_FN pt ladder_varbase(const BITS &bits, const TABLE &table) {
+// table.lookup(idx) is the digit's entry: a direct read for public digits, a scan of the whole
+// table for secret ones (the policy decides).
+template <int W, class BITS, class TABLE>
+GD_FN pt ladder_varbase_w(const BITS &bits, const TABLE &table) {
     uint32_t idx;
     bool neg;
-    signed_digit(window5(bits, 445), idx, neg);
-    pt acc = pniels_to_pt(table.load(idx), neg);
+    signed_digit_w<W>(window_w<W>(bits, window_plan<W>::TOP), idx, neg);
+    pt acc = pniels_to_pt(table.lookup(idx), neg);
 #pragma unroll 1
-    for (int pos = 440; pos >= 0; pos -= 5) {
-        signed_digit(window5(bits, pos), idx, neg);
+    for (int pos = window_plan<W>::TOP - W; pos >= 0; pos -= W) {
+        signed_digit_w<W>(window_w<W>(bits, pos), idx, neg);
 #pragma unroll 1
-        for (int j = 0; j < 5; j++) pt_double(acc, j == 4);
-        pniels e = table.load(idx);
+        for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
+        pniels e = table.lookup(idx);
         // T is only needed by a following addition, i.e. never after the last window's
         // add -- except that the caller wants a complete extended point at pos == 0.
         pt_add_pniels(acc, e, neg, pos == 0);
     }
     return acc;
 }
+template <class BITS, class TABLE>
+GD_FN pt ladder_varbase(const BITS &bits, const TABLE &table) { return ladder_varbase_w<5>(bits, table); }
 
 // (s1*B, s2*B) for one base: the window table is built once and walked twice ("next" row f4;
 // the reference's point_dual_scalarmul, src/goldilocks.c:543-642, gets there with a bucket
 // method -- same two group elements).
+template <int W, class BITS, class TABLE>
+GD_FN void ladder_dual_w(pt &out1, pt &out2, const BITS &bits1, const BITS &bits2, const TABLE &table) {
+    out1 = ladder_varbase_w<W>(bits1, table);
+    out2 = ladder_varbase_w<W>(bits2, table);
+}
 template <class BITS, class TABLE>
 GD_FN void ladder_dual(pt &out1, pt &out2, const BITS &bits1, const BITS &bits2, const TABLE &table) {
-    out1 = ladder_varbase(bits1, table);
-    out2 = ladder_varbase(bits2, table);
+    ladder_dual_w<5>(out1, out2, bits1, bits2, table);
 }
 
 // Comb: 18 rounds; round i adds, for each of the 5 combs j, the entry selected by
@@ -180,25 +211,29 @@ struct FixedBwt {
     }
 };
 
-// out = s1*P1 + s2*P2, both through 16-entry window tables (src/goldilocks.c:467-541).
-template <class BITS, class TABLE1, class TABLE2>
-GD_FN pt ladder_double(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2) {
+// out = s1*P1 + s2*P2, both through window tables of width W (src/goldilocks.c:467-541 with W = 5).
+template <int W, class BITS, class TABLE1, class TABLE2>
+GD_FN pt ladder_double_w(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2) {
     uint32_t idx;
     bool neg;
-    signed_digit(window5(bits1, 445), idx, neg);
-    pt acc = pniels_to_pt(t1.load(idx), neg);
-    signed_digit(window5(bits2, 445), idx, neg);
-    pt_add_pniels(acc, t2.load(idx), neg, false);
+    signed_digit_w<W>(window_w<W>(bits1, window_plan<W>::TOP), idx, neg);
+    pt acc = pniels_to_pt(t1.lookup(idx), neg);
+    signed_digit_w<W>(window_w<W>(bits2, window_plan<W>::TOP), idx, neg);
+    pt_add_pniels(acc, t2.lookup(idx), neg, false);
 #pragma unroll 1
-    for (int pos = 440; pos >= 0; pos -= 5) {
+    for (int pos = window_plan<W>::TOP - W; pos >= 0; pos -= W) {
 #pragma unroll 1
-        for (int j = 0; j < 5; j++) pt_double(acc, j == 4);
-        signed_digit(window5(bits1, pos), idx, neg);
-        pt_add_pniels(acc, t1.load(idx), neg, true);
-        signed_digit(window5(bits2, pos), idx, neg);
-        pt_add_pniels(acc, t2.load(idx), neg, pos == 0);
+        for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
+        signed_digit_w<W>(window_w<W>(bits1, pos), idx, neg);
+        pt_add_pniels(acc, t1.lookup(idx), neg, true);
+        signed_digit_w<W>(window_w<W>(bits2, pos), idx, neg);
+        pt_add_pniels(acc, t2.lookup(idx), neg, pos == 0);
     }
     return acc;
+}
+template <class BITS, class TABLE1, class TABLE2>
+GD_FN pt ladder_double(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2) {
+    return ladder_double_w<5>(bits1, t1, bits2, t2);
 }
 
 }  // namespace gd

@@ -1,0 +1,164 @@
+// varbase_bodies.hpp -- bodies of the kernels that multiply a caller's point by a scalar, as
+// templates on the table-access policy; instantiated by kernels_varbase.hip / kernels_verify.hip
+// (CT = false: the digit picks the address of its entry in the lane's table, 5-bit windows) and
+// kernels_varbase_ct.hip (CT = true: every lookup scans the whole table, 4-bit windows; the
+// counterpart of the reference's constant_time_lookup, src/include/constant_time.h:134-183, which
+// goldilocks_448_point_scalarmul / _double_scalarmul / _dual_scalarmul / direct_scalarmul all use,
+// src/goldilocks.c:437-442, :500-520, :590-610).
+#pragma once
+#include "kernels.hpp"
+
+namespace gd {
+
+template <bool CT>
+struct VarTable;
+template <>
+struct VarTable<false> {
+    static constexpr int W = 5;
+    using type = LaneTable;
+    // table `which` of `ntab` tables of this lane
+    static __device__ __forceinline__ type at(uint4 *ws, int which, int ntab) {
+        const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+        return type{ws + ((size_t)lane * ntab + which) * TABLE_U4};
+    }
+};
+template <>
+struct VarTable<true> {
+    static constexpr int W = 4;
+    static constexpr int ENTRIES = window_plan<W>::ENTRIES;
+    using type = ScanTable<ENTRIES>;
+    static __device__ __forceinline__ type at(uint4 *ws, int which, int ntab) {
+        const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
+        return type{ws + ((size_t)wave * ntab + which) * scan_table_wave_u4<ENTRIES>() + (threadIdx.x & 63u)};
+    }
+};
+// uint4 of workspace per resident lane and table
+template <bool CT>
+constexpr int var_table_lane_u4() { return CT ? scan_table_wave_u4<VarTable<true>::ENTRIES>() / 64 : TABLE_U4; }
+
+// config 2: scaled[i] = scalar[i] * base[i]   (ref: goldilocks_448_point_scalarmul)
+// out may alias base (the host-array path multiplies in place): no __restrict__ on that pair.
+template <bool CT>
+__device__ __forceinline__ void point_scalarmul_body(uint64_t *out, const uint64_t *base,
+                                                     const uint64_t *__restrict__ scalar, uint32_t n,
+                                                     uint4 *__restrict__ workspace) {
+    constexpr int W = VarTable<CT>::W;
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint4 s_stage[(BLOCK / 64) * WAVE_STAGE_U4];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t l = threadIdx.x & 63u;
+    uint4 *stage = s_stage + (threadIdx.x >> 6) * WAVE_STAGE_U4;
+    auto tab = VarTable<CT>::at(workspace, 0, 1);
+    // wave-uniform loop: the 64 lanes of a wave own 64 consecutive operations per round
+    for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {
+        const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
+        pt b = wave_load_points(stage, base, i0, m, l);
+        const sc k = wave_load_scalars(stage, scalar, i0, m, l);
+        pt r = b;
+        if (l < m) {
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(k));
+            build_window_table_w<W>(tab, b);
+            r = ladder_varbase_w<W>(bits, tab);
+        }
+        wave_store_points(stage, out, i0, m, l, r);
+    }
+    if (CT) {   // the scalar was secret: neither its recoding nor its staged copy stays in LDS
+        lds_wipe_lane(s_bits + threadIdx.x, 15);
+        wave_sync();
+        for (int k = 0; k < WAVE_STAGE_U4 / 64; k++) stage[k * 64 + l] = make_uint4(0, 0, 0, 0);
+    }
+}
+
+// "next" row f2: wire-format scalarmul, 56 bytes in / 56 bytes out   (ref: goldilocks_448_direct_scalarmul)
+template <bool CT>
+__device__ __forceinline__ void direct_scalarmul_body(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                                                      const uint8_t *__restrict__ base,
+                                                      const uint64_t *__restrict__ scalar, uint32_t n,
+                                                      int allow_identity, int short_circuit,
+                                                      uint4 *__restrict__ workspace,
+                                                      const uint64_t *__restrict__ point_base_abi) {
+    constexpr int W = VarTable<CT>::W;
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    auto tab = VarTable<CT>::at(workspace, 0, 1);
+    for (uint32_t i = lane; i < n; i += stride) {
+        uint32_t w[14];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(base + 56 * (size_t)i);
+#pragma unroll
+        for (int k = 0; k < 14; k++) w[k] = src[k];
+        pt b;
+        bool ok = pt_decode_words(b, w, allow_identity != 0);
+        status[i] = ok ? -1 : 0;
+        if (!ok && short_circuit) continue;         // the encoding is public: so is this branch
+        if (!ok) b = pt_load_abi(point_base_abi);   // src/goldilocks.c:898: multiply the base point instead
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(sc_load_abi(scalar + 7 * (size_t)i)));
+        build_window_table_w<W>(tab, b);
+        pt r = ladder_varbase_w<W>(bits, tab);
+        pt_encode_words(w, r);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(scaled + 56 * (size_t)i);
+#pragma unroll
+        for (int k = 0; k < 14; k++) dst[k] = w[k];
+    }
+    if (CT) lds_wipe_lane(s_bits + threadIdx.x, 15);
+}
+
+// "next" row f4: (s1*B, s2*B) for one base   (ref: goldilocks_448_point_dual_scalarmul)
+// out1 may alias base.
+template <bool CT>
+__device__ __forceinline__ void point_dual_scalarmul_body(uint64_t *out1, uint64_t *__restrict__ out2,
+                                                          const uint64_t *base, const uint64_t *__restrict__ s1,
+                                                          const uint64_t *__restrict__ s2, uint32_t n,
+                                                          uint4 *__restrict__ workspace) {
+    constexpr int W = VarTable<CT>::W;
+    __shared__ uint32_t s_bits[30 * BLOCK];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    auto tab = VarTable<CT>::at(workspace, 0, 1);
+    for (uint32_t i = lane; i < n; i += stride) {
+        LdsBits b1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(sc_load_abi(s1 + 7 * (size_t)i)));
+        LdsBits b2 = lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_window<W>(sc_load_abi(s2 + 7 * (size_t)i)));
+        build_window_table_w<W>(tab, pt_load_abi(base + 32 * (size_t)i));
+        pt r1, r2;
+        ladder_dual_w<W>(r1, r2, b1, b2, tab);
+        pt_store_abi(out1 + 32 * (size_t)i, r1);
+        pt_store_abi(out2 + 32 * (size_t)i, r2);
+    }
+    if (CT) lds_wipe_lane(s_bits + threadIdx.x, 30);
+}
+
+// combo[i] = s1[i]*b1[i] + s2[i]*b2[i]   (ref: goldilocks_448_point_double_scalarmul, constant time there:
+// src/goldilocks.c:467-541).  b1 == nullptr (CT = false only): b1 is the base point through the shared
+// table -- goldilocks_448_base_double_scalarmul_non_secret, public scalars by contract.
+// out may alias b2.
+template <bool CT>
+__device__ __forceinline__ void double_scalarmul_body(uint64_t *out, const uint64_t *__restrict__ b1,
+                                                      const uint64_t *__restrict__ s1, const uint64_t *b2,
+                                                      const uint64_t *__restrict__ s2, uint32_t n,
+                                                      uint4 *__restrict__ workspace,
+                                                      const uint4 *__restrict__ base_tab) {
+    constexpr int W = VarTable<CT>::W;
+    __shared__ uint32_t s_bits[30 * BLOCK];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    auto t2 = VarTable<CT>::at(workspace, 0, 2);
+    auto t1 = VarTable<CT>::at(workspace, 1, 2);
+    for (uint32_t i = lane; i < n; i += stride) {
+        LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(sc_load_abi(s1 + 7 * (size_t)i)));
+        LdsBits bits2 =
+            lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_window<W>(sc_load_abi(s2 + 7 * (size_t)i)));
+        build_window_table_w<W>(t2, pt_load_abi(b2 + 32 * (size_t)i));
+        pt r;
+        if (CT || b1) {  // uniform
+            build_window_table_w<W>(t1, pt_load_abi(b1 + 32 * (size_t)i));
+            r = ladder_double_w<W>(bits1, t1, bits2, t2);
+        } else {
+            if constexpr (!CT) r = ladder_double_w<W>(bits1, SharedTable{base_tab}, bits2, t2);
+        }
+        pt_store_abi(out + 32 * (size_t)i, r);
+    }
+    if (CT) lds_wipe_lane(s_bits + threadIdx.x, 30);
+}
+
+}  // namespace gd

@@ -1,11 +1,28 @@
-"""Sharding of independent Ed448 operations over the GPUs of one node.
+"""Multi-GPU plumbing of the batch engine: one process per GPU, no collective on the data path.
 
-The path shards embarrassingly: operation i of a batch of n belongs to
-exactly one rank, no data-path collective.  Two layouts are used:
-  * strong: one global batch, contiguous slices  [g*n/G, (g+1)*n/G)   (shard_range)
-  * weak:   every rank owns its own batch of the same size (bench.py, per-GPU throughput)
-The only collectives are control-plane: a barrier around the timed region, MAX of the elapsed
-time and SUM of per-rank counters (accepted signatures, processed ops)."""
+The path shards embarrassingly: operation i of a batch belongs to exactly
+one rank and the devices never exchange data.  Two layouts:
+  * weak:   every rank owns its own batch of the same size            (bench.py default)
+  * strong: one global batch, contiguous slices [g*n/G, (g+1)*n/G)    (shard_range; BASELINE
+            config 5: 2^24 verifications over 8 GPUs = 2^21 per GPU)
+The only collectives are control-plane: the barrier around the timed region, MAX of the elapsed
+time and an all-gather of per-rank figures.
+
+bench.py uses everything in this file:
+  launch_ranks()   `python bench.py --gpus N` without a launcher: start N fresh children, one per
+                   rank, BEFORE anything in this process has touched a GPU (this module imports
+                   neither torch nor HIP at module level; a process that has initialised the GPU
+                   must never re-exec, and this one never initialises it at all)
+  init_group()     the process group of a rank: RCCL ("nccl") when every rank has a GPU of its own,
+                   gloo when ranks have to share a device (2 ranks on a 1-GPU box) or run without one
+  timed_region()   W untimed steps, barrier + sync, K timed steps, barrier + sync
+  max_over_ranks / sum_over_ranks / gather_over_ranks
+"""
+import os
+import socket
+import subprocess
+import sys
+import time
 
 
 def shard_range(n, rank, world):
@@ -15,21 +32,133 @@ def shard_range(n, rank, world):
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
-def max_over_ranks(value, dist=None, device=None):
+def device_for_rank(local_rank, visible_devices):
+    """Ranks map onto the visible devices modulo their count (so a 1-GPU box can run a 2-rank job)."""
+    if visible_devices < 1:
+        raise ValueError("no visible device")
+    return local_rank % visible_devices
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def rank_env(rank, world, port, base=None):
+    env = dict(os.environ if base is None else base)
+    env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+               MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool (RCCL needs it)
+    return env
+
+
+def launch_ranks(argv, world, timeout=None):
+    """Run `python argv...` once per rank (fresh processes, rendezvous on 127.0.0.1) and return the
+    largest exit code.  Rank 0's stdout is this process's stdout (the one JSON line); the other
+    ranks' stdout goes to stderr.  Nothing here touches a GPU."""
+    port = free_port()
+    procs = []
+    for rank in range(world):
+        out = None if rank == 0 else sys.stderr
+        procs.append(subprocess.Popen([sys.executable] + list(argv), env=rank_env(rank, world, port), stdout=out))
+    deadline = None if timeout is None else time.time() + timeout
+    code = 0
+    try:
+        for p in procs:
+            left = None if deadline is None else max(1.0, deadline - time.time())
+            rc = p.wait(timeout=left)
+            code = max(code, abs(rc))
+    except subprocess.TimeoutExpired:
+        code = 124
+    finally:
+        for p in procs:           # exactly the children started here, by pid
+            if p.poll() is None:
+                p.kill()
+                p.wait()
+    return code
+
+
+def init_group(world, rank, visible_devices, use_gpu=True):
+    """torch.distributed process group for this rank, or None when world == 1.  Returns (dist, backend)."""
+    if world <= 1:
+        return None, None
+    import torch
+    import torch.distributed as dist
+    own_device = use_gpu and visible_devices >= world
+    backend = "nccl" if own_device else "gloo"
+    os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's banner off stdout: one JSON line only
+    kw = {}
+    if backend == "nccl":
+        kw["device_id"] = torch.device("cuda", device_for_rank(rank, visible_devices))
+    # gloo and RCCL print banners on the C-level stdout; rank 0's stdout carries ONE JSON line only
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+        dist.barrier()                                   # connections are made (and announced) lazily
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
+    return dist, backend
+
+
+def _reduce(value, op_name, dist, backend, dtype_name):
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    import torch
+    dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=getattr(torch, dtype_name), device=dev)
+    dist.all_reduce(t, op=getattr(dist.ReduceOp, op_name))
+    return t.item()
+
+
+def max_over_ranks(value, dist=None, backend="gloo"):
     """MAX-reduce a python float over the process group (identity without one)."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return float(value)
-    import torch
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    return float(_reduce(float(value), "MAX", dist, backend, "float64"))
 
 
-def sum_over_ranks(value, dist=None, device=None):
+def sum_over_ranks(value, dist=None, backend="gloo"):
     """SUM-reduce a python int over the process group (identity without one)."""
+    return int(_reduce(int(value), "SUM", dist, backend, "int64"))
+
+
+def gather_over_ranks(values, dist=None, backend="gloo"):
+    """All-gather a short list of python floats; returns one list per rank, in rank order."""
+    vals = [float(v) for v in values]
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
-        return int(value)
+        return [vals]
     import torch
-    t = torch.tensor([int(value)], dtype=torch.int64, device=device or "cpu")
-    dist.all_reduce(t, op=dist.ReduceOp.SUM)
-    return int(t.item())
+    dev = "cuda" if backend == "nccl" else "cpu"
+    mine = torch.tensor(vals, dtype=torch.float64, device=dev)
+    out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [[float(x) for x in t.cpu().tolist()] for t in out]
+
+
+def timed_region(step, steps, warmup, sync, dist=None, backend="gloo", after_step=None):
+    """The driver's timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by
+    barrier + device sync on both sides.  Returns this rank's seconds and the MAX over ranks.
+    after_step(i) runs inside the loop right after step i was enqueued (event records)."""
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        sync()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    if after_step:
+        after_step(-1)
+    for i in range(steps):
+        step()
+        if after_step:
+            after_step(i)
+    sync()
+    mine = time.perf_counter() - t0
+    barrier()
+    return mine, max_over_ranks(mine, dist, backend)

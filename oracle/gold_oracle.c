@@ -1307,3 +1307,31 @@ void orc_extern_scalarmul_batch(ext_scalarmul_fn fn, orc_point *out, const orc_p
     struct ext_args a = {fn, out, base, s};
     run_ranges(ext_range, &a, n, nt);
 }
+
+/* Timing harness in the shape of the reference's Benchmark class (test/bench_goldilocks.cxx:73-143;
+ * the "Point scalarmul" line is :190): nsamples samples of ntests back-to-back calls each, wall
+ * clock per sample written to times[] (seconds).  The caller sorts, drops DISCARD low and high
+ * samples and takes the mean, as the destructor there does (:94-116).  One thread; the inputs cycle
+ * over n_in (point, scalar) pairs so that the loop is not a single cached operand pair. */
+#include <time.h>
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void orc_bench_extern_scalarmul(ext_scalarmul_fn fn, const orc_point *base, const orc_scalar *s, size_t n_in,
+                                int nsamples, int ntests, double *times) {
+    orc_point out;
+    size_t k = 0;
+    double begin = now_s();
+    for (int j = 0; j < nsamples; j++) {
+        for (int i = 0; i < ntests; i++) {
+            if (fn) fn(&out, &base[k], &s[k]);
+            else orc_point_scalarmul(&out, &base[k], &s[k]);
+            if (++k == n_in) k = 0;
+        }
+        double t = now_s();
+        times[j] = t - begin;
+        begin = t;
+    }
+}

@@ -116,6 +116,10 @@ ORC_API void orc_precomputed_scalarmul_batch(orc_point *out, const orc_precomput
 /* times an external (e.g. the real reference's) scalarmul function over a batch */
 ORC_API void orc_extern_scalarmul_batch(void (*fn)(void *, const void *, const void *), orc_point *out,
                                         const orc_point *base, const orc_scalar *s, size_t n, int nthreads);
+/* reference-style timing (test/bench_goldilocks.cxx:73-143): nsamples x ntests calls, one thread;
+ * fn == NULL times the oracle's own orc_point_scalarmul */
+ORC_API void orc_bench_extern_scalarmul(void (*fn)(void *, const void *, const void *), const orc_point *base,
+                                        const orc_scalar *s, size_t n_in, int nsamples, int ntests, double *times);
 ORC_API void orc_point_encode_batch(uint8_t *out56, const orc_point *p, size_t n, int nthreads);
 /* msgs: n fixed-length messages of msglen bytes each, contiguous. status[i] = -1/0 */
 ORC_API void orc_ed448_verify_batch(int32_t *status, const uint8_t *sig114, const uint8_t *pk57,

@@ -131,6 +131,7 @@ def oracle():
         "orc_precomputed_scalarmul_batch": (None, [vp, vp, vp, C.c_size_t, C.c_int]),
         "orc_point_encode_batch": (None, [vp, vp, C.c_size_t, C.c_int]),
         "orc_extern_scalarmul_batch": (None, [vp, vp, vp, vp, C.c_size_t, C.c_int]),
+        "orc_bench_extern_scalarmul": (None, [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp]),
         "orc_ed448_verify_batch": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8,
                                           C.c_size_t, C.c_int]),
         "orc_ed448_sign_batch": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8,

@@ -31,6 +31,7 @@ struct HostTable {
     pniels e[17];
     void store(int k, const pniels &p) { e[k] = p; }
     pniels load(uint32_t k) const { return e[k]; }
+    pniels lookup(uint32_t k) const { return e[k]; }
 };
 struct HostComb {
     niels e[80];

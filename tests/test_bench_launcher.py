@@ -1,0 +1,78 @@
+"""bench.py's N > 1 path, without a GPU: `python bench.py --gpus 2` must start its own ranks (the
+driver runs it exactly like that), print ONE JSON line with the aggregate and the per-GPU figures,
+and never import torch in the launching process (a process that touched the GPU may not re-exec;
+this one never touches it).  The step is a stub (--stub-step-ms): what is under test is
+libgoldilocks_amd/shard.py -- launcher, process group, barrier-bracketed timing, MAX over ranks,
+all-gather of per-rank rows -- the same code the GPU ranks run."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def _check_line(out, world, step_ms, steps):
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == world and line["steps"] == steps and line["scaling"] == "weak"
+    assert [g["rank"] for g in line["per_gpu"]] == list(range(world))
+    # rank r sleeps (1 + r) * step_ms per step: the job's time is the slowest rank's (MAX over ranks)
+    assert line["ms_per_step"] >= world * step_ms * 0.95
+    slowest = min(g["value"] for g in line["per_gpu"])
+    assert line["value"] == pytest.approx(world * slowest, rel=0.05)
+    return line
+
+
+def test_plain_invocation_launches_its_own_ranks():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-step-ms", "20",
+                        "--log2-batch", "10"], env=_env(), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    _check_line(r.stdout, 2, 20, 3)
+    launcher = [json.loads(l) for l in r.stderr.splitlines() if l.startswith('{"launcher"')]
+    assert launcher and launcher[0]["launcher"]["ranks"] == 2
+    assert launcher[0]["launcher"]["torch_imported_by_launcher"] is False
+
+
+def test_under_torch_distributed_run():
+    from libgoldilocks_amd.shard import free_port
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(free_port()), BENCH, "--gpus", "2",
+                        "--steps", "2", "--warmup", "1", "--stub-step-ms", "20"], env=_env(), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    _check_line(r.stdout, 2, 20, 2)
+
+
+def test_failing_rank_fails_the_launch():
+    from libgoldilocks_amd import shard
+    code = shard.launch_ranks(["-c", "import os, sys; sys.exit(3 if os.environ['RANK'] == '1' else 0)"], 2, timeout=60)
+    assert code == 3
+
+
+def test_shard_module_is_torch_free_at_import():
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import libgoldilocks_amd.shard; "
+                        "print(any(m.split('.')[0] == 'torch' for m in sys.modules))" % ROOT],
+                       capture_output=True, text=True, timeout=120)
+    assert r.stdout.strip() == "False", r.stdout + r.stderr
+
+
+def test_rank_to_device_mapping_and_strong_slices():
+    from libgoldilocks_amd.shard import device_for_rank, shard_range
+    assert [device_for_rank(r, 1) for r in range(4)] == [0, 0, 0, 0]
+    assert [device_for_rank(r, 8) for r in range(8)] == list(range(8))
+    with pytest.raises(ValueError):
+        device_for_rank(0, 0)
+    # BASELINE config 5: 2^24 verifications over 8 GPUs = 2^21 each
+    assert [shard_range(1 << 24, r, 8)[1] - shard_range(1 << 24, r, 8)[0] for r in range(8)] == [1 << 21] * 8

@@ -1,0 +1,58 @@
+"""bench.py as the driver runs it, on the GPU box: `python bench.py --gpus 2 ...` without a launcher must
+start its own two ranks (mapped onto the visible devices modulo their count: both on device 0 of a 1-GPU
+box), run the real kernels and print ONE JSON line with n_gpus = 2, the aggregate and the per-GPU
+figures; and the BASELINE config-5 invocation (verify, one global batch cut into per-rank slices)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r.stderr
+
+
+def test_two_ranks_self_launched_variable_base():
+    line, err = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--log2-batch", "16", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["parity_spot_check"] == "ok"
+    assert [g["rank"] for g in line["per_gpu"]] == [0, 1] and all(g["value"] > 0 for g in line["per_gpu"])
+    assert line["value"] > 0 and line["roofline"]["kernel"] == "k_point_scalarmul"
+    assert "configs" not in line and "cpu_baseline" not in line          # N = 1 only
+    launcher = [json.loads(l) for l in err.splitlines() if l.startswith('{"launcher"')]
+    assert launcher and launcher[0]["launcher"]["torch_imported_by_launcher"] is False
+
+
+def test_config5_invocation_strong_slices_verify():
+    """BASELINE config 5 in miniature: one global batch of 2^15 verifications over 2 ranks = 2^14 each."""
+    line, _ = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--workload", "verify", "--global-log2-batch", "15"])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["unit"] == "verifies/s"
+    assert [g["batch"] for g in line["per_gpu"]] == [1 << 14, 1 << 14]
+    assert line["config"]["parity_spot_check"] == "ok"
+
+
+def test_default_line_carries_configs_and_cpu_baseline():
+    """The driver's N = 1 invocation at a reduced batch: headline + configs 3, 3', 4 and the
+    index-independent variable-base mode + the CPU baseline with its single-thread figure."""
+    line, _ = _run(["--steps", "2", "--warmup", "1", "--log2-batch", "15"])
+    assert line["n_gpus"] == 1 and line["config"]["parity_spot_check"] == "ok"
+    assert set(line["configs"]) == {"fixed", "base", "verify", "varbase_index_independent"}
+    for c in line["configs"].values():
+        assert c["parity_spot_check"] == "ok" and c["value"] > 0 and c["kernel_ms_avg"] > 0
+    assert line["configs"]["varbase_index_independent"]["kernel"] == "k_point_scalarmul_ct"
+    cb = line["cpu_baseline"]
+    assert cb["cores"] >= 1 and cb["single_thread"]["us_per_op"] > 0
+    # the stated core count is consistent with the speed-up over one thread (within 2x)
+    ratio = cb["value"] / cb["single_thread"]["value"]
+    assert cb["cores"] / 2.0 <= max(ratio, 1.0) * 2.0 and ratio <= cb["cores"] * 2.0

@@ -160,28 +160,29 @@ def test_concurrent_host_threads_on_one_device(ga, O):
 
 
 def test_index_independent_tables_match_fast_tables(ga, O):
-    """goldilocks_amd_set_table_access(INDEX_INDEPENDENT): derive / sign / X448 keygen / base-point
-    scalarmul through the LDS comb + wavefront-shuffle gather give the same bytes as the default
-    window-table kernels, on ragged batch sizes (idle lanes of the last wave redo the last operation)."""
+    """Derive / sign / X448 keygen / base-point scalarmul through the LDS comb + wavefront-shuffle gather
+    (the default, index-independent) give the same bytes as the opt-in window-table kernels
+    (GOLDILOCKS_AMD_TABLES_FAST), on ragged batch sizes (idle lanes of the last wave redo the last operation)."""
     for n in (1, 63, 3001):
         sk = np.frombuffer(_gen.stream(b"ct/sk/%d" % n, 57 * n), np.uint8).reshape(n, 57).copy()
         xs = np.frombuffer(_gen.stream(b"ct/x448/%d" % n, 56 * n), np.uint8).reshape(n, 56).copy()
         msgs = [_gen.stream(b"ct/msg/%d/%d" % (n, i), i % 200) for i in range(n)]     # ragged lengths
         k = _gen.stream_scalars(n, b"ct/scalar/%d" % n)
-        pk0 = ga.ed448_derive_public_key_batch(sk)
-        sig0 = ga.ed448_sign_batch(sk, pk0, msgs, context=b"ct")
-        x0, _ = ga.x448_batch(xs)
-        b0 = ga.precomputed_scalarmul_batch(k)
-        ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+        ga.set_table_access(ga.TABLES_FAST)
         try:
-            pk1 = ga.ed448_derive_public_key_batch(sk)
-            sig1 = ga.ed448_sign_batch(sk, pk0, msgs, context=b"ct")
-            x1, _ = ga.x448_batch(xs)
-            b1 = ga.precomputed_scalarmul_batch(k)
+            pk0 = ga.ed448_derive_public_key_batch(sk)
+            sig0 = ga.ed448_sign_batch(sk, pk0, msgs, context=b"ct")
+            x0, _ = ga.x448_batch(xs)
+            b0 = ga.precomputed_scalarmul_batch(k)
             with pytest.raises(ga.GoldilocksAmdError):
                 ga.set_table_access(7)
         finally:
-            ga.set_table_access(ga.TABLES_FAST)
+            ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+        assert ga.get_table_access() == ga.TABLES_INDEX_INDEPENDENT
+        pk1 = ga.ed448_derive_public_key_batch(sk)
+        sig1 = ga.ed448_sign_batch(sk, pk0, msgs, context=b"ct")
+        x1, _ = ga.x448_batch(xs)
+        b1 = ga.precomputed_scalarmul_batch(k)
         assert (pk0 == pk1).all() and (sig0 == sig1).all() and (x0 == x1).all()
         assert (ga.point_encode_batch(b0) == ga.point_encode_batch(b1)).all()
         assert (ga.ed448_verify_batch(sig1, pk1, msgs, context=b"ct") == -1).all()

@@ -1,0 +1,118 @@
+"""GPU tests of the table-access policy (reference: constant_time_lookup,
+src/include/constant_time.h:134-183, used at src/goldilocks.c:437-442 and :864; contract in the
+reference's README.md:92-97).  The library's default is index-independent access for every scalar that
+may be secret; GOLDILOCKS_AMD_TABLES_FAST is the opt-in for public scalars.  Both must give the same
+bytes -- checked here on the reference's own golden vectors (F1) and against the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import _gen
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+@pytest.fixture()
+def modes(ga):
+    """Runs the body once per mode and always leaves the library in its default."""
+    def each(fn):
+        out = {}
+        try:
+            for name, mode in (("index_independent", ga.TABLES_INDEX_INDEPENDENT), ("fast", ga.TABLES_FAST)):
+                ga.set_table_access(mode)
+                assert ga.get_table_access() == mode
+                out[name] = fn()
+        finally:
+            ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+        return out
+    return each
+
+
+def test_default_is_index_independent():
+    """A fresh process: the drop-in names keep the reference's constant-time contract unless told otherwise."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import libgoldilocks_amd as ga; "
+                        "print(ga.get_table_access() == ga.TABLES_INDEX_INDEPENDENT)" % root],
+                       capture_output=True, text=True, timeout=300)
+    assert r.stdout.strip() == "True", r.stdout + r.stderr
+
+
+def test_both_modes_reproduce_golden_f1(ga, modes):
+    """The 1024 reference vectors of fixture F1 (variable-base scalarmul) in both table-access modes."""
+    d = np.load(os.path.join(G, "f1_varbase.npz"))
+    bases, st = ga.point_decode_batch(d["base"], allow_identity=True)
+    assert (st == -1).all()
+    res = modes(lambda: ga.point_encode_batch(ga.point_scalarmul_batch(bases, d["scalar"])))
+    assert (res["index_independent"] == d["out"]).all()
+    assert (res["fast"] == d["out"]).all()
+
+
+def test_both_modes_on_every_variable_base_entry_point(ga, O, modes):
+    """direct_scalarmul, point_double_scalarmul, point_dual_scalarmul: both modes against the oracle,
+    ragged batch sizes (1, 63, 257) and edge scalars."""
+    from _libs import Q
+    for n in (1, 63, 257):
+        k = _gen.stream_scalars(n, b"ta/base/%d" % n)
+        bases = _gen.oracle_fixed(O, k)
+        bases2 = _gen.oracle_fixed(O, _gen.stream_scalars(n, b"ta/base2/%d" % n))
+        s1 = _gen.stream_scalars(n, b"ta/s1/%d" % n)
+        s2 = _gen.stream_scalars(n, b"ta/s2/%d" % n)
+        edge = _gen.scalars_from_ints([0, 1, Q - 1, 2**445, 2**444 - 1, 15, 16, 17])
+        s1[:min(n, len(edge))] = edge[:min(n, len(edge))]
+        want_mul = _gen.oracle_encode(_gen.oracle_varbase(O, bases, s1))
+        want_mul2 = _gen.oracle_encode(_gen.oracle_varbase(O, bases, s2))
+        dbl = np.empty((n, 32), dtype=np.uint64)
+        for i in range(n):
+            O.orc_point_double_scalarmul(_p(dbl[i]), _p(bases[i]), _p(s1[i]), _p(bases2[i]), _p(s2[i]))
+        want_dbl = _gen.oracle_encode(dbl)
+        base_enc = _gen.oracle_encode(bases)
+
+        def body():
+            enc, st = ga.direct_scalarmul_batch(base_enc, s1)
+            o1, o2 = ga.point_dual_scalarmul_batch(bases, s1, s2)
+            return dict(direct=enc, direct_st=st, dbl=ga.point_encode_batch(ga.point_double_scalarmul_batch(bases, s1, bases2, s2)),
+                        dual1=ga.point_encode_batch(o1), dual2=ga.point_encode_batch(o2),
+                        mul=ga.point_encode_batch(ga.point_scalarmul_batch(bases, s1)))
+        for mode, r in modes(body).items():
+            assert (r["direct_st"] == -1).all(), mode
+            assert (r["direct"] == want_mul).all(), (mode, "direct", n)
+            assert (r["mul"] == want_mul).all(), (mode, "scalarmul", n)
+            assert (r["dbl"] == want_dbl).all(), (mode, "double_scalarmul", n)
+            assert (r["dual1"] == want_mul).all() and (r["dual2"] == want_mul2).all(), (mode, "dual", n)
+
+
+def test_index_independent_scan_on_a_full_residency(ga, O):
+    """More operations than resident lanes (grid-stride rounds, partial last wave) through the scan
+    tables; a sample of lanes against the oracle and all of them against the fast tables on the device."""
+    import torch
+    info = ga.device_info()
+    n = info["compute_units"] * 2 * 256 + 1000 + 37
+    k = torch.from_numpy(_gen.stream_scalars(n, b"ta/full/base").view(np.int64)).cuda()
+    s = torch.from_numpy(_gen.stream_scalars(n, b"ta/full/scalar").view(np.int64)).cuda()
+    bases = torch.empty((n, 32), dtype=torch.int64, device="cuda")
+    out_ct, out_fast = torch.empty_like(bases), torch.empty_like(bases)
+    ga.dev("precomputed_scalarmul", bases.data_ptr(), None, k.data_ptr(), n, None)
+    try:
+        ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+        ga.dev("point_scalarmul", out_ct.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None)
+        ga.set_table_access(ga.TABLES_FAST)
+        ga.dev("point_scalarmul", out_fast.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None)
+    finally:
+        ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    ga.dev("point_pred", st.data_ptr(), out_ct.data_ptr(), out_fast.data_ptr(), 0, n, None)
+    assert int((st == -1).sum()) == n
+    idx = np.unique(np.concatenate([np.arange(0, n, 4099), [0, 63, 64, n - 1, n - 37, n - 38]]))
+    b_h = bases.cpu().numpy().view(np.uint64)[idx]
+    s_h = s.cpu().numpy().view(np.uint64)[idx]
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, b_h, s_h))
+    got = ga.point_encode_batch(out_ct.cpu().numpy().view(np.uint64)[idx])
+    assert (got == want).all()
