@@ -48,14 +48,22 @@ struct fe {
 
 #if defined(GF_CHECKED)
 // Host-side checker accumulator: 128-bit, aborts if a 64-bit accumulator would
-// have overflowed or gone negative.
+// have overflowed or gone negative.  It also counts the multiply-accumulates (one v_mad_u64_u32 each on
+// the device): bench.py's MACs-per-operation figures come from this counter (tests/test_hostsim.py).
+inline unsigned long long &gf_mac_counter() {
+    static thread_local unsigned long long count = 0;
+    return count;
+}
 struct acc_t {
     unsigned __int128 x;   // the exact value; the device accumulator holds it mod 2^64
     GD_MFN acc_t() : x(0) {}
     GD_MFN explicit acc_t(uint64_t v) : x(v) {}
     // a finished column is read out: it must be what a wrapping u64 accumulator holds
     GD_MFN void chk() const { if (x >> 64) __builtin_trap(); }
-    GD_MFN void mac(uint32_t a, uint32_t b) { x += (unsigned __int128)a * b; }
+    GD_MFN void mac(uint32_t a, uint32_t b) {
+        x += (unsigned __int128)a * b;
+        gf_mac_counter()++;
+    }
     GD_MFN void add(const acc_t &o) { x += o.x; }
     GD_MFN void add32(uint32_t o) { x += o; }
     GD_MFN void sub(const acc_t &o) { if (o.x > x) __builtin_trap(); x -= o.x; }

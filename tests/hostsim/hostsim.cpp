@@ -109,6 +109,51 @@ void hs_sc_decode_long(uint64_t *o, const uint8_t *in, size_t len) {
     sc_to_abi(o, sc_decode_long_bytes(in, len));
 }
 
+// 4-bit windows (the ladder the index-independent kernels run): same group element as the 5-bit one
+void hs_point_scalarmul_w4(uint64_t *out, const uint64_t *base, const uint64_t *scalar) {
+    sc r = sc_recode_window<4>(sc_from_abi(scalar));
+    HostBits bits;
+    for (int i = 0; i < 14; i++) bits.w[i] = r.w[i];
+    bits.w[14] = 0;
+    HostTable tab;
+    build_window_table_w<4>(tab, pt_from_abi(base));
+    pt_to_abi(out, ladder_varbase_w<4>(bits, tab));
+}
+// Multiply-accumulates (v_mad_u64_u32 on the device) of one call of a building block; the counts
+// do not depend on the data.  what: 0 fe_mul, 1 fe_sqr, 2 fe_mulw, 3 pt_double, 4 pt_double + T,
+// 5 pt_add_niels + T, 6 niels_to_pt, 7 fe_isr, 8 pt_decode_eddsa, 9 pt_add (full), 10 pt_eq,
+// 11 variable base W = 5 (table + ladder), 12 variable base W = 4, 13 comb ladder
+void hs_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *scalar);
+void hs_precomputed_scalarmul(uint64_t *out, const uint64_t *table, const uint64_t *scalar);
+unsigned long long hs_mac_count_of(int what, const uint64_t *point, const uint64_t *scalar, const uint64_t *comb_table) {
+    pt p = pt_from_abi(point), q = p;
+    uint64_t out[32];
+    uint32_t w15[15] = {0};
+    bool ok;
+    niels nl;
+    nl.a = p.x; nl.b = p.y; nl.cn = p.t;
+    unsigned long long &c = gf_mac_counter();
+    c = 0;
+    switch (what) {
+    case 0: (void)fe_mul(p.x, p.y); break;
+    case 1: (void)fe_sqr(p.x); break;
+    case 2: (void)fe_mulw(p.x, 39081); break;
+    case 3: pt_double(q, false); break;
+    case 4: pt_double(q, true); break;
+    case 5: pt_add_niels(q, nl, false, true); break;
+    case 6: (void)niels_to_pt(nl, false); break;
+    case 7: (void)fe_isr(p.x, &ok); break;
+    case 8: (void)pt_decode_eddsa_words(q, w15); break;
+    case 9: (void)pt_add(p, q, false); break;
+    case 10: (void)pt_eq(p, q); break;
+    case 11: hs_point_scalarmul(out, point, scalar); break;
+    case 12: hs_point_scalarmul_w4(out, point, scalar); break;
+    case 13: hs_precomputed_scalarmul(out, comb_table, scalar); break;
+    default: return 0;
+    }
+    return c;
+}
+
 void hs_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *scalar) {
     HostBits bits = make_bits(sc_from_abi(scalar));
     HostTable tab;

@@ -19,6 +19,16 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def _pt(a):
+    from _libs import Point
+    return a.ctypes.data_as(C.POINTER(Point))
+
+
+def _sc(a):
+    from _libs import Scalar
+    return a.ctypes.data_as(C.POINTER(Scalar))
+
+
 @pytest.fixture()
 def modes(ga):
     """Runs the body once per mode and always leaves the library in its default."""
@@ -71,7 +81,7 @@ def test_both_modes_on_every_variable_base_entry_point(ga, O, modes):
         want_mul2 = _gen.oracle_encode(_gen.oracle_varbase(O, bases, s2))
         dbl = np.empty((n, 32), dtype=np.uint64)
         for i in range(n):
-            O.orc_point_double_scalarmul(_p(dbl[i]), _p(bases[i]), _p(s1[i]), _p(bases2[i]), _p(s2[i]))
+            O.orc_point_double_scalarmul(_pt(dbl[i]), _pt(bases[i]), _sc(s1[i]), _pt(bases2[i]), _sc(s2[i]))
         want_dbl = _gen.oracle_encode(dbl)
         base_enc = _gen.oracle_encode(bases)
 

@@ -168,3 +168,49 @@ def test_elligator_and_dual(H, O):
         H.hs_point_dual_scalarmul(C.byref(o1), C.byref(o2), C.byref(a), C.byref(s1), C.byref(s2))
         O.orc_point_scalarmul(C.byref(w1), C.byref(a), C.byref(s1)); O.orc_point_scalarmul(C.byref(w2), C.byref(a), C.byref(s2))
         assert _enc(O, o1) == _enc(O, w1) and _enc(O, o2) == _enc(O, w2)
+
+
+def test_mac_counts_match_bench(H, O):
+    """bench.py prices its kernels in 32x32->64 multiply-accumulates per operation: the figures must be
+    what the lane code really executes, counted by the checker accumulator of this host build."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    H.hs_mac_count_of.restype = C.c_ulonglong
+    base = np.frombuffer(bytes(O.orc_point_base().contents), np.uint64).copy()
+    comb = np.frombuffer(bytes(O.orc_precomputed_base().contents), np.uint64).copy()
+    s = _gen.stream_scalars(1, b"mac-count")[0].copy()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    names = ["fe_mul", "fe_sqr", "fe_mulw", "dbl", "dbl_t", "add_niels_t", "niels_to_pt", "isr", "decode_eddsa",
+             "pt_add", "pt_eq", "varbase5", "varbase4", "comb"]
+    c = {name: H.hs_mac_count_of(i, p(base), p(s), p(comb)) for i, name in enumerate(names)}
+    assert (c["fe_mul"], c["fe_sqr"], c["fe_mulw"]) == (192, 136, 16)
+    assert c["dbl"] == 4 * 136 + 3 * 192 and c["dbl_t"] == c["dbl"] + 192
+    W = bench.WORKLOADS
+    assert W["varbase"]["macs"] == c["varbase5"] == 2175 * 192 + 1785 * 136 + 17 * 16
+    assert W["varbase"]["macs_index_independent"] == c["varbase4"]
+    assert W["fixed"]["macs"] == W["base"]["macs_index_independent"] == c["comb"]
+    # base-point window table, 16-bit digits: one conversion + 27 mixed additions
+    assert W["base"]["macs"] == c["niels_to_pt"] + 27 * c["add_niels_t"]
+    assert W["verify"]["macs"] == 2 * c["decode_eddsa"] + c["varbase5"] + W["base"]["macs"] + c["pt_add"] + c["pt_eq"]
+
+
+def test_four_bit_window_ladder_matches_oracle(H, O):
+    """The 4-bit-window ladder of the index-independent kernels (recoding with 2^448 - 1, 8-entry table)."""
+    rnd = random.Random(9)
+    bases = _gen.oracle_fixed(O, _gen.stream_scalars(12, b"w4/base"))
+    vals = [0, 1, 2, Q - 1, Q - 2, 2**445, 2**444 - 1, 7, 8, 9, 15, 16] 
+    scal = _gen.scalars_from_ints(vals)
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, bases, scal))
+    out = np.empty((12, 32), dtype=np.uint64)
+    for i in range(12):
+        H.hs_point_scalarmul_w4(out[i].ctypes.data_as(C.c_void_p), bases[i].ctypes.data_as(C.c_void_p),
+                                scal[i].ctypes.data_as(C.c_void_p))
+    assert (_gen.oracle_encode(out) == want).all()
+    s2 = _gen.stream_scalars(8, b"w4/rand")
+    b2 = _gen.oracle_fixed(O, _gen.stream_scalars(8, b"w4/base2"))
+    o2 = np.empty((8, 32), dtype=np.uint64)
+    for i in range(8):
+        H.hs_point_scalarmul_w4(o2[i].ctypes.data_as(C.c_void_p), b2[i].ctypes.data_as(C.c_void_p),
+                                s2[i].ctypes.data_as(C.c_void_p))
+    assert (_gen.oracle_encode(o2) == _gen.oracle_encode(_gen.oracle_varbase(O, b2, s2))).all()
