@@ -260,28 +260,47 @@ GD_FN void load_bytes_as_words(uint32_t *w, const uint8_t *p, int nbytes, int nw
 // FB: fixed-base multiplier for the base point (FixedComb / FixedBwt).  AT: this lane's window
 // table, filled here.  STAGE: sponge block; `mkbits(sc, slot)` turns a recoded scalar into a BITS
 // reader (LDS-backed on the device).  The two halves S*B and (-h)*A are computed separately --
-// fixed-base table for one, signed-window ladder for the other -- and added: fewer field
-// multiplications than interleaving them on one doubling chain, and no lane divergence.
+// signed-window ladder for one, fixed-base table for the other, accumulated onto the ladder's result:
+// fewer field multiplications than interleaving them on one doubling chain, and no lane divergence.
+//
+// The phases are ordered so that their live state does not overlap (one lane has 256 registers):
+//   decode A -> A's window table (A itself is dead afterwards)
+//   decode R -> its X and Y wait in the table's build slot, free once the table is built
+//   challenge hash (the Keccak state is the only large live object)
+//   ladder -h*A, then the base-point additions onto the same accumulator
+//   compare with R read back.
 template <class FB, class AT, class STAGE, class MKBITS>
 GD_FN bool ed448_verify_core(const Ed448Msg &m, const FB &fb, AT &a_tab, STAGE &stage, MKBITS &mkbits) {
+    constexpr int PARK = window_plan<5>::ENTRIES;
     uint32_t w[29];
-    pt A, R;
-    load_bytes_as_words(w, m.b, 57, 15);          // public key
-    bool ok = pt_decode_eddsa_words(A, w);
-    load_bytes_as_words(w, m.a, 57, 15);          // R = sig[0:57]
-    ok = pt_decode_eddsa_words(R, w) && ok;   // (both decoded: lanes stay uniform)
-
+    bool ok;
+    {
+        pt A;
+        load_bytes_as_words(w, m.b, 57, 15);          // public key
+        ok = pt_decode_eddsa_words(A, w);
+        build_window_table(a_tab, A);
+    }
+    {
+        pt R;
+        load_bytes_as_words(w, m.a, 57, 15);          // R = sig[0:57]
+        ok = pt_decode_eddsa_words(R, w) && ok;       // (both decoded: lanes stay uniform)
+        pniels park;
+        park.a = R.x;
+        park.b = R.y;
+        park.cn = fe_zero();
+        park.z = fe_zero();
+        a_tab.store(PARK, park);
+    }
     shake256_114(w, m, m.total(), stage);
     sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));   // -h mod q
     load_bytes_as_words(w, m.a + 57, 57, 15);     // S = sig[57:114]
     sc response = sc_decode_long_words<57>(w);                        // S mod q, no range check
 
-    build_window_table(a_tab, A);
     auto bits_c = mkbits(sc_recode_signed(challenge), 1);
-    pt hA = ladder_varbase(bits_c, a_tab);                            // -h*A
-    pt sB = fb.mul(response, mkbits);                                 // S*B
-    pt P = pt_add(hA, sB, false);
-    return ok && pt_eq(P, R);
+    pt P = ladder_varbase(bits_c, a_tab);                             // -h*A, T included
+    fb.add_to(P, response, mkbits);                                   // + S*B
+    const pniels r = a_tab.load(PARK);
+    return ok && fe_eq(fe_mul(P.y, r.a), fe_mul(r.b, P.x));          // P == R up to 2-torsion (src/goldilocks.c:644-653)
 }
 
 // ------------------------------------------------------------------ key derivation and signing

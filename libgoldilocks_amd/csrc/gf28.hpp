@@ -419,6 +419,17 @@ GD_FN void fe_serialize_words(uint32_t w[14], const fe &a) {
         w[k] = (uint32_t)acc;
     }
 }
+// 14 words (16 x 28 bits, little-endian bit string) -> limbs, no range check
+GD_FN fe fe_unpack_words(const uint32_t w[14]) {
+    fe c;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int bit = 28 * i, k = bit / 32, sh = bit % 32;
+        uint64_t two = (uint64_t)w[k] | (k + 1 < 14 ? (uint64_t)w[k + 1] << 32 : 0);
+        c.v[i] = (uint32_t)(two >> sh) & M28;
+    }
+    return c;
+}
 // Returns false iff the 448-bit value read is >= p (cf. gf_deserialize,
 // src/f_generic.c:49-68).  The result limbs are < 2^28 either way.
 GD_FN bool fe_deserialize_words(fe &c, const uint32_t w[14]) {

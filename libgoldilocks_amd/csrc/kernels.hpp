@@ -25,6 +25,13 @@
 
 namespace gd {
 
+#ifndef GD_SCAN_UNROLL
+#define GD_SCAN_UNROLL 1            // entries of an index-independent scan in flight together (ScanTable)
+#endif
+constexpr int SCAN_UNROLL = GD_SCAN_UNROLL;
+#ifndef GD_SCAN_PIPELINED
+#define GD_SCAN_PIPELINED 0
+#endif
 constexpr int BLOCK = 256;          // 4 waves: one per SIMD
 #ifndef GD_WAVES_PER_SIMD
 #define GD_WAVES_PER_SIMD 2
@@ -188,79 +195,117 @@ __device__ __forceinline__ pniels pniels_load(const uint4 *q) {
     e.z = fe_load(q + 12);
     return e;
 }
+struct DirectEntry {   // one 256-byte entry at a known address
+    const uint4 *q;
+    __device__ __forceinline__ gd::fe field(int c) const { return fe_load(q + 4 * c); }
+};
 struct LaneTable {  // this lane's window table in the HBM workspace, lane-contiguous; the digit picks the address
     uint4 *p;
     __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
+    __device__ __forceinline__ DirectEntry entry(uint32_t idx) const { return DirectEntry{p + 16 * idx}; }
+    __device__ __forceinline__ DirectEntry entry_public(uint32_t k) const { return entry(k); }
 };
 struct SharedTable {  // read-only 16-entry table shared by all lanes (base point; public scalars only)
     const uint4 *p;
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
+    __device__ __forceinline__ DirectEntry entry(uint32_t idx) const { return DirectEntry{p + 16 * idx}; }
 };
 // The index-independent window table: the counterpart of the reference's constant_time_lookup
 // (src/include/constant_time.h:134-183, used at src/goldilocks.c:440): every lookup reads EVERY entry
 // and keeps the wanted one with v_cndmask, so neither the addresses issued nor the number of
 // transactions depend on the (secret) digit.  The table is private to a lane, so there is nothing for
-// a wavefront shuffle to share; instead the wave's 64 tables are interleaved [entry][uint4][lane] --
-// each of the ENTRIES x 16 loads of a scan is one fully coalesced 1-KiB row.  With W = 4 the
-// resident tables (8 x 256 B per lane) stay inside the 256-MiB Infinity Cache.
+// a wavefront shuffle to share; instead
+//   * the wave's 64 tables are interleaved [entry][row][lane], so each load of a scan is one fully
+//     coalesced 1-KiB row (a lane-contiguous table would touch 64 lines per instruction);
+//   * entries are stored canonical and bit-packed, 4 field elements x 448 bits = 14 uint4 = 224 B
+//     instead of 256: a scan moves ENTRIES x 224 B per digit, which is what bounds this kernel
+//     (HBM / Infinity-Cache bandwidth), and with 4-bit windows the tables of all
+//     resident lanes (131 072 x 8 x 224 B = 224 MiB) fit the 256-MiB Infinity Cache.
+constexpr int SCAN_ROWS = 14;   // uint4 per packed entry
 template <int ENTRIES>
 struct ScanTable {
-    uint4 *p;   // the wave's region + lane: element (k, q) of this lane at p[(16 * k + q) * 64]
+    uint4 *p;   // the wave's region + lane: row r of entry k of this lane at p[(SCAN_ROWS * k + r) * 64]
     __device__ __forceinline__ void store(int k, const pniels &e) const {
-        uint4 *q = p + (size_t)(16 * k) * 64;
-        const fe *f[4] = {&e.a, &e.b, &e.cn, &e.z};
+        uint32_t w[56];
+        fe_serialize_words(w, e.a);          // canonical limbs < 2^28, packed
+        fe_serialize_words(w + 14, e.b);
+        fe_serialize_words(w + 28, e.cn);
+        fe_serialize_words(w + 42, e.z);     // 2Z mod p
+        uint4 *q = p + (size_t)(SCAN_ROWS * k) * 64;
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const fe &a = *f[c];
-            q[(4 * c + 0) * 64] = make_uint4(a.v[0], a.v[1], a.v[2], a.v[3]);
-            q[(4 * c + 1) * 64] = make_uint4(a.v[4], a.v[5], a.v[6], a.v[7]);
-            q[(4 * c + 2) * 64] = make_uint4(a.v[8], a.v[9], a.v[10], a.v[11]);
-            q[(4 * c + 3) * 64] = make_uint4(a.v[12], a.v[13], a.v[14], a.v[15]);
+        for (int r = 0; r < SCAN_ROWS; r++) q[r * 64] = make_uint4(w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]);
+    }
+    __device__ __forceinline__ void load_raw(uint4 (&w)[SCAN_ROWS], int k) const {
+        const uint4 *q = p + (size_t)(SCAN_ROWS * k) * 64;
+#pragma unroll
+        for (int i = 0; i < SCAN_ROWS; i++) w[i] = q[i * 64];
+    }
+    __device__ __forceinline__ static pniels from_raw(const uint4 (&r)[SCAN_ROWS]) {
+        uint32_t w[56];
+#pragma unroll
+        for (int i = 0; i < SCAN_ROWS; i++) {
+            w[4 * i] = r[i].x; w[4 * i + 1] = r[i].y; w[4 * i + 2] = r[i].z; w[4 * i + 3] = r[i].w;
         }
-    }
-    __device__ __forceinline__ void load_raw(uint4 (&w)[16], int k) const {
-        const uint4 *q = p + (size_t)(16 * k) * 64;
-#pragma unroll
-        for (int i = 0; i < 16; i++) w[i] = q[i * 64];
-    }
-    __device__ __forceinline__ static pniels from_raw(const uint4 (&w)[16]) {
         pniels e;
-        e.a = fe_from_u4(w[0], w[1], w[2], w[3]);
-        e.b = fe_from_u4(w[4], w[5], w[6], w[7]);
-        e.cn = fe_from_u4(w[8], w[9], w[10], w[11]);
-        e.z = fe_from_u4(w[12], w[13], w[14], w[15]);
+        e.a = fe_unpack_words(w);
+        e.b = fe_unpack_words(w + 14);
+        e.cn = fe_unpack_words(w + 28);
+        e.z = fe_unpack_words(w + 42);
         return e;
     }
+    struct ValueEntry {   // an entry already in registers
+        pniels e;
+        __device__ __forceinline__ gd::fe field(int c) const { return c == 0 ? e.a : c == 1 ? e.b : c == 2 ? e.cn : e.z; }
+    };
     __device__ __forceinline__ pniels load(uint32_t k) const {   // table building only (k is public)
-        uint4 w[16];
+        uint4 w[SCAN_ROWS];
         load_raw(w, (int)k);
         return from_raw(w);
     }
-    __device__ __forceinline__ pniels lookup(uint32_t idx) const {
-        uint4 r[16];
-        load_raw(r, 0);
-#pragma unroll 1
-        for (int k = 1; k < ENTRIES; k++) {
-            uint4 w[16];
-            load_raw(w, k);
-            const bool take = idx == (uint32_t)k;
+    __device__ __forceinline__ ValueEntry entry_public(uint32_t k) const { return ValueEntry{load(k)}; }
+    // the entry a SECRET digit asks for: all ENTRIES candidates are read, one is kept
+    __device__ __forceinline__ static void keep(uint4 (&r)[SCAN_ROWS], const uint4 (&w)[SCAN_ROWS], bool take) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                r[i].x = take ? w[i].x : r[i].x;
-                r[i].y = take ? w[i].y : r[i].y;
-                r[i].z = take ? w[i].z : r[i].z;
-                r[i].w = take ? w[i].w : r[i].w;
-            }
+        for (int i = 0; i < SCAN_ROWS; i++) {
+            r[i].x = take ? w[i].x : r[i].x;
+            r[i].y = take ? w[i].y : r[i].y;
+            r[i].z = take ? w[i].z : r[i].z;
+            r[i].w = take ? w[i].w : r[i].w;
         }
+    }
+    __device__ __forceinline__ pniels lookup(uint32_t idx) const {
+        uint4 r[SCAN_ROWS];
+#if GD_SCAN_PIPELINED
+        // two candidates in flight: the loads of entry k+1 are issued before entry k is looked at
+        uint4 a[SCAN_ROWS], b[SCAN_ROWS];
+        load_raw(r, 0);
+        load_raw(a, 1);
+#pragma unroll
+        for (int k = 1; k < ENTRIES; k += 2) {
+            if (k + 1 < ENTRIES) load_raw(b, k + 1);
+            keep(r, a, idx == (uint32_t)k);
+            if (k + 2 < ENTRIES) load_raw(a, k + 2);
+            if (k + 1 < ENTRIES) keep(r, b, idx == (uint32_t)(k + 1));
+        }
+#else
+        load_raw(r, 0);
+#pragma unroll SCAN_UNROLL
+        for (int k = 1; k < ENTRIES; k++) {
+            uint4 w[SCAN_ROWS];
+            load_raw(w, k);
+            keep(r, w, idx == (uint32_t)k);
+        }
+#endif
         return from_raw(r);
     }
+    __device__ __forceinline__ ValueEntry entry(uint32_t idx) const { return ValueEntry{lookup(idx)}; }
 };
-// uint4 per WAVE of a scan table: (ENTRIES + 1 build slot) x 16 uint4 x 64 lanes
+// uint4 per WAVE of a scan table: (ENTRIES + 1 build slot) x SCAN_ROWS uint4 x 64 lanes
 template <int ENTRIES>
-constexpr int scan_table_wave_u4() { return (ENTRIES + 1) * 16 * 64; }
+constexpr int scan_table_wave_u4() { return (ENTRIES + 1) * SCAN_ROWS * 64; }
 // The comb staged in LDS and gathered with wavefront shuffles.  Entry e occupies words
 // [49e, 49e+48) (stride 49 keeps the fill reads below conflict-free).  For comb j every lane
 // first reads 12 words with a LANE-dependent, index-INDEPENDENT address: lane l takes words

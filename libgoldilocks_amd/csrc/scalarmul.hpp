@@ -11,9 +11,11 @@
 // (a) instantiated by the HIP kernels with HBM/LDS-backed storage and (b) run on
 // the host by tests/hostsim with plain arrays (checker only, never shipped):
 //   BITS  : bits.word(k) -> k-th 32-bit word of s' (k < 15, word 14 is zero)
-//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table (ENTRIES + 1 slots:
-//           the entries + one scratch slot used while the table is built); table.lookup(idx) is the
-//           read of a digit's entry -- direct, or index-independent (a scan of every entry)
+//   TABLE : table.store(k, pniels) for the per-lane window table (ENTRIES + 1 slots: the entries + one
+//           scratch slot used while the table is built); table.entry(idx) is a reader of the digit's
+//           entry, field by field (r.field(c)) -- direct, or index-independent (every field a scan of the
+//           whole table); table.lookup(idx) the whole entry at once; table.entry_public(k) a direct
+//           reader for the table-building code, whose indices are not secret
 #pragma once
 #include "point.hpp"
 #include "sc14.hpp"
@@ -68,7 +70,7 @@ GD_FN void build_window_table_w(TABLE &table, const pt &b) {
     pt acc = b;
 #pragma unroll 1
     for (int k = 1; k < E; k++) {
-        pt_add_pniels(acc, table.load(E), false, true);
+        pt_add_entry(acc, table.entry_public(E), false, true);
         table.store(k, pt_to_pniels(acc));
     }
 }
@@ -89,10 +91,9 @@ GD_FN pt ladder_varbase_w(const BITS &bits, const TABLE &table) {
         signed_digit_w<W>(window_w<W>(bits, pos), idx, neg);
 #pragma unroll 1
         for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
-        pniels e = table.lookup(idx);
         // T is only needed by a following addition, i.e. never after the last window's
         // add -- except that the caller wants a complete extended point at pos == 0.
-        pt_add_pniels(acc, e, neg, pos == 0);
+        pt_add_entry(acc, table.entry(idx), neg, pos == 0);
     }
     return acc;
 }
@@ -176,6 +177,17 @@ GD_FN void signed_digit_bwt(uint32_t w, uint32_t &idx, bool &neg) {
     neg = w < (uint32_t)BWT_PER_WINDOW;
     idx = (neg ? ~w : w) & (uint32_t)(BWT_PER_WINDOW - 1);
 }
+// acc += s*B through the same table: one mixed addition per digit onto a caller's accumulator (acc.t valid)
+template <class BITS, class BWT>
+GD_FN void ladder_bwt_onto(pt &acc, const BITS &bits, const BWT &bwt) {
+    uint32_t idx;
+    bool neg;
+#pragma unroll 1
+    for (int i = BWT_WINDOWS - 1; i >= 0; i--) {
+        signed_digit_bwt(window_bwt(bits, i), idx, neg);
+        pt_add_niels(acc, bwt.load(i, idx), neg, true);
+    }
+}
 template <class BITS, class BWT>
 GD_FN pt ladder_bwt(const BITS &bits, const BWT &bwt) {
     uint32_t idx;
@@ -200,6 +212,8 @@ struct FixedComb {
         auto bits = mk(sc_recode_signed(s), 0);
         return ladder_comb(bits, comb);
     }
+    template <class MK>
+    GD_MFN void add_to(pt &acc, const sc &s, MK &mk) const { acc = pt_add(acc, mul(s, mk), false); }
 };
 template <class BWT>
 struct FixedBwt {
@@ -208,6 +222,11 @@ struct FixedBwt {
     GD_MFN pt mul(const sc &s, MK &mk) const {
         auto bits = mk(sc_recode_bwt(s), 0);
         return ladder_bwt(bits, bwt);
+    }
+    template <class MK>
+    GD_MFN void add_to(pt &acc, const sc &s, MK &mk) const {
+        auto bits = mk(sc_recode_bwt(s), 0);
+        ladder_bwt_onto(acc, bits, bwt);
     }
 };
 
@@ -219,15 +238,15 @@ GD_FN pt ladder_double_w(const BITS &bits1, const TABLE1 &t1, const BITS &bits2,
     signed_digit_w<W>(window_w<W>(bits1, window_plan<W>::TOP), idx, neg);
     pt acc = pniels_to_pt(t1.lookup(idx), neg);
     signed_digit_w<W>(window_w<W>(bits2, window_plan<W>::TOP), idx, neg);
-    pt_add_pniels(acc, t2.lookup(idx), neg, false);
+    pt_add_entry(acc, t2.entry(idx), neg, false);
 #pragma unroll 1
     for (int pos = window_plan<W>::TOP - W; pos >= 0; pos -= W) {
 #pragma unroll 1
         for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
         signed_digit_w<W>(window_w<W>(bits1, pos), idx, neg);
-        pt_add_pniels(acc, t1.lookup(idx), neg, true);
+        pt_add_entry(acc, t1.entry(idx), neg, true);
         signed_digit_w<W>(window_w<W>(bits2, pos), idx, neg);
-        pt_add_pniels(acc, t2.lookup(idx), neg, pos == 0);
+        pt_add_entry(acc, t2.entry(idx), neg, pos == 0);
     }
     return acc;
 }

@@ -22,9 +22,12 @@ struct VarTable<false> {
         return type{ws + ((size_t)lane * ntab + which) * TABLE_U4};
     }
 };
+#ifndef GD_CT_WINDOW
+#define GD_CT_WINDOW 4
+#endif
 template <>
 struct VarTable<true> {
-    static constexpr int W = 4;
+    static constexpr int W = GD_CT_WINDOW;
     static constexpr int ENTRIES = window_plan<W>::ENTRIES;
     using type = ScanTable<ENTRIES>;
     static __device__ __forceinline__ type at(uint4 *ws, int which, int ntab) {

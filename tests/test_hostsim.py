@@ -192,7 +192,7 @@ def test_mac_counts_match_bench(H, O):
     assert W["fixed"]["macs"] == W["base"]["macs_index_independent"] == c["comb"]
     # base-point window table, 16-bit digits: one conversion + 27 mixed additions
     assert W["base"]["macs"] == c["niels_to_pt"] + 27 * c["add_niels_t"]
-    assert W["verify"]["macs"] == 2 * c["decode_eddsa"] + c["varbase5"] + W["base"]["macs"] + c["pt_add"] + c["pt_eq"]
+    assert W["verify"]["macs"] == 2 * c["decode_eddsa"] + c["varbase5"] + 28 * c["add_niels_t"] + c["pt_eq"]
 
 
 def test_four_bit_window_ladder_matches_oracle(H, O):
