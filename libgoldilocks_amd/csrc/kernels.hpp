@@ -195,23 +195,16 @@ __device__ __forceinline__ pniels pniels_load(const uint4 *q) {
     e.z = fe_load(q + 12);
     return e;
 }
-struct DirectEntry {   // one 256-byte entry at a known address
-    const uint4 *q;
-    __device__ __forceinline__ gd::fe field(int c) const { return fe_load(q + 4 * c); }
-};
 struct LaneTable {  // this lane's window table in the HBM workspace, lane-contiguous; the digit picks the address
     uint4 *p;
     __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
-    __device__ __forceinline__ DirectEntry entry(uint32_t idx) const { return DirectEntry{p + 16 * idx}; }
-    __device__ __forceinline__ DirectEntry entry_public(uint32_t k) const { return entry(k); }
 };
 struct SharedTable {  // read-only 16-entry table shared by all lanes (base point; public scalars only)
     const uint4 *p;
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
-    __device__ __forceinline__ DirectEntry entry(uint32_t idx) const { return DirectEntry{p + 16 * idx}; }
 };
 // The index-independent window table: the counterpart of the reference's constant_time_lookup
 // (src/include/constant_time.h:134-183, used at src/goldilocks.c:440): every lookup reads EVERY entry
@@ -256,16 +249,11 @@ struct ScanTable {
         e.z = fe_unpack_words(w + 42);
         return e;
     }
-    struct ValueEntry {   // an entry already in registers
-        pniels e;
-        __device__ __forceinline__ gd::fe field(int c) const { return c == 0 ? e.a : c == 1 ? e.b : c == 2 ? e.cn : e.z; }
-    };
     __device__ __forceinline__ pniels load(uint32_t k) const {   // table building only (k is public)
         uint4 w[SCAN_ROWS];
         load_raw(w, (int)k);
         return from_raw(w);
     }
-    __device__ __forceinline__ ValueEntry entry_public(uint32_t k) const { return ValueEntry{load(k)}; }
     // the entry a SECRET digit asks for: all ENTRIES candidates are read, one is kept
     __device__ __forceinline__ static void keep(uint4 (&r)[SCAN_ROWS], const uint4 (&w)[SCAN_ROWS], bool take) {
 #pragma unroll
@@ -301,7 +289,6 @@ struct ScanTable {
 #endif
         return from_raw(r);
     }
-    __device__ __forceinline__ ValueEntry entry(uint32_t idx) const { return ValueEntry{lookup(idx)}; }
 };
 // uint4 per WAVE of a scan table: (ENTRIES + 1 build slot) x SCAN_ROWS uint4 x 64 lanes
 template <int ENTRIES>

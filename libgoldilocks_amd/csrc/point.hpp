@@ -87,33 +87,6 @@ GD_FN void pt_add_pniels(pt &p, const pniels &e, bool neg, bool need_t) {
     fe zz = fe_mul(e.z, p.z);                    // e.z mag 2
     pt_add_core(p, zz, e.a, e.b, e.cn, neg, need_t);
 }
-// The same addition with the table entry read field by field, each right before the product that
-// consumes it (ENTRY: r.field(c), c = 0 a, 1 b, 2 cn, 3 z): at most one or two entry fields are live
-// next to the accumulator instead of all four, which is what keeps the add out of scratch memory --
-// and for the index-independent tables each field is its own scan over the whole table.
-template <class ENTRY>
-GD_FN void pt_add_entry(pt &p, const ENTRY &r, bool neg, bool need_t) {
-    fe zz = fe_mul(r.field(3), p.z);
-    fe u = fe_sub<2>(p.y, p.x);                  // mag 3
-    fe v = fe_add(p.x, p.y);                     // mag 2
-    fe A, B;
-    {
-        const fe ea_ = r.field(0), eb_ = r.field(1);
-        A = fe_mul(u, fe_select(ea_, eb_, neg));
-        B = fe_mul(v, fe_select(eb_, ea_, neg));
-    }
-    fe Cn = fe_mul(r.field(2), p.t);                // = -C of the reference
-    fe E = fe_weak(fe_sub<2>(B, A));             // mag 1
-    fe H = fe_add(A, B);                         // mag 2
-    fe zm = fe_sub<2>(zz, Cn);
-    fe zp = fe_add(zz, Cn);
-    fe F = fe_select(zp, zm, neg);
-    fe G = fe_select(zm, zp, neg);
-    p.x = fe_mul(F, E);
-    p.y = fe_mul(G, H);
-    p.z = fe_mul(F, G);
-    if (need_t) p.t = fe_mul(E, H);
-}
 GD_FN void pt_add_niels(pt &p, const niels &e, bool neg, bool need_t) {
     pt_add_core(p, p.z, e.a, e.b, e.cn, neg, need_t);
 }

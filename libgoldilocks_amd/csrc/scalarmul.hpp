@@ -11,11 +11,10 @@
 // (a) instantiated by the HIP kernels with HBM/LDS-backed storage and (b) run on
 // the host by tests/hostsim with plain arrays (checker only, never shipped):
 //   BITS  : bits.word(k) -> k-th 32-bit word of s' (k < 15, word 14 is zero)
-//   TABLE : table.store(k, pniels) for the per-lane window table (ENTRIES + 1 slots: the entries + one
-//           scratch slot used while the table is built); table.entry(idx) is a reader of the digit's
-//           entry, field by field (r.field(c)) -- direct, or index-independent (every field a scan of the
-//           whole table); table.lookup(idx) the whole entry at once; table.entry_public(k) a direct
-//           reader for the table-building code, whose indices are not secret
+//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table (ENTRIES + 1 slots:
+//           the entries + one scratch slot used while the table is built; k is public there);
+//           table.lookup(idx) is the read of a digit's entry -- direct, or index-independent (a scan
+//           of every entry, kernels.hpp ScanTable)
 #pragma once
 #include "point.hpp"
 #include "sc14.hpp"
@@ -70,7 +69,7 @@ GD_FN void build_window_table_w(TABLE &table, const pt &b) {
     pt acc = b;
 #pragma unroll 1
     for (int k = 1; k < E; k++) {
-        pt_add_entry(acc, table.entry_public(E), false, true);
+        pt_add_pniels(acc, table.load(E), false, true);
         table.store(k, pt_to_pniels(acc));
     }
 }
@@ -91,9 +90,12 @@ GD_FN pt ladder_varbase_w(const BITS &bits, const TABLE &table) {
         signed_digit_w<W>(window_w<W>(bits, pos), idx, neg);
 #pragma unroll 1
         for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
+        // all of the entry's loads are issued together, behind the doublings (read field by field, each
+        // right before its product, the same kernel measures 0.8 % slower: profiles/r02/experiments.md)
+        pniels e = table.lookup(idx);
         // T is only needed by a following addition, i.e. never after the last window's
         // add -- except that the caller wants a complete extended point at pos == 0.
-        pt_add_entry(acc, table.entry(idx), neg, pos == 0);
+        pt_add_pniels(acc, e, neg, pos == 0);
     }
     return acc;
 }
@@ -238,15 +240,15 @@ GD_FN pt ladder_double_w(const BITS &bits1, const TABLE1 &t1, const BITS &bits2,
     signed_digit_w<W>(window_w<W>(bits1, window_plan<W>::TOP), idx, neg);
     pt acc = pniels_to_pt(t1.lookup(idx), neg);
     signed_digit_w<W>(window_w<W>(bits2, window_plan<W>::TOP), idx, neg);
-    pt_add_entry(acc, t2.entry(idx), neg, false);
+    pt_add_pniels(acc, t2.lookup(idx), neg, false);
 #pragma unroll 1
     for (int pos = window_plan<W>::TOP - W; pos >= 0; pos -= W) {
 #pragma unroll 1
         for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
         signed_digit_w<W>(window_w<W>(bits1, pos), idx, neg);
-        pt_add_entry(acc, t1.entry(idx), neg, true);
+        pt_add_pniels(acc, t1.lookup(idx), neg, true);
         signed_digit_w<W>(window_w<W>(bits2, pos), idx, neg);
-        pt_add_entry(acc, t2.entry(idx), neg, pos == 0);
+        pt_add_pniels(acc, t2.lookup(idx), neg, pos == 0);
     }
     return acc;
 }

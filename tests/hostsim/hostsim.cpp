@@ -32,12 +32,6 @@ struct HostTable {
     void store(int k, const pniels &p) { e[k] = p; }
     pniels load(uint32_t k) const { return e[k]; }
     pniels lookup(uint32_t k) const { return e[k]; }
-    struct Entry {
-        const pniels *q;
-        fe field(int c) const { return c == 0 ? q->a : c == 1 ? q->b : c == 2 ? q->cn : q->z; }
-    };
-    Entry entry(uint32_t k) const { return Entry{&e[k]}; }
-    Entry entry_public(uint32_t k) const { return Entry{&e[k]}; }
 };
 struct HostComb {
     niels e[80];
