@@ -88,11 +88,12 @@ GD_FN pt ladder_varbase_w(const BITS &bits, const TABLE &table) {
 #pragma unroll 1
     for (int pos = window_plan<W>::TOP - W; pos >= 0; pos -= W) {
         signed_digit_w<W>(window_w<W>(bits, pos), idx, neg);
+        table.prefetch(idx);   // a policy may start fetching the entry now (the digit is known); most do nothing
 #pragma unroll 1
         for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
         // all of the entry's loads are issued together, behind the doublings (read field by field, each
         // right before its product, the same kernel measures 0.8 % slower: profiles/r02/experiments.md)
-        pniels e = table.lookup(idx);
+        pniels e = table.fetch(idx);
         // T is only needed by a following addition, i.e. never after the last window's
         // add -- except that the caller wants a complete extended point at pos == 0.
         pt_add_pniels(acc, e, neg, pos == 0);

@@ -82,24 +82,47 @@ def launch_ranks(argv, world, timeout=None):
 
 
 def init_group(world, rank, visible_devices, use_gpu=True):
-    """torch.distributed process group for this rank, or None when world == 1.  Returns (dist, backend)."""
-    if world <= 1:
+    """torch.distributed process group for this rank, or None when world == 1.  Returns (dist, backend).
+    RCCL ("nccl") when every rank has a GPU of its own, gloo otherwise; GOLDILOCKS_BENCH_BACKEND=gloo
+    forces gloo, and a failing RCCL bring-up falls back to it (the group only carries the barrier, the MAX
+    of the elapsed time and the per-rank rows -- nothing of the data path)."""
+    if world <= 1 and not os.environ.get("GOLDILOCKS_BENCH_FORCE_DIST"):   # the knob lets a 1-GPU box exercise RCCL
         return None, None
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(free_port()))
+    world = max(world, 1)
+    import datetime
     import torch
     import torch.distributed as dist
     own_device = use_gpu and visible_devices >= world
-    backend = "nccl" if own_device else "gloo"
+    backend = os.environ.get("GOLDILOCKS_BENCH_BACKEND") or ("nccl" if own_device else "gloo")
     os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's banner off stdout: one JSON line only
-    kw = {}
-    if backend == "nccl":
-        kw["device_id"] = torch.device("cuda", device_for_rank(rank, visible_devices))
+
+    def bring_up(which):
+        kw = {}
+        if which == "nccl":
+            kw["device_id"] = torch.device("cuda", device_for_rank(rank, visible_devices))
+        dist.init_process_group(which, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600), **kw)
+        dist.barrier()                                   # connections are made (and announced) lazily
+
     # gloo and RCCL print banners on the C-level stdout; rank 0's stdout carries ONE JSON line only
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
     try:
-        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-        dist.barrier()                                   # connections are made (and announced) lazily
+        try:
+            bring_up(backend)
+        except Exception as e:   # noqa: BLE001 -- whatever RCCL raises on this node
+            if backend != "nccl":
+                raise
+            print("shard.init_group: RCCL bring-up failed (%s); control plane falls back to gloo" % e, file=sys.stderr)
+            try:
+                dist.destroy_process_group()
+            except Exception:   # noqa: BLE001
+                pass
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            backend = "gloo"
+            bring_up(backend)
     finally:
         os.dup2(saved, 1)
         os.close(saved)

@@ -34,15 +34,20 @@ def timeit(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-print("%8s | %21s | %21s | %21s" % ("batch", "variable-base", "fixed-base (window)", "verify"))
-print("%8s | %10s %10s | %10s %10s | %10s %10s" % ("", "ms", "M op/s", "ms", "M op/s", "ms", "M op/s"))
-for lg in range(6, 23, 2):
-    n = 1 << lg
-    reps = 3 if lg >= 18 else 5
-    a = timeit(lambda: ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), scal.data_ptr(), n, None), reps)
-    b = timeit(lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scal.data_ptr(), n, None), reps)
-    c = timeit(lambda: ga.dev("ed448_verify", st.data_ptr(), sig.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0,
-                              None, 0, n, None), reps)
-    assert int((st[:n] == -1).sum()) == n
-    print("    2^%-2d | %10.3f %10.3f | %10.3f %10.3f | %10.3f %10.3f" % (lg, a, n / a / 1e3, b, n / b / 1e3, c, n / c / 1e3),
-          flush=True)
+for mode, name in ((ga.TABLES_INDEX_INDEPENDENT, "index-independent tables (library default)"), (ga.TABLES_FAST, "fast tables (opt-in)")):
+  ga.set_table_access(mode)
+  print("\n" + name)
+  print("%8s | %21s | %21s | %21s" % ("batch", "variable-base", "base point", "verify (always fast)"))
+  print("%8s | %10s %10s | %10s %10s | %10s %10s" % ("", "ms", "M op/s", "ms", "M op/s", "ms", "M op/s"))
+  for lg in range(6, 23, 2):
+      n = 1 << lg
+      reps = 3 if lg >= 18 else 5
+      a = timeit(lambda: ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), scal.data_ptr(), n, None), reps)
+      b = timeit(lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scal.data_ptr(), n, None), reps)
+      c = timeit(lambda: ga.dev("ed448_verify", st.data_ptr(), sig.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0,
+                                None, 0, n, None), reps)
+      assert int((st[:n] == -1).sum()) == n
+      print("    2^%-2d | %10.3f %10.3f | %10.3f %10.3f | %10.3f %10.3f" % (lg, a, n / a / 1e3, b, n / b / 1e3, c, n / c / 1e3),
+            flush=True)
+
+ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)

@@ -32,6 +32,8 @@ struct HostTable {
     void store(int k, const pniels &p) { e[k] = p; }
     pniels load(uint32_t k) const { return e[k]; }
     pniels lookup(uint32_t k) const { return e[k]; }
+    void prefetch(uint32_t) const {}
+    pniels fetch(uint32_t k) const { return e[k]; }
 };
 struct HostComb {
     niels e[80];

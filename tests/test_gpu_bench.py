@@ -14,8 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 BENCH = os.path.join(ROOT, "bench.py")
 
 
-def _run(args):
+def _run(args, **extra_env):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(extra_env)
     r = subprocess.run([sys.executable, BENCH] + args, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
@@ -56,3 +57,12 @@ def test_default_line_carries_configs_and_cpu_baseline():
     # the stated core count is consistent with the speed-up over one thread (within 2x)
     ratio = cb["value"] / cb["single_thread"]["value"]
     assert cb["cores"] / 2.0 <= max(ratio, 1.0) * 2.0 and ratio <= cb["cores"] * 2.0
+
+
+def test_control_plane_over_rccl_on_one_gpu():
+    """The barrier / MAX / all-gather path over RCCL ("nccl"), as the ranks of a real multi-GPU run use it:
+    a one-rank group on this box's GPU."""
+    line, _ = _run(["--steps", "2", "--warmup", "1", "--log2-batch", "14", "--no-cpu-baseline", "--no-configs"],
+                   GOLDILOCKS_BENCH_FORCE_DIST="1")
+    assert line["config"]["control_plane"] == "nccl" and line["n_gpus"] == 1
+    assert line["config"]["parity_spot_check"] == "ok"

@@ -1,39 +1,61 @@
 #!/bin/bash
 # Round profile on the GPU box (run through gpurun from the repo root):
-#     gpurun --timeout 1500 -- 'bash tools/profile_round.sh r01'
-# For each bench workload: one `rocprofv3 --kernel-trace --stats` run, then SEPARATE --pmc passes
-# (FETCH_SIZE, WRITE_SIZE, SQ instruction counters; never combined with a trace domain).  Raw output
-# goes to gpurun_out/prof/<tag>/; the summaries that get committed are written to
-# gpurun_out/profiles_<round>/ by tools/summarize_prof.py (copy them to profiles/<round>/).
+#     gpurun --timeout 1500 -- 'bash tools/profile_round.sh r02'
+# One `rocprofv3 --kernel-trace --stats` run of the SAME command the driver times (bench.py defaults)
+# and of each workload, then SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ counters; never
+# combined with a trace domain).  Raw output goes to gpurun_out/prof/; the summaries that get
+# committed are written to gpurun_out/profiles_<round>/ by tools/summarize_prof.py (copy them to
+# profiles/<round>/).  The program after `--` is always python3 itself (no env/bash hop).
 set -u
-ROUND=${1:-r01}
+ROUND=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
-rm -rf "$OUT" "$ROOT/gpurun_out/profiles_$ROUND"
-mkdir -p "$OUT" "$ROOT/gpurun_out/profiles_$ROUND"
+DST=$ROOT/gpurun_out/profiles_$ROUND
+rm -rf "$OUT" "$DST"
+mkdir -p "$OUT" "$DST"
 cd /tmp && export TMPDIR=/tmp
 BENCH="$ROOT/bench.py"
+II="--table-access index-independent"
+
+# the driver's command: headline + configs + cpu_baseline on one line
+python3 "$BENCH" > "$DST/bench_default.json" 2> "$OUT/bench_default.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_default" -- \
+    python3 "$BENCH" --steps 5 --warmup 1 > "$OUT/stats_default.log" 2>&1
+
 for wl in varbase fixed base verify sign x448 direct; do
-    python3 "$BENCH" --workload $wl > "$ROOT/gpurun_out/profiles_$ROUND/bench_$wl.json" 2> "$OUT/bench_$wl.err"
+    python3 "$BENCH" --workload $wl --no-cpu-baseline --no-configs > "$DST/bench_$wl.json" 2> "$OUT/bench_$wl.err"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- \
-        python3 "$BENCH" --workload $wl --steps 5 --warmup 1 --no-cpu-baseline > "$OUT/stats_$wl.log" 2>&1
+        python3 "$BENCH" --workload $wl --steps 5 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/stats_$wl.log" 2>&1
 done
-for wl in sign base; do   # the index-independent (LDS comb + shuffle gather) variants, bench line only
-    python3 "$BENCH" --workload $wl --table-access index-independent --no-cpu-baseline \
-        > "$ROOT/gpurun_out/profiles_$ROUND/bench_${wl}_index_independent.json" 2> "$OUT/bench_${wl}_ii.err"
+for wl in varbase base sign direct; do   # the library's default: index-independent table access
+    python3 "$BENCH" --workload $wl $II --no-cpu-baseline --no-configs > "$DST/bench_${wl}_index_independent.json" 2> "$OUT/bench_${wl}_ii.err"
 done
-for wl in varbase fixed verify; do
-    for ctr in FETCH_SIZE WRITE_SIZE; do
-        rocprofv3 --pmc $ctr --output-format csv -d "$OUT/pmc_${ctr}_$wl" -- \
-            python3 "$BENCH" --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_${ctr}_$wl.log" 2>&1
-    done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_varbaseii" -- \
+    python3 "$BENCH" --workload varbase $II --steps 5 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/stats_varbaseii.log" 2>&1
+
+pmc() {   # pmc <tag> <workload> <extra bench args...> -- <counters...>
+    local tag=$1 wl=$2; shift 2
+    local extra=()
+    while [ "$1" != "--" ]; do extra+=("$1"); shift; done
+    shift
+    rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_${tag}_$wl" -- \
+        python3 "$BENCH" --workload $wl "${extra[@]}" --steps 2 --warmup 1 --no-cpu-baseline --no-configs > "$OUT/pmc_${tag}_$wl.log" 2>&1
+}
+for wl in varbase fixed base verify; do
+    pmc FETCH $wl -- FETCH_SIZE
+    pmc WRITE $wl -- WRITE_SIZE
 done
-for wl in varbase verify x448; do
-    rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES --output-format csv -d "$OUT/pmc_SQ1_$wl" -- \
-        python3 "$BENCH" --workload $wl --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_SQ1_$wl.log" 2>&1
+pmc FETCHII varbase $II -- FETCH_SIZE
+pmc WRITEII varbase $II -- WRITE_SIZE
+for wl in varbase verify; do
+    pmc SQ1 $wl -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES
+    pmc SQ2 $wl -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 done
-rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d "$OUT/pmc_SQ2_varbase" -- \
-    python3 "$BENCH" --workload varbase --steps 2 --warmup 1 --no-cpu-baseline > "$OUT/pmc_SQ2_varbase.log" 2>&1
-"$ROOT/tools/fieldbench" > "$ROOT/gpurun_out/profiles_$ROUND/fieldbench.txt" 2>&1
-python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$ROOT/gpurun_out/profiles_$ROUND"
-ls -la "$ROOT/gpurun_out/profiles_$ROUND"
+pmc SQ1II varbase $II -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES
+pmc SQ2II varbase $II -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
+pmc GRBM varbase -- GRBM_GUI_ACTIVE
+
+"$ROOT/tools/fieldbench" > "$DST/fieldbench.txt" 2>&1
+python3 "$ROOT/tests/batch_sweep.py" > "$DST/batch_sweep.txt" 2>&1
+python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$DST"
+ls -la "$DST"

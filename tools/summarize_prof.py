@@ -33,6 +33,9 @@ def main(raw, out):
         if not os.path.isdir(d):
             continue
         wl = os.path.basename(d).rsplit("_", 1)[1]
+        tag = os.path.basename(d).split("_")[1]
+        if tag.endswith("II"):
+            wl += "_index_independent"
         # the bench process is the one with the most dispatches
         best = None
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
@@ -51,9 +54,12 @@ def main(raw, out):
         for (kern, ctr), a in agg.items():
             if kern.startswith("__amd_rocclr") or "at::native" in kern:
                 continue
+            # rocprofv3's VGPR_Count is the ARCHITECTURAL half of the unified file as it reports it (128 for
+            # a kernel whose code-object note says .vgpr_count 256): the authoritative per-kernel figures
+            # are kernel_resources.json (tools/kernel_resources.py, straight from the code-object notes)
             rows.append({"bench": wl, "kernel": kern, "counter": ctr, "dispatches": len(a["ids"]),
-                         "avg_per_dispatch": a["sum"] / len(a["ids"]), "vgpr": a["vgpr"], "agpr": a["agpr"],
-                         "scratch": a["scratch"], "lds": a["lds"]})
+                         "avg_per_dispatch": a["sum"] / len(a["ids"]), "rocprof_vgpr_count_field": a["vgpr"],
+                         "rocprof_accum_vgpr_count_field": a["agpr"], "scratch": a["scratch"], "lds": a["lds"]})
     json.dump(rows, open(os.path.join(out, "rocprofv3_pmc_summary.json"), "w"), indent=1)
     # HBM bytes per launch for bench.py's roofline.traffic: 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes)
     fetch, write = {}, {}
