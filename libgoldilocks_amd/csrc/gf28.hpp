@@ -49,7 +49,7 @@ struct fe {
 #if defined(GF_CHECKED)
 // Host-side checker accumulator: 128-bit, aborts if a 64-bit accumulator would
 // have overflowed or gone negative.  It also counts the multiply-accumulates (one v_mad_u64_u32 each on
-// the device): bench.py's MACs-per-operation figures come from this counter (tests/test_hostsim.py).
+// the device): bench.py's MACs-per-operation figures come from this counter (the checker build's tests).
 inline unsigned long long &gf_mac_counter() {
     static thread_local unsigned long long count = 0;
     return count;

@@ -89,6 +89,17 @@ def test_product_sources_do_not_reference_the_oracle():
                     "tests/hostsim", ""), f
 
 
+def test_library_exports_nothing_but_the_declared_abi(L):
+    """No host-side arithmetic (the checker build's branches of the lane headers), no helper and no
+    oracle symbol leaks out of the shared library: its dynamic symbol table is exactly the header."""
+    import libgoldilocks_amd as ga
+    out = subprocess.run(["nm", "-D", "--defined-only", ga.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {l.split()[-1] for l in out.splitlines() if l.split()[1:2] and l.split()[1] in "TDBRVW"}
+    declared = set(ga.FUNCTIONS) | set(ga.DATA_SYMBOLS)
+    assert exported == declared, sorted(exported ^ declared)      # libgoldilocks_amd/csrc/exports.map
+    assert not any("orc_" in s or "hs_" in s or "oracle" in s for s in exported)
+
+
 def test_void_drop_in_functions_abort_loudly_without_gpu(L):
     """The reference's void functions cannot report errors; without a device ours abort with a
     message instead of returning garbage or computing on the CPU."""

@@ -13,6 +13,15 @@ pytestmark = pytest.mark.gpu
 EDGE_SCALARS = [0, 1, 2, Q - 1, Q - 2, 2**445, 2**445 - 1, (Q + 1) // 2, 31, 32, 2**224, 2**440 + 12345]
 
 
+@pytest.fixture(autouse=True, params=["index_independent", "fast"])
+def table_mode(request, ga):
+    """Every test of this module runs under both table-access policies (include/goldilocks_amd.h): the
+    library's default (index-independent scans / LDS comb) and the opt-in digit-addressed tables."""
+    ga.set_table_access(ga.TABLES_FAST if request.param == "fast" else ga.TABLES_INDEX_INDEPENDENT)
+    yield request.param
+    ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+
+
 def enc(ga, pts):
     return ga.point_encode_batch(pts)
 
@@ -368,12 +377,10 @@ def test_rfc8032_vectors_through_the_abi(ga):
     assert (enc(ga, ga.point_scalarmul_batch(np.tile(ga.point_base(), (16, 1)), ks)) == want).all()
 
 
-@pytest.mark.parametrize("mode", ["fast", "index_independent"])
-def test_golden_f6_full_batch_digest(ga, mode):
-    """The whole 2^20 benchmark batch, pinned by 32 bytes computed with the real reference: the
-    digit-addressed tables bench.py's headline is quoted on, and the library's default scan tables."""
+def test_golden_f6_full_batch_digest(ga, table_mode):
+    """The whole 2^20 benchmark batch, pinned by 32 bytes computed with the real reference: under the
+    digit-addressed tables bench.py's headline is quoted on, and under the library's default scan tables."""
     import torch
-    ga.set_table_access(ga.TABLES_FAST if mode == "fast" else ga.TABLES_INDEX_INDEPENDENT)
     dig = json.load(open(os.path.join(GOLD, "f6_bench_digest.json")))["digest_shake256_32"]
     n = 1 << 20
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
@@ -386,7 +393,6 @@ def test_golden_f6_full_batch_digest(ga, mode):
     ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None)
     ga.dev("point_encode", ser.data_ptr(), out.data_ptr(), n, None)
     enc_all = ser.cpu().numpy()
-    ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
     for lg in (10, 16, 20):
         assert hashlib.shake_256(enc_all[:1 << lg].tobytes()).hexdigest(32) == dig[str(lg)], lg
 

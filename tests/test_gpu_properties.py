@@ -12,6 +12,15 @@ pytestmark = pytest.mark.gpu
 N = 256
 
 
+@pytest.fixture(autouse=True, params=["index_independent", "fast"])
+def table_mode(request, ga):
+    """Every test of this module runs under both table-access policies (include/goldilocks_amd.h): the
+    library's default (index-independent scans / LDS comb) and the opt-in digit-addressed tables."""
+    ga.set_table_access(ga.TABLES_FAST if request.param == "fast" else ga.TABLES_INDEX_INDEPENDENT)
+    yield request.param
+    ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+
+
 def limbs_to_int(l):
     return sum(int(x) << (56 * i) for i, x in enumerate(l))
 

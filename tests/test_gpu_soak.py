@@ -15,6 +15,15 @@ import os
 SEED = os.environ.get("GOLDILOCKS_SOAK_SEED", "").encode()
 
 
+@pytest.fixture(autouse=True, params=["index_independent", "fast"])
+def table_mode(request, ga):
+    """Every test of this module runs under both table-access policies (include/goldilocks_amd.h): the
+    library's default (index-independent scans / LDS comb) and the opt-in digit-addressed tables."""
+    ga.set_table_access(ga.TABLES_FAST if request.param == "fast" else ga.TABLES_INDEX_INDEPENDENT)
+    yield request.param
+    ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+
+
 def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
