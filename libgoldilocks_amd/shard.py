@@ -124,6 +124,11 @@ def init_group(world, rank, visible_devices, use_gpu=True):
             backend = "gloo"
             bring_up(backend)
     finally:
+        try:   # what the C libraries wrote sits in stdio's buffer: push it out while fd 1 still is stderr
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:   # noqa: BLE001
+            pass
         os.dup2(saved, 1)
         os.close(saved)
     return dist, backend
