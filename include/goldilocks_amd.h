@@ -308,6 +308,14 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
 #define GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT 1
 GOLDILOCKS_AMD_API int goldilocks_amd_set_table_access(int mode);
 GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the mode in force */
+/* Small batches.  One lane's ladder takes 2.1-2.5 ms however few operations a call has, so batches of
+ * up to `n` variable-base multiplications (the single-operation drop-in names included) run ONE
+ * OPERATION PER WAVEFRONT instead: the 64 lanes share the operation (a field element spread over the
+ * 16 lanes of a row, four field elements per register), 0.3-0.6 ms per call.  Index-independent table
+ * access in either table mode.  The default is the measured crossover; 0 disables the path. */
+#define GOLDILOCKS_AMD_WAVE_BATCH_DEFAULT 8192
+GOLDILOCKS_AMD_API void goldilocks_amd_set_wave_batch_max(size_t n);
+GOLDILOCKS_AMD_API size_t goldilocks_amd_get_wave_batch_max(void);
 /* "gfx950", number of CUs, workspace bytes currently held */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
         size_t *workspace_bytes);

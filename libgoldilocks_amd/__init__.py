@@ -80,6 +80,8 @@ FUNCTIONS = {
     "goldilocks_amd_use_devices": (C.c_int, "pi"),
     "goldilocks_amd_set_table_access": (C.c_int, "i"),
     "goldilocks_amd_get_table_access": (C.c_int, ""),
+    "goldilocks_amd_set_wave_batch_max": (None, "z"),
+    "goldilocks_amd_get_wave_batch_max": (C.c_size_t, ""),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -396,6 +398,15 @@ def set_table_access(mode):
     TABLES_FAST (opt-in for public scalars): how every kernel whose scalar may be secret looks up its
     window / comb table -- see include/goldilocks_amd.h."""
     _check(lib().goldilocks_amd_set_table_access(int(mode)))
+
+
+def set_wave_batch_max(n):
+    """Batches of up to n variable-base multiplications run one operation per wavefront (0 disables)."""
+    lib().goldilocks_amd_set_wave_batch_max(int(n))
+
+
+def get_wave_batch_max():
+    return lib().goldilocks_amd_get_wave_batch_max()
 
 
 def get_table_access():

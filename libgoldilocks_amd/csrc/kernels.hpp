@@ -450,6 +450,9 @@ GD_KERNEL k_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t 
                             uint4 *__restrict__ workspace);
 GD_KERNEL_CT k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
                                   uint32_t n, uint4 *__restrict__ workspace);
+// one operation per WAVE (wave_coop.hpp): the small-batch / single-call path
+extern "C" __global__ void k_point_scalarmul_wave(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
+                                                  uint32_t n);
 GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ comb,
                                   const uint64_t *__restrict__ scalar, uint32_t n);
 GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ bwt,

@@ -1,0 +1,120 @@
+"""GPU parity of the one-operation-per-WAVE path (libgoldilocks_amd/csrc/wave_coop.hpp): batches of up to
+goldilocks_amd_get_wave_batch_max() variable-base multiplications -- the single-operation drop-in name
+included -- run with the 64 lanes of a wavefront sharing one operation (0.35-0.6 ms instead of the
+2.1-2.5 ms of a lane's ladder).  Same reference lines as the lane kernels (src/goldilocks.c:405-465),
+same bar: bit-exact encodings, against the reference's golden vectors (F1) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+import _gen
+from _libs import Q
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture()
+def paths(ga):
+    """Run a body through the wave path (threshold raised) and the lane path (threshold 0)."""
+    default = ga.get_wave_batch_max()
+
+    def both(fn):
+        out = {}
+        try:
+            for name, mx in (("wave", 1 << 20), ("lane", 0)):
+                ga.set_wave_batch_max(mx)
+                out[name] = fn()
+        finally:
+            ga.set_wave_batch_max(default)
+        return out
+    return both
+
+
+def test_default_threshold_is_the_documented_one(ga):
+    assert ga.get_wave_batch_max() == 8192
+
+
+def test_golden_f1_through_the_wave_path(ga, paths):
+    d = np.load(os.path.join(G, "f1_varbase.npz"))
+    bases, st = ga.point_decode_batch(d["base"], allow_identity=True)
+    assert (st == -1).all()
+    r = paths(lambda: ga.point_encode_batch(ga.point_scalarmul_batch(bases, d["scalar"])))
+    assert (r["wave"] == d["out"]).all()
+    assert (r["lane"] == d["out"]).all()
+
+
+def test_ragged_batches_edge_scalars_and_special_points(ga, O, paths):
+    edge = [0, 1, 2, Q - 1, Q - 2, 2**445, 2**445 - 1, (Q + 1) // 2, 15, 16, 17, 31, 32, 33, 2**224, 2**440 + 12345]
+    for n in (1, 2, 3, 5, 63, 64, 65, 257, 1000):
+        k = _gen.stream_scalars(n, b"wave/base/%d" % n)
+        bases = _gen.oracle_fixed(O, k)
+        s = _gen.stream_scalars(n, b"wave/scalar/%d" % n)
+        m = min(n, len(edge))
+        s[:m] = _gen.scalars_from_ints(edge[:m])
+        if n >= 5:
+            bases[3] = ga.point_identity()             # the identity as base
+            bases[4] = ga.point_base()
+        want = _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))
+        r = paths(lambda: ga.point_encode_batch(ga.point_scalarmul_batch(bases, s)))
+        assert (r["wave"] == want).all(), n
+        assert (r["lane"] == want).all(), n
+
+
+def test_unreduced_and_rescaled_representatives(ga, O, paths):
+    """Weakly reduced limbs (above 2^56) and projectively rescaled inputs give the same group element."""
+    from _libs import P
+    n = 64
+    bases = _gen.oracle_fixed(O, _gen.stream_scalars(n, b"wave/rep/base"))
+    s = _gen.stream_scalars(n, b"wave/rep/scalar")
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))
+    rng = np.random.default_rng(3)
+    alt = bases.copy()
+    pl = [(1 << 56) - 1] * 8
+    pl[4] -= 1
+    for i in range(n):
+        c = [sum(int(x) << (56 * j) for j, x in enumerate(bases[i, 8 * k:8 * k + 8])) % P for k in range(4)]
+        f = int.from_bytes(rng.bytes(56), "little") % P or 1
+        c = [x * f % P for x in c]
+        limbs = []
+        for x in c:
+            l = [(x >> (56 * j)) & ((1 << 56) - 1) for j in range(8)]
+            if i % 2:
+                l = [a + b for a, b in zip(l, pl)]       # + p limb-wise: limbs above 2^56
+            limbs += l
+        alt[i] = np.array(limbs, dtype=np.uint64)
+    r = paths(lambda: ga.point_encode_batch(ga.point_scalarmul_batch(alt, s)))
+    assert (r["wave"] == want).all() and (r["lane"] == want).all()
+
+
+def test_single_operation_drop_in_and_in_place_output(ga, O):
+    """goldilocks_448_point_scalarmul (one operation) takes the wave path by default; out may alias base."""
+    import torch
+    k = _gen.stream_scalars(4, b"wave/single/base")
+    bases = _gen.oracle_fixed(O, k)
+    s = _gen.stream_scalars(4, b"wave/single/scalar")
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))
+    for i in range(4):
+        got = ga.point_scalarmul(bases[i], s[i])
+        assert (ga.point_encode_batch(got.reshape(1, 32)) == want[i]).all()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+    io, ds = d(bases), d(s)
+    ga.dev("point_scalarmul", io.data_ptr(), io.data_ptr(), ds.data_ptr(), 4, None)      # in place
+    torch.cuda.synchronize()
+    assert (ga.point_encode_batch(io.cpu().numpy().view(np.uint64)) == want).all()
+
+
+def test_both_sides_of_the_threshold_agree(ga, O):
+    default = ga.get_wave_batch_max()
+    try:
+        ga.set_wave_batch_max(100)
+        k = _gen.stream_scalars(101, b"wave/thr/base")
+        bases = _gen.oracle_fixed(O, k)
+        s = _gen.stream_scalars(101, b"wave/thr/scalar")
+        a = ga.point_encode_batch(ga.point_scalarmul_batch(bases[:100], s[:100]))      # wave
+        b = ga.point_encode_batch(ga.point_scalarmul_batch(bases, s))                  # lane (101 > 100)
+        assert (a == b[:100]).all()
+        assert (b == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all()
+    finally:
+        ga.set_wave_batch_max(default)

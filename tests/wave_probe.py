@@ -1,0 +1,33 @@
+"""Quick check + timing of the one-operation-per-wave kernel (tests/test_gpu_wave.py is the real test)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np, torch
+import libgoldilocks_amd as ga
+d = np.load(os.path.join(ROOT, "tests", "golden", "f1_varbase.npz"))
+bases, st = ga.point_decode_batch(d["base"], allow_identity=True)
+for mx in (0, 1 << 20):
+    ga.set_wave_batch_max(mx)
+    got = ga.point_encode_batch(ga.point_scalarmul_batch(bases, d["scalar"]))
+    bad = np.nonzero((got != d["out"]).any(axis=1))[0]
+    print("wave_batch_max", mx, "mismatches", len(bad), bad[:10], flush=True)
+dv = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
+rng = np.random.default_rng(0)
+def timeit(fn, reps=5):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+N = 1 << 16
+idx = rng.integers(0, 1024, N)
+B, S = dv(bases[idx]), dv(d["scalar"][idx]); out = torch.empty_like(B)
+print("%8s %12s %12s" % ("n", "wave ms", "lane ms"))
+for lg in (0, 2, 4, 6, 8, 10, 11, 12, 13, 14, 15, 16):
+    n = 1 << lg
+    r = []
+    for mx in (1 << 20, 0):
+        ga.set_wave_batch_max(mx)
+        r.append(timeit(lambda: ga.dev("point_scalarmul", out.data_ptr(), B.data_ptr(), S.data_ptr(), n, None)))
+    print("%8d %12.3f %12.3f" % (n, r[0], r[1]), flush=True)
