@@ -34,8 +34,11 @@ def timeit(fn, reps):
     return e0.elapsed_time(e1) / reps
 
 
-for mode, name in ((ga.TABLES_INDEX_INDEPENDENT, "index-independent tables (library default)"), (ga.TABLES_FAST, "fast tables (opt-in)")):
+print("variable base: batches up to %d operations run one operation per wavefront (csrc/wave_coop.hpp)" % ga.get_wave_batch_max())
+for mode, name in ((ga.TABLES_INDEX_INDEPENDENT, "index-independent tables (library default)"), (ga.TABLES_FAST, "fast tables (opt-in)"),
+                   (ga.TABLES_INDEX_INDEPENDENT, "index-independent tables, one-operation-per-wave path disabled")):
   ga.set_table_access(mode)
+  ga.set_wave_batch_max(0 if "disabled" in name else 8192)
   print("\n" + name)
   print("%8s | %21s | %21s | %21s" % ("batch", "variable-base", "base point", "verify (always fast)"))
   print("%8s | %10s %10s | %10s %10s | %10s %10s" % ("", "ms", "M op/s", "ms", "M op/s", "ms", "M op/s"))
@@ -51,3 +54,4 @@ for mode, name in ((ga.TABLES_INDEX_INDEPENDENT, "index-independent tables (libr
             flush=True)
 
 ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+ga.set_wave_batch_max(8192)
