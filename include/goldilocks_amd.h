@@ -308,12 +308,15 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
 #define GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT 1
 GOLDILOCKS_AMD_API int goldilocks_amd_set_table_access(int mode);
 GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the mode in force */
-/* Small batches.  One lane's ladder takes 2.1-2.5 ms however few operations a call has, so batches of
- * up to `n` variable-base multiplications (the single-operation drop-in names included) run ONE
- * OPERATION PER WAVEFRONT instead: the 64 lanes share the operation (a field element spread over the
- * 16 lanes of a row, four field elements per register), 0.3-0.6 ms per call.  Index-independent table
- * access in either table mode.  The default is the measured crossover; 0 disables the path. */
+/* Small batches.  One lane's ladder takes 2.1-2.8 ms however few operations a call has, so batches of
+ * up to `n` variable-base multiplications -- and up to min(n, GOLDILOCKS_AMD_WAVE_VERIFY_DEFAULT)
+ * verifications (any n above GOLDILOCKS_AMD_WAVE_BATCH_DEFAULT applies to both) -- the single-operation
+ * drop-in names included, run ONE OPERATION PER WAVEFRONT instead: the 64 lanes share the operation (a
+ * field element spread over the 16 lanes of a row, four field elements per register), 0.35 ms per
+ * multiplication call, 0.6 ms per verification call.  Index-independent table access in either table
+ * mode.  The defaults are the measured crossovers; 0 disables the path. */
 #define GOLDILOCKS_AMD_WAVE_BATCH_DEFAULT 8192
+#define GOLDILOCKS_AMD_WAVE_VERIFY_DEFAULT 4096   /* the same path for verification: up to this many per call */
 GOLDILOCKS_AMD_API void goldilocks_amd_set_wave_batch_max(size_t n);
 GOLDILOCKS_AMD_API size_t goldilocks_amd_get_wave_batch_max(void);
 /* "gfx950", number of CUs, workspace bytes currently held */
@@ -389,6 +392,12 @@ GOLDILOCKS_AMD_API int goldilocks_amd_x448_dev(void *shared /* n*56 */, void *st
  *               reduction, ma = (op >> 8) & 0xff, mb = (op >> 16) & 0xff: operands at the limits of the
  *               device arithmetic's magnitude contract. */
 GOLDILOCKS_AMD_API int goldilocks_amd_field_op_dev(void *out, void *status, const void *a, const void *b,
+        int op, size_t n, void *stream);
+
+/* The same hook for the row arithmetic of the one-operation-per-wave path (four elements per wavefront):
+ * op 0 mul, 1 strong_reduce (raw limbs), 2 isr (+ mask), 3 eq (mask), 4 lobit (mask),
+ * 5 deserialize (a = 56 bytes; out = limbs, status = value < p). */
+GOLDILOCKS_AMD_API int goldilocks_amd_wave_field_op_dev(void *out, void *status, const void *a, const void *b,
         int op, size_t n, void *stream);
 
 #ifdef __cplusplus

@@ -25,4 +25,64 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_point_scalarmul_wave(uint6
     if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
 }
 
+// Field-level test hook for the row arithmetic: every wave takes FOUR consecutive elements (one per row).
+//   0 mul  1 strong_reduce (canonical limbs)  2 isr (+ mask)  3 eq (mask)  4 lobit (mask)
+//   5 deserialize: a holds 56 bytes; out = limbs, status = value < p
+extern "C" __global__ void __launch_bounds__(BLOCK) k_wave_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status,
+                                                                    const uint64_t *__restrict__ a,
+                                                                    const uint64_t *__restrict__ b, uint32_t n, int op) {
+    const wc::Lane L = wc::make_lane();
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    for (uint32_t g = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); 4 * g < n; g += nwaves) {
+        const uint32_t e = 4 * g + L.row;
+        const bool live = e < n;
+        const size_t at = 8 * (size_t)(live ? e : n - 1);
+        auto ld = [&](const uint64_t *p) {
+            const uint64_t l56 = p[at + (L.i >> 1)];
+            return wc::weak(L, (L.i & 1u) ? (uint32_t)(l56 >> 28) : (uint32_t)l56 & M28);
+        };
+        bool ok = true;
+        wc::wfe r = 0;
+        if (op == 0) r = wc::mul(L, ld(a), ld(b));
+        else if (op == 1) r = wc::strong(L, ld(a));
+        else if (op == 2) r = wc::isr(L, ld(a), ok);
+        else if (op == 3) ok = wc::eq(L, ld(a), ld(b));
+        else if (op == 4) ok = wc::lobit(L, ld(a));
+        else if (op == 5) r = wc::deserialize(L, reinterpret_cast<const uint8_t *>(a + at), ok);
+        else {   // 6..9: coordinate X, Y, Z, T of the EdDSA decoding of the 57 bytes at a
+            wc::wfe X, Y, Z, T;
+            ok = wc::decode_eddsa_rows(L, reinterpret_cast<const uint8_t *>(a + at), X, Y, Z, T);
+            r = op == 6 ? X : op == 7 ? Y : op == 8 ? Z : T;
+        }
+        if (op != 1 && op != 5) r = wc::weak(L, r);
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)r, 0x101, 0xF, 0xF, false);
+        if (live && out && !(L.i & 1u)) out[at + (L.i >> 1)] = (uint64_t)r + ((uint64_t)nb << 28);
+        if (live && status && L.i == 0) status[e] = ok ? -1 : 0;
+    }
+}
+
+// status[i] = ed448_verify(sig[i], pk[i], msg[i]), one verification per wave   (ref: goldilocks_ed448_verify)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_ed448_verify_wave(
+    int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ pk,
+    const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
+    const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n, const uint4 *__restrict__ bwt) {
+    __shared__ uint32_t s_tab[BLOCK / 64][wc::TABLE_WORDS];
+    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    __shared__ uint32_t s_stage[34 * BLOCK];
+    const wc::Lane L = wc::make_lane();
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    const wc::WaveTable tab{s_tab[w]};
+    LdsStage stage{s_stage + threadIdx.x};
+    for (uint32_t i = blockIdx.x * (BLOCK / 64) + w; i < n; i += nwaves) {   // wave-uniform
+        const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
+        const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
+        const bool fits = len64 < MAX_MESSAGE_BYTES;
+        const uint32_t mlen = fits ? (uint32_t)len64 : 0u;
+        const Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx, ctx_len);
+        const bool ok = wc::verify(L, tab, s_bits[w], m, stage, bwt);
+        if ((threadIdx.x & 63u) == 0) status[i] = ok && fits ? -1 : 0;
+    }
+}
+
 }  // namespace gd

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #include "abi.hpp"
+#include "eddsa.hpp"
 #include "scalarmul.hpp"
 
 namespace gd {
@@ -268,6 +269,184 @@ __device__ __forceinline__ wfe scalarmul(const Lane &L, const WaveTable &tab, ui
         acc = add_entry(L, acc, tab.lookup(L, idx, neg), neg, swap_row);
     }
     return acc;
+}
+
+// ---------------------------------------------------------------- canonical form, predicates (per row)
+
+// dst[l] = src[l - 1], lane 0 of every row gets 0
+__device__ __forceinline__ uint32_t shr1_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1, bound_ctrl: 0 shifted in
+}
+// Full carry/borrow propagation of signed limbs t_i (|t_i| < 2^30): returns limbs in [0, 2^28) and in
+// `top` (every lane of the row) the signed carry out of limb 15: value = sum limb_i 2^(28 i) + top 2^448.
+__device__ __forceinline__ wfe ripple(const Lane &L, int32_t t, int32_t &top) {
+    int32_t out = 0;
+#pragma unroll 1
+    for (int k = 0; k < 16; k++) {
+        const int32_t c = t >> 28;                   // arithmetic: borrows are negative carries
+        out += c;                                    // meaningful in lane 15 only
+        t = (t & (int32_t)M28) + (int32_t)shr1_zero((uint32_t)c);
+    }
+    top = (int32_t)bcast<15>(L, (uint32_t)out);
+    return (uint32_t)t;
+}
+// Canonical representative in [0, p), limbs < 2^28  (cf. gf_strong_reduce, src/f_generic.c:71-105).  Input mag <= 15.
+__device__ __forceinline__ wfe strong(const Lane &L, wfe a) {
+    const wfe w = weak(L, weak(L, a));               // value < 2p, limbs <= 2^28
+    int32_t top;
+    const wfe t = ripple(L, (int32_t)w - (int32_t)L.pb, top);      // w - p
+    // top == -1: w < p, add p back (the carry out of that addition cancels the borrow)
+    int32_t dummy;
+    return ripple(L, (int32_t)t + (int32_t)(L.pb & (uint32_t)top), dummy);
+}
+// a == 0 mod p, per row (the answer is the same in every lane of a row)
+__device__ __forceinline__ bool is_zero(const Lane &L, wfe a) {
+    uint32_t x = strong(L, a);
+    x |= ror<8>(x);
+    x |= ror<4>(x);
+    x |= ror<2>(x);
+    x |= ror<1>(x);
+    return x == 0;
+}
+__device__ __forceinline__ bool eq(const Lane &L, wfe a, wfe b) { return is_zero(L, sub<2>(L, a, weak(L, b))); }   // a, b mag <= 2
+__device__ __forceinline__ bool lobit(const Lane &L, wfe a) { return bcast<0>(L, strong(L, a)) & 1u; }
+__device__ __forceinline__ wfe neg(const Lane &L, wfe a) { return sub<2>(L, 0u, weak(L, a)); }                    // mag 2
+__device__ __forceinline__ wfe one(const Lane &L) { return L.i == 0 ? 1u : 0u; }
+__device__ __forceinline__ wfe sqrn(const Lane &L, wfe x, int n) {
+#pragma unroll 1
+    for (int k = 0; k < n; k++) x = mul(L, x, x);
+    return x;
+}
+// x^((p-3)/4) in every row at once; ok = (result^2 * x == 1) per row  (cf. gf_isr, src/f_arithmetic.c:14-46)
+__device__ __forceinline__ wfe isr(const Lane &L, wfe x, bool &ok) {
+    const wfe e1 = weak(L, x);
+    const wfe e2 = mul(L, sqrn(L, e1, 1), e1);
+    const wfe e3 = mul(L, sqrn(L, e2, 1), e1);
+    const wfe e6 = mul(L, sqrn(L, e3, 3), e3);
+    const wfe e9 = mul(L, sqrn(L, e6, 3), e3);
+    const wfe e18 = mul(L, sqrn(L, e9, 9), e9);
+    const wfe e19 = mul(L, sqrn(L, e18, 1), e1);
+    const wfe e37 = mul(L, sqrn(L, e19, 18), e18);
+    const wfe e74 = mul(L, sqrn(L, e37, 37), e37);
+    const wfe e111 = mul(L, sqrn(L, e74, 37), e37);
+    const wfe e222 = mul(L, sqrn(L, e111, 111), e111);
+    const wfe e223 = mul(L, sqrn(L, e222, 1), e1);
+    const wfe r = mul(L, sqrn(L, e223, 223), e222);
+    ok = eq(L, mul(L, mul(L, r, r), e1), one(L));
+    return r;
+}
+
+// 56 little-endian bytes -> limbs (lane i takes bits [28 i, 28 i + 28)); *below_p = the value is < p
+// (cf. gf_deserialize, src/f_generic.c:49-68).  Rows read from their own string: p = this ROW's bytes.
+__device__ __forceinline__ wfe deserialize(const Lane &L, const uint8_t *p, bool &below_p) {
+    const uint32_t bit = 28 * L.i, b = bit >> 3, sh = bit & 7;
+    uint64_t v = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 5; k++) {
+        const uint32_t at = b + k;
+        v |= (uint64_t)(at < 56 ? p[at] : 0) << (8 * k);
+    }
+    const wfe x = (uint32_t)(v >> sh) & M28;
+    int32_t top;
+    (void)ripple(L, (int32_t)x - (int32_t)L.pb, top);
+    below_p = top != 0;                               // x - p went negative
+    return x;
+}
+
+// RFC 8032 decoding followed by the 4-isogeny (cf. pt_decode_eddsa_words, src/goldilocks.c:949-1004), one
+// encoding per ROW (enc = this row's 57 bytes): returns the row's (X, Y, Z, T) in four registers.
+__device__ __forceinline__ bool decode_eddsa_rows(const Lane &L, const uint8_t *enc, wfe &X, wfe &Y, wfe &Z, wfe &T) {
+    const uint32_t last = enc[56];
+    const bool low = (last & 0x80u) != 0;
+    bool ok = (last & 0x7fu) == 0, below, sq;
+    const wfe y = deserialize(L, enc, below);
+    ok = ok && below;
+    const wfe y2 = mul(L, y, y);
+    const wfe num = weak(L, sub<2>(L, one(L), y2));                            // 1 - y^2
+    const wfe den = weak(L, one(L) + mulw(L, y2, NEG_EDWARDS_D));             // 1 - d y^2, d = -39081
+    const wfe r = isr(L, mul(L, num, den), sq);
+    ok = ok && sq;
+    wfe x = mul(L, r, num);
+    {   // cross-lane operations must run with every lane active: both candidates first, then a plain select
+        const wfe nx = neg(L, x);
+        const bool flip = lobit(L, x) != low;
+        x = weak(L, flip ? nx : x);
+    }
+    // isogeny: like doubling with Z = 1 but E = 2 - D
+    const wfe c = mul(L, x, x);
+    const wfe d = c + y2;                                                       // mag 2
+    const wfe xy = x + y;
+    const wfe b = weak(L, sub<4>(L, mul(L, xy, xy), d));
+    const wfe tt = weak(L, sub<2>(L, y2, c));
+    const wfe e = weak(L, sub<4>(L, (L.i == 0 ? 2u : 0u), d));                  // 2 - D
+    X = mul(L, e, b);
+    Z = mul(L, tt, e);
+    Y = mul(L, d, tt);
+    T = mul(L, d, b);
+    return ok;
+}
+// four registers holding row K's (X, Y, Z, T) -> one register with rows (X, Y, Z, T)
+template <int K>
+__device__ __forceinline__ wfe pack_point(const Lane &L, wfe X, wfe Y, wfe Z, wfe T) {
+    const wfe x = from_row<K>(L, X), y = from_row<K>(L, Y), z = from_row<K>(L, Z), t = from_row<K>(L, T);
+    return L.row == 0 ? x : (L.row == 1 ? y : (L.row == 2 ? z : t));
+}
+
+// acc += s*B through the base point's window table (affine niels, 12 uint4 per entry: scalarmul.hpp
+// ladder_bwt; the entries are (Y-X, Y+X, 2*39082*T) / 2Z, i.e. projective niels with z = 1): rows
+// (a, b, cn) read their limb, row 3 is the constant 1.  Public scalars only (verification).
+template <class BITS>
+__device__ __forceinline__ wfe add_base_multiple(const Lane &L, wfe acc, const BITS &bits, const uint4 *bwt) {
+    const uint32_t swap_row = L.row ^ 1u;
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(bwt);
+#pragma unroll 1
+    for (int w = BWT_WINDOWS - 1; w >= 0; w--) {
+        uint32_t idx;
+        bool neg;
+        signed_digit_bwt(window_bwt(bits, w), idx, neg);
+        const uint32_t frow = (neg && L.row < 2) ? (L.row ^ 1u) : L.row;
+        const uint32_t *e = tab + 48 * ((size_t)BWT_PER_WINDOW * w + idx);
+        const wfe ev = L.row == 3 ? (L.i == 0 ? 1u : 0u) : e[frow * 16 + L.i];
+        acc = add_entry(L, acc, ev, neg, swap_row);
+    }
+    return acc;
+}
+
+// One Ed448 verification by this wave (cf. ed448_verify_core, src/eddsa.c:253-306): the two point
+// decodings run in rows 0 and 1 of the same instruction stream, the hash and the scalars are computed
+// by every lane alike, the ladder and the base-point additions are the wave ladder above.
+template <class STAGE>
+__device__ __forceinline__ bool verify(const Lane &L, const WaveTable &tab, uint32_t *bits, const Ed448Msg &m, STAGE &stage,
+                                       const uint4 *bwt) {
+    // row 0 decodes the public key, row 1 R (the other rows run along on the key)
+    const uint8_t *enc = L.row == 1 ? m.a : m.b;
+    wfe X, Y, Z, T;
+    const bool okrow = decode_eddsa_rows(L, enc, X, Y, Z, T);
+    const uint64_t okmask = __builtin_amdgcn_ballot_w64(okrow);
+    const bool ok = (okmask & 1u) && ((okmask >> 16) & 1u);
+    const wfe A = pack_point<0>(L, X, Y, Z, T), R = pack_point<1>(L, X, Y, Z, T);
+
+    uint32_t w[29];
+    shake256_114(w, m, m.total(), stage);
+    const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));   // -h mod q
+    load_bytes_as_words(w, m.a + 57, 57, 15);
+    const sc response = sc_decode_long_words<57>(w);                        // S mod q, no range check
+
+    wfe P = scalarmul(L, tab, bits, A, challenge);                          // -h*A
+    const sc rs = sc_recode_bwt(response);
+#pragma unroll
+    for (int k = 0; k < 14; k++) bits[k] = rs.w[k];
+    bits[14] = 0;
+    struct Bits {
+        const uint32_t *p;
+        __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
+    } rb{bits};
+    P = add_base_multiple(L, P, rb, bwt);                                   // + S*B
+    // P == R up to 2-torsion: X_P Y_R == Y_P X_R  (src/goldilocks.c:644-653)
+    const wfe pswap = rows(L, P, L.row ^ 1u);                               // (Y_P, X_P, ...)
+    const wfe prod = mul(L, pswap, R);                                      // (Y_P X_R, X_P Y_R, ...)
+    const bool same = eq(L, from_row<0>(L, prod), from_row<1>(L, prod));
+    return ok && same;
 }
 
 }  // namespace wc

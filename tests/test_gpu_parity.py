@@ -13,13 +13,18 @@ pytestmark = pytest.mark.gpu
 EDGE_SCALARS = [0, 1, 2, Q - 1, Q - 2, 2**445, 2**445 - 1, (Q + 1) // 2, 31, 32, 2**224, 2**440 + 12345]
 
 
-@pytest.fixture(autouse=True, params=["index_independent", "fast"])
+@pytest.fixture(autouse=True, params=["index_independent", "fast", "lane_kernels_only"])
 def table_mode(request, ga):
     """Every test of this module runs under both table-access policies (include/goldilocks_amd.h): the
-    library's default (index-independent scans / LDS comb) and the opt-in digit-addressed tables."""
+    library's default (index-independent scans / LDS comb) and the opt-in digit-addressed tables -- and a
+    third time with the one-operation-per-wave path for small batches switched off, so that small inputs
+    reach the lane-per-operation kernels too."""
+    default = ga.get_wave_batch_max()
     ga.set_table_access(ga.TABLES_FAST if request.param == "fast" else ga.TABLES_INDEX_INDEPENDENT)
+    ga.set_wave_batch_max(0 if request.param == "lane_kernels_only" else default)
     yield request.param
     ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
+    ga.set_wave_batch_max(default)
 
 
 def enc(ga, pts):

@@ -118,3 +118,73 @@ def test_both_sides_of_the_threshold_agree(ga, O):
         assert (b == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all()
     finally:
         ga.set_wave_batch_max(default)
+
+
+def test_verification_through_both_paths(ga, O, paths):
+    """goldilocks_ed448_verify, one verification per wave against one per lane: valid, corrupted (R, S, key,
+    message), contexts, ragged message lengths, RFC 8032's vectors and the torsion fixture F7."""
+    import json
+    sigs, pks, msgs = _gen.signatures(O, 300, msglen=40, seed=b"wave/verify", nkeys=17, context=b"ctx")
+    rng = np.random.default_rng(9)
+    for i in range(0, 300, 3):
+        which = i % 4
+        if which == 0: sigs[i, rng.integers(0, 57)] ^= 1 << rng.integers(0, 8)
+        elif which == 1: sigs[i, 57 + rng.integers(0, 56)] ^= 1 << rng.integers(0, 8)
+        elif which == 2: pks[i, rng.integers(0, 56)] ^= 1 << rng.integers(0, 8)
+        else: msgs[i] = msgs[i][:-1] + bytes([msgs[i][-1] ^ 1])
+    msgs = [m[:len(m) - (i % 7)] if i % 5 == 0 else m for i, m in enumerate(msgs)]      # ragged lengths (and thus invalid)
+    want = _gen.oracle_verify(O, sigs, pks, msgs, context=b"ctx")
+    r = paths(lambda: ga.ed448_verify_batch(sigs, pks, msgs, context=b"ctx"))
+    assert (r["wave"] == want).all() and (r["lane"] == want).all()
+    assert 0 < (want == -1).sum() < 300
+    cases = json.load(open(os.path.join(G, "f7_verify_torsion.json")))["cases"]
+    f = lambda k: np.array([np.frombuffer(bytes.fromhex(c[k]), np.uint8) for c in cases])
+    fm = [bytes.fromhex(c["msg"]) for c in cases]
+    r = paths(lambda: ga.ed448_verify_batch(f("sig"), f("pk"), fm))
+    verdicts = np.array([c["verdict"] for c in cases])
+    assert (r["wave"] == verdicts).all() and (r["lane"] == verdicts).all()
+
+
+def test_wave_field_arithmetic_against_exact_integers(ga):
+    """The row arithmetic itself (goldilocks_amd_wave_field_op_dev): mul, strong_reduce, isr, eq, lobit,
+    deserialize, on special values, unreduced limbs and random elements, every element checked."""
+    import torch
+    from _libs import P
+    M = (1 << 56) - 1
+    val = lambda l: sum(int(x) << (56 * i) for i, x in enumerate(l)) % P
+    raw = lambda l: sum(int(x) << (56 * i) for i, x in enumerate(l))
+
+    def run(op, a, b=None):
+        n = len(a)
+        da = torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint64).view(np.int64)).cuda()
+        db = da if b is None else torch.from_numpy(np.ascontiguousarray(b, dtype=np.uint64).view(np.int64)).cuda()
+        out = torch.zeros((n, 8), dtype=torch.int64, device="cuda")
+        st = torch.zeros(n, dtype=torch.int32, device="cuda")
+        ga.dev("wave_field_op", out.data_ptr(), st.data_ptr(), da.data_ptr(), db.data_ptr(), op, n, None)
+        torch.cuda.synchronize()
+        return out.cpu().numpy().view(np.uint64), st.cpu().numpy()
+    rng = np.random.default_rng(1)
+    n = 403                                                          # not a multiple of 4: a partial last wave
+    a = rng.integers(0, 2**56, size=(n, 8), dtype=np.uint64)
+    b = rng.integers(0, 2**56, size=(n, 8), dtype=np.uint64)
+    a[0] = 0; a[1] = M; a[2] = [M] * 4 + [M - 1] + [M] * 3; a[3] = [M - 1] + [M] * 3 + [M - 1] + [M] * 3
+    a[4] = [1, 0, 0, 0, 0, 0, 0, 0]; a[5] = [2**56 + 255] * 8; b[1] = M; b[5] = [2**56 + 255] * 8
+    o, _ = run(0, a, b)
+    assert all(val(o[i]) == val(a[i]) * val(b[i]) % P for i in range(n))
+    o, _ = run(1, a)
+    assert all(raw(o[i]) == val(a[i]) for i in range(n))
+    o, s = run(2, a[:64])
+    for i in range(64):
+        x = val(a[i]); r = pow(x, (P - 3) // 4, P)
+        assert val(o[i]) == r and (s[i] != 0) == (r * r * x % P == 1)
+    b2 = a.copy(); b2[::3, 0] ^= np.uint64(1); b2[1::5] += np.array([M] * 4 + [M - 1] + [M] * 3, dtype=np.uint64)   # + p
+    _, s = run(3, a, b2)
+    assert all((s[i] != 0) == (val(a[i]) == val(b2[i])) for i in range(n))
+    _, s = run(4, a)
+    assert all((s[i] != 0) == bool(val(a[i]) & 1) for i in range(n))
+    vals = [0, 1, P - 1, P, P + 1, 2**448 - 1, 2**447] + [int.from_bytes(rng.bytes(56), "little") for _ in range(90)]
+    rb = np.zeros((len(vals), 8), dtype=np.uint64)
+    for i, v in enumerate(vals):
+        rb[i, :7] = np.frombuffer(v.to_bytes(56, "little"), dtype=np.uint64)
+    o, s = run(5, rb)
+    assert all(raw(o[i]) == vals[i] and (s[i] != 0) == (vals[i] < P) for i in range(len(vals)))

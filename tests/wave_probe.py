@@ -31,3 +31,23 @@ for lg in (0, 2, 4, 6, 8, 10, 11, 12, 13, 14, 15, 16):
         ga.set_wave_batch_max(mx)
         r.append(timeit(lambda: ga.dev("point_scalarmul", out.data_ptr(), B.data_ptr(), S.data_ptr(), n, None)))
     print("%8d %12.3f %12.3f" % (n, r[0], r[1]), flush=True)
+
+# verification: one per wave vs one per lane
+from _libs import oracle
+import _gen
+O = oracle()
+sigs, pks, msgs = _gen.signatures(O, 4096, msglen=32, seed=b"wprobe-sig", nkeys=64)
+sigs[5, 9] ^= 1
+dsig, dpk = torch.from_numpy(sigs).cuda(), torch.from_numpy(pks).cuda()
+dmsg = torch.from_numpy(np.frombuffer(b"".join(msgs), np.uint8).reshape(4096, 32).copy()).cuda()
+st = torch.empty(4096, dtype=torch.int32, device="cuda")
+print("%8s %12s %12s   verify" % ("n", "wave ms", "lane ms"))
+for lg in (0, 4, 8, 10, 11, 12):
+    n = 1 << lg
+    r = []
+    for mx in (1 << 20, 0):
+        ga.set_wave_batch_max(mx)
+        r.append(timeit(lambda: ga.dev("ed448_verify", st.data_ptr(), dsig.data_ptr(), dpk.data_ptr(), dmsg.data_ptr(), None, 32, 0, None, 0, n, None)))
+        s_ = st[:n].cpu().numpy()
+        assert (s_[np.arange(n) != 5] == -1).all() and (n <= 5 or s_[5] == 0), (mx, n, s_[:8])
+    print("%8d %12.3f %12.3f" % (n, r[0], r[1]), flush=True)
