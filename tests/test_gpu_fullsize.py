@@ -123,10 +123,14 @@ def test_sharded_host_batches_match_single_device(ga, O):
         with pytest.raises(ga.GoldilocksAmdError):
             ga.use_devices([0, 99])                      # not a visible device
         # a single-operation drop-in call still works with sharding configured
-        assert (ga.point_scalarmul(got_fixed[0], s[0]) == want_var[0]).all()
+        assert (ga.point_encode_batch(ga.point_scalarmul(got_fixed[0], s[0]).reshape(1, 32)) ==
+                ga.point_encode_batch(want_var[:1])).all()
     finally:
         ga.use_devices(None)
-    assert (got_fixed == want_fixed).all() and (got_var == want_var).all()
+    # group elements, not raw limbs: a shard of 4 099 operations runs one operation per wave, the
+    # unsharded 12 299 one per lane -- different projective representatives of the same points
+    enc = ga.point_encode_batch
+    assert (got_fixed == want_fixed).all() and (enc(got_var) == enc(want_var)).all()
     assert (got_st == want_st).all() and got_st[5] == 0 and got_st[699] == 0 and (got_st == -1).sum() == 698
     assert (ga.point_encode_batch(got_var[:64]) == _gen.oracle_encode(_gen.oracle_varbase(O, want_fixed[:64], s[:64]))).all()
 
@@ -159,7 +163,7 @@ def test_concurrent_host_threads_on_one_device(ga, O):
     [x.join() for x in th]
     assert not errs, errs
     for t in range(4):
-        assert (got[t][0] == want[t][0]).all() and (got[t][1] == want[t][1]).all()
+        assert (got[t][0] == want[t][0]).all() and (got[t][1] == want[t][1]).all()    # same kernels, same limbs
 
 
 def test_index_independent_tables_match_fast_tables(ga, O):
@@ -279,7 +283,8 @@ def test_batch_output_may_alias_the_base_array(ga, O):
     want = ga.point_scalarmul_batch(bases, s)
     buf = bases.copy()
     rc = ga.lib().goldilocks_448_point_scalarmul_batch(buf.ctypes.data, buf.ctypes.data, s.ctypes.data, n)
-    assert rc == 0 and (buf == want).all()
-    small = bases[:100].copy()
+    enc = ga.point_encode_batch
+    assert rc == 0 and (enc(buf) == enc(want)).all()
+    small = bases[:100].copy()                                     # 100 operations: the one-operation-per-wave path
     assert ga.lib().goldilocks_448_point_scalarmul_batch(small.ctypes.data, small.ctypes.data, s.ctypes.data, 100) == 0
-    assert (small == want[:100]).all()
+    assert (enc(small) == enc(want[:100])).all()
