@@ -137,12 +137,15 @@ def test_verification_through_both_paths(ga, O, paths):
     r = paths(lambda: ga.ed448_verify_batch(sigs, pks, msgs, context=b"ctx"))
     assert (r["wave"] == want).all() and (r["lane"] == want).all()
     assert 0 < (want == -1).sum() < 300
-    cases = json.load(open(os.path.join(G, "f7_verify_torsion.json")))["cases"]
-    f = lambda k: np.array([np.frombuffer(bytes.fromhex(c[k]), np.uint8) for c in cases])
-    fm = [bytes.fromhex(c["msg"]) for c in cases]
-    r = paths(lambda: ga.ed448_verify_batch(f("sig"), f("pk"), fm))
-    verdicts = np.array([c["verdict"] for c in cases])
-    assert (r["wave"] == verdicts).all() and (r["lane"] == verdicts).all()
+    groups = {}
+    for c in json.load(open(os.path.join(G, "f7_verify_torsion.json")))["cases"]:
+        groups.setdefault(c["ctx"], []).append(c)
+    for ctx, cs in groups.items():
+        f = lambda k: np.array([np.frombuffer(bytes.fromhex(c[k]), np.uint8) for c in cs])
+        fm = [bytes.fromhex(c["msg"]) for c in cs]
+        r = paths(lambda: ga.ed448_verify_batch(f("sig"), f("pk"), fm, context=bytes.fromhex(ctx)))
+        verdicts = np.array([c["verdict"] for c in cs])
+        assert (r["wave"] == verdicts).all() and (r["lane"] == verdicts).all()
 
 
 def test_wave_field_arithmetic_against_exact_integers(ga):
