@@ -25,6 +25,42 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_point_scalarmul_wave(uint6
     if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
 }
 
+// combo[i] = s1[i]*b1[i] + s2[i]*b2[i], one operation per wave; b1 == nullptr: b1 is the base point through
+// its window table (goldilocks_448_base_double_scalarmul_non_secret: public scalars by contract).
+// (ref: goldilocks_448_point_double_scalarmul, src/goldilocks.c:467-541, :1260-1330).  out may alias b2.
+extern "C" __global__ void __launch_bounds__(BLOCK) k_double_scalarmul_wave(uint64_t *out, const uint64_t *__restrict__ b1,
+                                                                            const uint64_t *__restrict__ s1, const uint64_t *b2,
+                                                                            const uint64_t *__restrict__ s2, uint32_t n,
+                                                                            const uint4 *__restrict__ bwt) {
+    __shared__ uint32_t s_tab[BLOCK / 64][wc::TABLE_WORDS];
+    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    const wc::Lane L = wc::make_lane();
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    const wc::WaveTable tab{s_tab[w]};
+    uint32_t *bits = s_bits[w];
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + w; op < n; op += nwaves) {   // wave-uniform
+        wc::wfe P = wc::scalarmul(L, tab, bits, wc::load_point(L, b2 + 32 * (size_t)op), sc_load_abi(s2 + 7 * (size_t)op));
+        const sc k1 = sc_load_abi(s1 + 7 * (size_t)op);
+        if (b1) {   // uniform
+            const wc::wfe Q = wc::scalarmul(L, tab, bits, wc::load_point(L, b1 + 32 * (size_t)op), k1);
+            P = wc::add_entry(L, P, wc::to_pniels(L, Q, L.row ^ 1u), false, L.row ^ 1u);
+        } else {
+            const sc r = sc_recode_bwt(k1);
+#pragma unroll
+            for (int k = 0; k < 14; k++) bits[k] = r.w[k];
+            bits[14] = 0;
+            struct Bits {
+                const uint32_t *p;
+                __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
+            } rb{bits};
+            P = wc::add_base_multiple(L, P, rb, bwt);
+        }
+        wc::store_point(L, out + 32 * (size_t)op, P);
+    }
+    if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
+}
+
 // Field-level test hook for the row arithmetic: every wave takes FOUR consecutive elements (one per row).
 //   0 mul  1 strong_reduce (canonical limbs)  2 isr (+ mask)  3 eq (mask)  4 lobit (mask)
 //   5 deserialize: a holds 56 bytes; out = limbs, status = value < p

@@ -191,3 +191,27 @@ def test_wave_field_arithmetic_against_exact_integers(ga):
         rb[i, :7] = np.frombuffer(v.to_bytes(56, "little"), dtype=np.uint64)
     o, s = run(5, rb)
     assert all(raw(o[i]) == vals[i] and (s[i] != 0) == (vals[i] < P) for i in range(len(vals)))
+
+
+def test_double_base_multiplications_through_both_paths(ga, O, paths):
+    """s1*P1 + s2*P2 and s1*B + s2*P2 (what the reference's eddsa.c verification calls), ragged sizes."""
+    import ctypes as C
+    from _libs import Point, Scalar
+    pt = lambda a: a.ctypes.data_as(C.POINTER(Point))
+    sc = lambda a: a.ctypes.data_as(C.POINTER(Scalar))
+    for n in (1, 5, 130):
+        b1 = _gen.oracle_fixed(O, _gen.stream_scalars(n, b"wave/dbl/b1/%d" % n))
+        b2 = _gen.oracle_fixed(O, _gen.stream_scalars(n, b"wave/dbl/b2/%d" % n))
+        s1 = _gen.stream_scalars(n, b"wave/dbl/s1/%d" % n)
+        s2 = _gen.stream_scalars(n, b"wave/dbl/s2/%d" % n)
+        s1[0] = 0
+        s2[n - 1] = _gen.scalars_from_ints([Q - 1])[0]
+        w1, w2 = np.empty((n, 32), np.uint64), np.empty((n, 32), np.uint64)
+        for i in range(n):
+            O.orc_point_double_scalarmul(pt(w1[i]), pt(b1[i]), sc(s1[i]), pt(b2[i]), sc(s2[i]))
+            O.orc_base_double_scalarmul_non_secret(pt(w2[i]), sc(s1[i]), pt(b2[i]), sc(s2[i]))
+        e1, e2 = _gen.oracle_encode(w1), _gen.oracle_encode(w2)
+        r = paths(lambda: (ga.point_encode_batch(ga.point_double_scalarmul_batch(b1, s1, b2, s2)),
+                           ga.point_encode_batch(ga.point_double_scalarmul_batch(None, s1, b2, s2))))
+        for name in ("wave", "lane"):
+            assert (r[name][0] == e1).all() and (r[name][1] == e2).all(), (name, n)
