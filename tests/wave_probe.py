@@ -51,3 +51,17 @@ for lg in (0, 4, 8, 10, 11, 12):
         s_ = st[:n].cpu().numpy()
         assert (s_[np.arange(n) != 5] == -1).all() and (n <= 5 or s_[5] == 0), (mx, n, s_[:8])
     print("%8d %12.3f %12.3f" % (n, r[0], r[1]), flush=True)
+
+# single drop-in calls, wall clock (host launch + sync included)
+import time, ctypes as C
+L_ = ga.lib()
+pt = bases[:1].copy(); sc1 = d["scalar"][:1].copy(); outp = np.zeros((1, 32), np.uint64)
+for mx, name in ((8192, "wave"), (0, "lane")):
+    ga.set_wave_batch_max(mx)
+    for fn, label in ((lambda: L_.goldilocks_448_point_scalarmul(outp.ctypes.data, pt.ctypes.data, sc1.ctypes.data), "point_scalarmul"),
+                      (lambda: L_.goldilocks_448_base_double_scalarmul_non_secret(outp.ctypes.data, sc1.ctypes.data, pt.ctypes.data, sc1.ctypes.data), "base_double_scalarmul"),
+                      (lambda: ga.ed448_verify(sigs[0].tobytes(), pks[0].tobytes(), msgs[0]), "ed448_verify")):
+        fn(); t0 = time.perf_counter()
+        for _ in range(20): fn()
+        print("single call %-24s %-5s %.3f ms" % (label, name, (time.perf_counter() - t0) / 20 * 1e3), flush=True)
+ga.set_wave_batch_max(8192)
