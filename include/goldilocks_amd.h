@@ -309,14 +309,14 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
 GOLDILOCKS_AMD_API int goldilocks_amd_set_table_access(int mode);
 GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the mode in force */
 /* Small batches.  One lane's ladder takes 2.1-2.8 ms however few operations a call has, so batches of
- * up to `n` variable-base multiplications -- and up to min(n, GOLDILOCKS_AMD_WAVE_VERIFY_DEFAULT)
- * verifications (any n above GOLDILOCKS_AMD_WAVE_BATCH_DEFAULT applies to both) -- the single-operation
- * drop-in names included, run ONE OPERATION PER WAVEFRONT instead: the 64 lanes share the operation (a
- * field element spread over the 16 lanes of a row, four field elements per register), 0.35 ms per
- * multiplication call, 0.6 ms per verification call.  Index-independent table access in either table
- * mode.  The defaults are the measured crossovers; 0 disables the path. */
+ * up to `n` variable-base multiplications -- and up to n / 2 verifications or double-base
+ * multiplications -- the single-operation drop-in names included, run ONE OPERATION PER WAVEFRONT
+ * instead: the 64 lanes share the operation (a field element spread over the 16 lanes of a row, four
+ * field elements per register), 0.35 ms per multiplication call, 0.6 ms per verification call.
+ * Index-independent table access in either table mode.  The default is the measured crossover
+ * (profiles/r02/wave_probe.txt); 0 disables the path. */
 #define GOLDILOCKS_AMD_WAVE_BATCH_DEFAULT 8192
-#define GOLDILOCKS_AMD_WAVE_VERIFY_DEFAULT 4096   /* the same path for verification: up to this many per call */
+#define GOLDILOCKS_AMD_WAVE_VERIFY_DEFAULT (GOLDILOCKS_AMD_WAVE_BATCH_DEFAULT / 2)
 GOLDILOCKS_AMD_API void goldilocks_amd_set_wave_batch_max(size_t n);
 GOLDILOCKS_AMD_API size_t goldilocks_amd_get_wave_batch_max(void);
 /* "gfx950", number of CUs, workspace bytes currently held */

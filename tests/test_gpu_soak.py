@@ -92,3 +92,28 @@ def test_soak_x448_and_elligator(ga, O):
         O.orc_point_from_hash_uniform(C.cast(_p(w[i]), C.POINTER(Point)), _p(h[i]))
     sel = np.arange(0, n, 5)
     assert (ga.point_encode_batch(pts[sel]) == _gen.oracle_encode(w[sel])).all()
+
+
+def test_soak_wave_path(ga, O, table_mode):
+    """The one-operation-per-wave kernels at their largest batch: 8192 random variable-base multiplications
+    and 4096 verifications (a quarter corrupted) against the oracle."""
+    if table_mode == "lane_kernels_only":
+        pytest.skip("this test is about the wave path")
+    n = ga.get_wave_batch_max()
+    assert n == 8192
+    k = _gen.stream_scalars(n, SEED + b"soak/wave/base")
+    s = _gen.stream_scalars(n, SEED + b"soak/wave/scalar")
+    bases = _gen.oracle_fixed(O, k)
+    got = ga.point_scalarmul_batch(bases, s)
+    assert (ga.point_encode_batch(got) == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all()
+    m = n // 2
+    sigs, pks, msgs = _gen.signatures(O, m, msglen=33, seed=SEED + b"soak/wave/sig", nkeys=97, context=b"w")
+    rng = np.random.default_rng(17)
+    bad = rng.random(m) < 0.25
+    sigs[bad, rng.integers(0, 114, bad.sum())] ^= (1 << rng.integers(0, 8, bad.sum())).astype(np.uint8)
+    st = ga.ed448_verify_batch(sigs, pks, msgs, context=b"w")
+    want = np.empty(m, np.int32)
+    msg_arr = np.frombuffer(b"".join(msgs), np.uint8).reshape(m, 33).copy()
+    ctx = (C.c_uint8 * 1).from_buffer_copy(b"w")
+    O.orc_ed448_verify_batch(_p(want), _p(sigs), _p(pks), _p(msg_arr), 33, 0, ctx, 1, m, _gen.NTHREADS)
+    assert (st == want).all() and (st[~bad] == -1).all() and (st == 0).sum() >= bad.sum() - 4
