@@ -456,6 +456,8 @@ extern "C" __global__ void k_point_scalarmul_wave(uint64_t *out, const uint64_t 
 extern "C" __global__ void k_double_scalarmul_wave(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                                    const uint4 *__restrict__ bwt);
+extern "C" __global__ void k_x448_wave(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
+                                       const uint8_t *__restrict__ scalar, uint32_t n);
 extern "C" __global__ void k_wave_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, const uint64_t *__restrict__ a,
                                            const uint64_t *__restrict__ b, uint32_t n, int op);
 extern "C" __global__ void k_ed448_verify_wave(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,

@@ -61,6 +61,22 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_double_scalarmul_wave(uint
     if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
 }
 
+// shared[i] = X448(scalar[i], base[i]), one ladder per wave   (ref: goldilocks_x448, src/goldilocks.c:1006-1076)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_x448_wave(uint8_t *__restrict__ shared, int32_t *__restrict__ status,
+                                                                const uint8_t *__restrict__ base,
+                                                                const uint8_t *__restrict__ scalar, uint32_t n) {
+    const wc::Lane L = wc::make_lane();
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); op < n; op += nwaves) {   // wave-uniform
+        uint32_t k[14];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(scalar + 56 * (size_t)op);
+#pragma unroll
+        for (int j = 0; j < 14; j++) k[j] = src[j];
+        const bool ok = wc::x448(L, shared + 56 * (size_t)op, base + 56 * (size_t)op, k);
+        if (status && (threadIdx.x & 63u) == 0) status[op] = ok ? -1 : 0;
+    }
+}
+
 // Field-level test hook for the row arithmetic: every wave takes FOUR consecutive elements (one per row).
 //   0 mul  1 strong_reduce (canonical limbs)  2 isr (+ mask)  3 eq (mask)  4 lobit (mask)
 //   5 deserialize: a holds 56 bytes; out = limbs, status = value < p

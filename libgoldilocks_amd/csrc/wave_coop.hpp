@@ -449,5 +449,75 @@ __device__ __forceinline__ bool verify(const Lane &L, const WaveTable &tab, uint
     return ok && same;
 }
 
+// ---------------------------------------------------------------- X448 (RFC 7748), one ladder per wave
+
+// 56 canonical bytes of the element held by row K, written by that row's even lanes (7 bytes per limb pair)
+template <int K>
+__device__ __forceinline__ void store_bytes(const Lane &L, uint8_t *out, wfe canonical) {
+    const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)canonical, 0x101, 0xF, 0xF, false);   // lane l+1's limb
+    const uint64_t w56 = (uint64_t)canonical | ((uint64_t)nb << 28);
+    if (L.row == K && !(L.i & 1u)) {
+        uint8_t *q = out + 7 * (L.i >> 1);
+#pragma unroll
+        for (int k = 0; k < 7; k++) q[k] = (uint8_t)(w56 >> (8 * k));
+    }
+}
+// 1/x in every row (0 -> 0)   (cf. gf_invert, src/goldilocks.c:69-80)
+__device__ __forceinline__ wfe invert(const Lane &L, wfe x) {
+    bool ok;
+    const wfe xr = weak(L, x);
+    const wfe t = isr(L, mul(L, xr, xr), ok);
+    return mul(L, mul(L, t, t), xr);
+}
+
+// The Montgomery ladder of src/goldilocks.c:1006-1076 with the state (x2, z2, x3, z3) in the four rows
+// of one register: a step is three vector multiplications -- (A^2, B^2, D*A, C*B), then
+// (AA*BB, E*(AA + a24 E), (DA+CB)^2, (DA-CB)^2), then the x1 factor of z3 -- and two row exchanges.
+// Signs: rows 1 and 3 carry -B and -CB (the differences taken the other way round), which squares and
+// the paired products absorb.  scalar: 14 words as given (clamped here).  Returns false iff the result is 0.
+__device__ __forceinline__ bool x448(const Lane &L, uint8_t *out56, const uint8_t *base56, const uint32_t (&k)[14]) {
+    bool below;
+    const wfe x1 = deserialize(L, base56, below);        // the reference ignores the range check too (:1014)
+    const wfe x1row = L.row == 3 ? x1 : one(L);           // third product: (1, 1, 1, x1)
+    wfe S = L.row == 0 ? one(L) : (L.row == 1 ? 0u : (L.row == 2 ? x1 : one(L)));   // (1, 0, x1, 1)
+    bool swap = false;
+#pragma unroll 1
+    for (int t = 447; t >= 0; t--) {
+        uint32_t w = 0;                                   // word t >> 5 of the scalar: a uniform select chain keeps k in registers
+#pragma unroll
+        for (int j = 0; j < 14; j++) w = (t >> 5) == j ? k[j] : w;
+        uint32_t bit = (w >> (t & 31)) & 1u;
+        if (t < 2) bit = 0;                               // scalar[0] &= -COFACTOR
+        if (t == 447) bit = 1;                            // top bit forced
+        const bool kt = bit != 0, sw = swap != kt;
+        swap = kt;
+        const wfe other = rows(L, S, L.row ^ 2u);         // (x3, z3, x2, z2)
+        S = sw ? other : S;
+        const wfe partner = rows(L, S, L.row ^ 1u);       // (z2, x2, z3, x3)
+        const wfe sum = S + partner;                      // (A, A, C, C)                mag 2
+        const wfe diff = sub<2>(L, S, partner);           // (B, -B, D, -D)              mag 3
+        const wfe a1 = (L.row == 0 || L.row == 3) ? sum : diff;          // (A, -B, D, C)
+        const wfe kk = (L.row & 1u) ? weak(L, diff) : sum;               // rows 0, 1: (A, -B)
+        const wfe b1 = rows(L, kk, L.row & 1u);                          // (A, -B, A, -B)
+        const wfe r1 = mul(L, a1, b1);                                   // (AA, BB, DA, -CB)
+        const wfe p1 = rows(L, r1, L.row ^ 1u);                          // (BB, AA, -CB, DA)
+        const wfe s2 = r1 + p1;                                          // (., ., DA-CB, DA-CB)       mag 2
+        const wfe d2 = weak(L, sub<2>(L, r1, p1));                       // (E, -E, DA+CB, -(DA+CB))   mag 1
+        const wfe f = sub<2>(L, mulw(L, d2, 39081), p1);                 // row 1: a24*(-E) - AA       mag 3
+        const wfe a2 = L.row == 0 ? r1 : (L.row == 3 ? s2 : d2);         // (AA, -E, DA+CB, DA-CB)
+        const wfe b2 = L.row == 0 ? p1 : (L.row == 1 ? f : (L.row == 2 ? d2 : s2));   // (BB, -(AA+a24 E), DA+CB, DA-CB)
+        const wfe r2 = mul(L, a2, b2);                                   // (x2', z2', x3', (DA-CB)^2)
+        S = mul(L, r2, x1row);                                           // z3' = x1 (DA-CB)^2
+    }
+    const wfe fin = rows(L, S, L.row ^ 2u);
+    S = swap ? fin : S;                                   // rows 0, 1: the result x2 / z2
+    const wfe zi = invert(L, from_row<1>(L, S));
+    const wfe r = strong(L, mul(L, from_row<0>(L, S), zi));
+    store_bytes<0>(L, out56, r);
+    uint32_t nz = r;
+    nz |= ror<8>(nz); nz |= ror<4>(nz); nz |= ror<2>(nz); nz |= ror<1>(nz);
+    return __builtin_amdgcn_readfirstlane(nz) != 0;       // row 0
+}
+
 }  // namespace wc
 }  // namespace gd

@@ -215,3 +215,26 @@ def test_double_base_multiplications_through_both_paths(ga, O, paths):
                            ga.point_encode_batch(ga.point_double_scalarmul_batch(None, s1, b2, s2))))
         for name in ("wave", "lane"):
             assert (r[name][0] == e1).all() and (r[name][1] == e2).all(), (name, n)
+
+
+def test_x448_through_both_paths(ga, O, paths):
+    """goldilocks_x448 with a peer's point: one Montgomery ladder per wave against one per lane, random
+    inputs, low-order and non-canonical u-coordinates (results 0 -> FAILURE), ragged sizes."""
+    import ctypes as C
+    from _libs import P
+    special = [0, 1, P - 1, P, P + 1, 2**448 - 1, 5]
+    for n in (1, 7, 200):
+        sc_ = np.frombuffer(_gen.stream(b"wave/x448/s/%d" % n, 56 * n), np.uint8).reshape(n, 56).copy()
+        u = np.frombuffer(_gen.stream(b"wave/x448/u/%d" % n, 56 * n), np.uint8).reshape(n, 56).copy()
+        for i, v in enumerate(special[:n]):
+            u[i] = np.frombuffer(v.to_bytes(56, "little"), np.uint8)
+        want, want_st = np.empty((n, 56), np.uint8), np.empty(n, np.int32)
+        for i in range(n):
+            w = (C.c_uint8 * 56)()
+            want_st[i] = O.orc_x448(w, u[i].ctypes.data_as(C.c_void_p), sc_[i].ctypes.data_as(C.c_void_p))
+            want[i] = np.frombuffer(bytes(w), np.uint8)
+        r = paths(lambda: ga.x448_batch(sc_, u))
+        for name in ("wave", "lane"):
+            got, st = r[name]
+            assert (st == want_st).all(), (name, n)
+            assert (got == want).all(), (name, n)
