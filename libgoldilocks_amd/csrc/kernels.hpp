@@ -458,6 +458,14 @@ extern "C" __global__ void k_double_scalarmul_wave(uint64_t *out, const uint64_t
                                                    const uint4 *__restrict__ bwt);
 extern "C" __global__ void k_x448_wave(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
                                        const uint8_t *__restrict__ scalar, uint32_t n);
+extern "C" __global__ void k_precomputed_scalarmul_wave(uint64_t *__restrict__ out, const uint4 *__restrict__ comb,
+                                                        const uint64_t *__restrict__ scalar, uint32_t n);
+extern "C" __global__ void k_derive_wave(uint8_t *__restrict__ out, const uint8_t *__restrict__ sk, uint32_t n,
+                                         const uint4 *__restrict__ comb, int x448_keygen);
+extern "C" __global__ void k_ed448_sign_wave(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,
+                                             const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
+                                             uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
+                                             uint32_t n, const uint4 *__restrict__ comb);
 extern "C" __global__ void k_wave_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, const uint64_t *__restrict__ a,
                                            const uint64_t *__restrict__ b, uint32_t n, int op);
 extern "C" __global__ void k_ed448_verify_wave(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,

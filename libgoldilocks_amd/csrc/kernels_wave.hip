@@ -77,6 +77,70 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_x448_wave(uint8_t *__restr
     }
 }
 
+// scaled[i] = scalar[i] * G, G given by a comb table in this library's form   (ref: goldilocks_448_precomputed_scalarmul)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_precomputed_scalarmul_wave(uint64_t *__restrict__ out,
+                                                                                 const uint4 *__restrict__ comb,
+                                                                                 const uint64_t *__restrict__ scalar, uint32_t n) {
+    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    const wc::Lane L = wc::make_lane();
+    const uint32_t w = threadIdx.x >> 6, nwaves = gridDim.x * (BLOCK / 64);
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + w; op < n; op += nwaves) {   // wave-uniform
+        const sc k = sc_load_abi(scalar + 7 * (size_t)op);
+        wc::store_point(L, out + 32 * (size_t)op, wc::comb_scalarmul(L, comb, wc::put_bits(s_bits[w], sc_recode_signed(k))));
+    }
+    if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
+}
+
+// pk[i] = derive_public_key(sk[i]) / out[i] = x448_derive_public_key(scalar[i]), one per wave
+extern "C" __global__ void __launch_bounds__(BLOCK) k_derive_wave(uint8_t *__restrict__ out, const uint8_t *__restrict__ sk,
+                                                                  uint32_t n, const uint4 *__restrict__ comb, int x448_keygen) {
+    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    __shared__ uint32_t s_stage[34 * BLOCK];
+    const wc::Lane L = wc::make_lane();
+    const uint32_t w = threadIdx.x >> 6, nwaves = gridDim.x * (BLOCK / 64);
+    LdsStage stage{s_stage + threadIdx.x};
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + w; op < n; op += nwaves) {   // wave-uniform
+        if (x448_keygen) {   // uniform
+            uint32_t k[14];
+            const uint32_t *src = reinterpret_cast<const uint32_t *>(sk + 56 * (size_t)op);
+#pragma unroll
+            for (int j = 0; j < 14; j++) k[j] = src[j];
+            const wc::wfe P = wc::comb_scalarmul(L, comb, wc::put_bits(s_bits[w], sc_recode_signed(x448_public_scalar(k))));
+            wc::encode_x448(L, out + 56 * (size_t)op, P);
+        } else {
+            wc::derive(L, out + 57 * (size_t)op, sk + 57 * (size_t)op, comb, s_bits[w], stage);
+        }
+    }
+    if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
+    lds_wipe_lane(s_stage + threadIdx.x, 34);
+}
+
+// sig[i] = sign(sk[i], pk[i], msg[i]), one signature per wave   (ref: goldilocks_ed448_sign)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_ed448_sign_wave(
+    uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
+    const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx,
+    uint32_t ctx_len, uint32_t n, const uint4 *__restrict__ comb) {
+    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    __shared__ uint32_t s_stage[34 * BLOCK];
+    __shared__ uint8_t s_bytes[BLOCK / 64][128];
+    const wc::Lane L = wc::make_lane();
+    const uint32_t w = threadIdx.x >> 6, nwaves = gridDim.x * (BLOCK / 64);
+    LdsStage stage{s_stage + threadIdx.x};
+    for (uint32_t i = blockIdx.x * (BLOCK / 64) + w; i < n; i += nwaves) {   // wave-uniform
+        const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
+        const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
+        const bool fits = len64 < MAX_MESSAGE_BYTES;
+        wc::sign(L, sig + 114 * (size_t)i, sk + 57 * (size_t)i, pk + 57 * (size_t)i, msg, fits ? (uint32_t)len64 : 0u, prehashed,
+                 ctx, ctx_len, comb, s_bits[w], s_bytes[w], stage);
+        if (!fits && (threadIdx.x & 63u) < 57) {
+            sig[114 * (size_t)i + (threadIdx.x & 63u)] = 0;
+            sig[114 * (size_t)i + 57 + (threadIdx.x & 63u)] = 0;
+        }
+    }
+    if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
+    lds_wipe_lane(s_stage + threadIdx.x, 34);
+}
+
 // Field-level test hook for the row arithmetic: every wave takes FOUR consecutive elements (one per row).
 //   0 mul  1 strong_reduce (canonical limbs)  2 isr (+ mask)  3 eq (mask)  4 lobit (mask)
 //   5 deserialize: a holds 56 bytes; out = limbs, status = value < p

@@ -519,5 +519,134 @@ __device__ __forceinline__ bool x448(const Lane &L, uint8_t *out56, const uint8_
     return __builtin_amdgcn_readfirstlane(nz) != 0;       // row 0
 }
 
+// ---------------------------------------------------------------- fixed base: the 5x5x18 comb, key derivation, signing
+
+// scalar * G through a comb table in this library's niels form (80 entries x 48 words, global memory, as
+// k_import_comb leaves it): the loop of ladder_comb (src/goldilocks.c:830-877); every lookup reads the 16
+// entries of its comb (one word per lane each) and keeps one -- index-independent, whatever the table mode.
+template <class BITS>
+__device__ __forceinline__ wfe comb_scalarmul(const Lane &L, const uint4 *comb, const BITS &bits) {
+    const uint32_t swap_row = L.row ^ 1u;
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(comb);
+    wfe acc = identity(L);
+#pragma unroll 1
+    for (int i = 17; i >= 0; i--) {
+        if (i != 17) acc = dbl(L, acc);
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) {
+            uint32_t idx;
+            bool neg;
+            signed_digit(comb_teeth(bits, i, j), idx, neg);
+            const uint32_t frow = (neg && L.row < 2) ? (L.row ^ 1u) : L.row;
+            const uint32_t *q = tab + 48 * 16 * j + (frow < 3 ? frow : 0u) * 16 + L.i;
+            wfe r = q[0];
+#pragma unroll
+            for (int k = 1; k < 16; k++) {
+                const wfe v = q[48 * k];
+                r = idx == (uint32_t)k ? v : r;
+            }
+            const wfe ev = L.row == 3 ? (L.i == 0 ? 1u : 0u) : r;       // affine entries: z = 1
+            acc = add_entry(L, acc, ev, neg, swap_row);
+        }
+    }
+    return acc;
+}
+
+// RFC 8032 encoding of 4*P (cf. pt_encode_eddsa_words, src/goldilocks.c:905-946): 57 bytes at out (any
+// address space).  The squares of the dual isogeny are the first half of a doubling.
+__device__ __forceinline__ void encode_eddsa(const Lane &L, uint8_t *out57, wfe P) {
+    const wfe x = from_row<0>(L, P), y = from_row<1>(L, P);
+    const wfe v1 = L.row == 3 ? x + y : P;
+    const wfe q = mul(L, v1, v1);                           // (X^2, Y^2, Z^2, (X+Y)^2)
+    const wfe c = from_row<0>(L, q), a = from_row<1>(L, q), zz = from_row<2>(L, q), ss = from_row<3>(L, q);
+    const wfe u = c + a;                                    // mag 2
+    const wfe yy = weak(L, sub<4>(L, ss, u));               // 2XY
+    const wfe z = weak(L, sub<2>(L, a, c));                 // Y^2 - X^2
+    const wfe tt = weak(L, sub<2>(L, zz + zz, z));          // 2Z^2 - (Y^2 - X^2)
+    const wfe av = L.row == 0 ? tt : u;                     // (tt, u, u, .)
+    const wfe bv = L.row == 0 ? yy : (L.row == 1 ? z : tt); // (yy, z, tt, .)
+    const wfe n = mul(L, av, bv);                           // (xn, yn, zn, .)
+    const wfe zi = invert(L, from_row<2>(L, n));
+    const wfe aff = mul(L, n, zi);                          // (x, y, 1, .) affine
+    const wfe can = strong(L, aff);
+    store_bytes<1>(L, out57, can);
+    const uint32_t sign = __builtin_amdgcn_readfirstlane(can) & 1u;   // row 0, limb 0: lobit(x)
+    if ((threadIdx.x & 63u) == 0) out57[56] = (uint8_t)(sign << 7);
+}
+// (y/x)^2 serialized (cf. x448_public_finish, src/goldilocks.c:1102-1113)
+__device__ __forceinline__ void encode_x448(const Lane &L, uint8_t *out56, wfe P) {
+    const wfe xi = invert(L, from_row<0>(L, P));
+    const wfe r = mul(L, from_row<1>(L, P), xi);
+    store_bytes<0>(L, out56, strong(L, mul(L, r, r)));
+}
+
+struct WaveBits {   // the wave's recoded scalar in LDS
+    const uint32_t *p;
+    __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
+};
+__device__ __forceinline__ WaveBits put_bits(uint32_t *bits, const sc &r) {
+#pragma unroll
+    for (int k = 0; k < 14; k++) bits[k] = r.w[k];
+    bits[14] = 0;
+    return WaveBits{bits};
+}
+
+// pk = encode((clamp(SHAKE256(sk)[0:57]) / 4) * B)   (cf. ed448_derive_core, src/eddsa.c:98-147)
+template <class STAGE>
+__device__ __forceinline__ void derive(const Lane &L, uint8_t *pk57, const uint8_t *sk57, const uint4 *comb, uint32_t *bits,
+                                       STAGE &stage) {
+    Ed448Msg m;
+    m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
+    m.ctx = sk57; m.ctxlen = 0; m.ph = 0; m.dom = false;
+    uint32_t w[29];
+    shake256_114(w, m, 57, stage);
+    ed448_clamp_words(w);
+    const sc secret = sc_halve(sc_halve(sc_decode_long_words<57>(w)));
+    encode_eddsa(L, pk57, comb_scalarmul(L, comb, put_bits(bits, sc_recode_signed(secret))));
+}
+
+// RFC 8032 signature (cf. ed448_sign_core, src/eddsa.c:149-230).  lds57: two 64-byte LDS buffers of this
+// wave, for the hashed-key seed and for R (both are hashed again).
+template <class STAGE>
+__device__ __forceinline__ void sign(const Lane &L, uint8_t *sig114, const uint8_t *sk57, const uint8_t *pk57, const uint8_t *msg,
+                                     uint32_t msglen, uint32_t ph, const uint8_t *ctx, uint32_t ctxlen, const uint4 *comb,
+                                     uint32_t *bits, uint8_t *lds128, STAGE &stage) {
+    uint8_t *seed = lds128, *rbytes = lds128 + 64;
+    Ed448Msg m;
+    m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
+    m.ctx = ctx; m.ctxlen = 0; m.ph = 0; m.dom = false;
+    uint32_t w[29];
+    shake256_114(w, m, 57, stage);                             // expanded = secret(57) | seed(57)
+    for (int i = 0; i < 57; i++) seed[i] = (uint8_t)(w[(57 + i) >> 2] >> (8 * ((57 + i) & 3)));   // every lane, same bytes
+    uint32_t sw[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) sw[i] = w[i];
+    ed448_clamp_words(sw);
+    const sc secret = sc_decode_long_words<57>(sw);
+    m.a = seed; m.alen = 57; m.blen = 0; m.msg = msg; m.msglen = msglen;
+    m.ctx = ctx; m.ctxlen = ctxlen; m.ph = ph ? 1u : 0u; m.dom = true;
+    shake256_114(w, m, m.total(), stage);
+    const sc nonce = sc_decode_long_words<114>(w);
+    const wfe R = comb_scalarmul(L, comb, put_bits(bits, sc_recode_signed(sc_halve(sc_halve(nonce)))));
+    encode_eddsa(L, rbytes, R);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const Ed448Msg c = ed448_challenge_string(rbytes, pk57, msg, msglen, ph, ctx, ctxlen);
+    shake256_114(w, c, c.total(), stage);
+    const sc challenge = sc_decode_long_words<114>(w);
+    const sc resp = sc_add(sc_mul(challenge, secret), nonce);
+    const uint32_t l = threadIdx.x & 63u;
+    if (l < 57) sig114[l] = rbytes[l];
+    if (l == 56) sig114[113] = 0;
+    // S: 56 bytes of resp + a zero byte; lane l writes byte l (the words are the same in every lane)
+    uint32_t word = 0;
+#pragma unroll
+    for (int j = 0; j < 14; j++) word = (l >> 2) == (uint32_t)j ? resp.w[j] : word;
+    if (l < 56) sig114[57 + l] = (uint8_t)(word >> (8 * (l & 3)));
+    // the seed does not stay behind
+    if (l < 16) reinterpret_cast<uint32_t *>(seed)[l] = 0;
+}
+
 }  // namespace wc
 }  // namespace gd

@@ -238,3 +238,50 @@ def test_x448_through_both_paths(ga, O, paths):
             got, st = r[name]
             assert (st == want_st).all(), (name, n)
             assert (got == want).all(), (name, n)
+
+
+def test_fixed_base_keygen_and_signing_through_both_paths(ga, O, paths):
+    """precomputed_scalarmul (built-in and caller table), ed448 derive_public_key / sign, x448 key generation:
+    one operation per wave against the lane kernels and the oracle, RFC 8032's vectors included."""
+    import ctypes as C
+    import hashlib
+    import json
+    _p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for n in (1, 6, 150):
+        k = _gen.stream_scalars(n, b"wave/fixed/k/%d" % n)
+        k[0] = 0
+        want = _gen.oracle_encode(_gen.oracle_fixed(O, k))
+        other = ga.precompute(_gen.oracle_fixed(O, _gen.stream_scalars(1, b"wave/fixed/pt"))[0])
+        want2 = _gen.oracle_encode(_gen.oracle_fixed(O, k, table=other))
+        sk = np.frombuffer(_gen.stream(b"wave/fixed/sk/%d" % n, 57 * n), np.uint8).reshape(n, 57).copy()
+        xs = np.frombuffer(_gen.stream(b"wave/fixed/xs/%d" % n, 56 * n), np.uint8).reshape(n, 56).copy()
+        msgs = [_gen.stream(b"wave/fixed/msg/%d/%d" % (n, i), (i * 37) % 300) for i in range(n)]      # ragged, up to 3 blocks
+        want_pk = np.empty((n, 57), np.uint8)
+        O.orc_ed448_derive_public_key_batch(_p(want_pk), _p(sk), n, _gen.NTHREADS)
+        want_sig, want_x = np.empty((n, 114), np.uint8), np.empty((n, 56), np.uint8)
+        ctx = (C.c_uint8 * 3).from_buffer_copy(b"abc")
+        for i in range(n):
+            m = (C.c_uint8 * max(1, len(msgs[i]))).from_buffer_copy(msgs[i] or b"\0")
+            O.orc_ed448_sign(_p(want_sig[i]), _p(sk[i]), _p(want_pk[i]), m, len(msgs[i]), 0, ctx, 3)
+            O.orc_x448_derive_public_key(_p(want_x[i]), _p(xs[i]))
+
+        def body():
+            pk = ga.ed448_derive_public_key_batch(sk)
+            return dict(fixed=ga.point_encode_batch(ga.precomputed_scalarmul_batch(k)),
+                        fixed2=ga.point_encode_batch(ga.precomputed_scalarmul_batch(k, table=other)),
+                        pk=pk, sig=ga.ed448_sign_batch(sk, pk, msgs, context=b"abc"), x=ga.x448_batch(xs)[0])
+        for name, r in paths(body).items():
+            assert (r["fixed"] == want).all() and (r["fixed2"] == want2).all(), (name, n)
+            assert (r["pk"] == want_pk).all(), (name, n)
+            assert (r["sig"] == want_sig).all(), (name, n)
+            assert (r["x"] == want_x).all(), (name, n)
+    for c in json.load(open(os.path.join(G, "kats.json")))["rfc8032_ed448"]:
+        msg = bytes.fromhex(c["message"])
+        if c["prehashed"]:
+            msg = hashlib.shake_256(msg).digest(64)
+        sk1 = np.frombuffer(bytes.fromhex(c["sk"]), np.uint8).reshape(1, 57)
+        r = paths(lambda: (ga.ed448_derive_public_key_batch(sk1),
+                           ga.ed448_sign_batch(sk1, np.frombuffer(bytes.fromhex(c["pk"]), np.uint8).reshape(1, 57), [msg],
+                                               prehashed=bool(c["prehashed"]), context=bytes.fromhex(c["context"]))))
+        for name in ("wave", "lane"):
+            assert r[name][0].tobytes().hex() == c["pk"] and r[name][1].tobytes().hex() == c["sig"], name
