@@ -65,3 +65,21 @@ for mx, name in ((8192, "wave"), (0, "lane")):
         for _ in range(20): fn()
         print("single call %-24s %-5s %.3f ms" % (label, name, (time.perf_counter() - t0) / 20 * 1e3), flush=True)
 ga.set_wave_batch_max(8192)
+
+# the other single calls
+sk1 = np.frombuffer(_gen.stream(b"wprobe/sk", 57), np.uint8).reshape(1, 57).copy()
+xs1 = np.frombuffer(_gen.stream(b"wprobe/x", 56), np.uint8).reshape(1, 56).copy()
+pk1 = ga.ed448_derive_public_key_batch(sk1)
+pub1, _ = ga.x448_batch(xs1)
+k1 = d["scalar"][:1].copy()
+for mx, name in ((8192, "wave"), (0, "lane")):
+    ga.set_wave_batch_max(mx)
+    for fn, label in ((lambda: ga.precomputed_scalarmul_batch(k1), "precomputed_scalarmul"),
+                      (lambda: ga.ed448_derive_public_key_batch(sk1), "ed448_derive_public_key"),
+                      (lambda: ga.ed448_sign_batch(sk1, pk1, [b"hello"]), "ed448_sign"),
+                      (lambda: ga.x448_batch(xs1), "x448_derive_public_key"),
+                      (lambda: ga.x448_batch(xs1, pub1), "x448")):
+        fn(); t0 = time.perf_counter()
+        for _ in range(20): fn()
+        print("single call %-24s %-5s %.3f ms" % (label, name, (time.perf_counter() - t0) / 20 * 1e3), flush=True)
+ga.set_wave_batch_max(8192)
