@@ -25,6 +25,10 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
     FixedBwt<GlobalBwt> b_tab{bwt_tab};
     LdsStage stage{s_stage + threadIdx.x};
     LdsMkBits mk{s_bits + threadIdx.x};
+    // One exponentiation per signature: each verification hands a pending quotient to the next one this
+    // lane handles (ed448_verify_chained, eddsa.hpp).
+    VerifyPending pend;
+    verify_pending_clear(pend);
     for (uint32_t i = lane; i < n; i += stride) {
         const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
         const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
@@ -32,8 +36,16 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
         const uint32_t mlen = fits ? (uint32_t)len64 : 0u;
         Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx,
                                             ctx_len);
-        bool ok = ed448_verify_core(m, b_tab, a_tab, stage, mk);
-        status[i] = ok && fits ? -1 : 0;
+        uint32_t done_index[2];
+        bool done_ok[2];
+        const int nd = ed448_verify_chained(m, i, pend, b_tab, a_tab, stage, mk, done_index, done_ok);
+        if (!fits) pend.ok = false;
+        for (int k = 0; k < nd; k++) status[done_index[k]] = done_ok[k] && (done_index[k] != i || fits) ? -1 : 0;
+    }
+    if (pend.live) {
+        uint32_t idx;
+        const bool v = ed448_verify_chain_flush(pend, idx);
+        status[idx] = v ? -1 : 0;
     }
 }
 

@@ -228,6 +228,36 @@ int hs_ed448_verify(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, s
     return ed448_verify_lane(sig, pk, msg, msglen, prehashed, ctx, ctxlen, fb, ta) ? -1 : 0;
 }
 
+// n signatures through the chained verification of one lane (one exponentiation per signature; the
+// last one flushed with a plain inversion): status[i] = -1 / 0.  Message i = msgs[msg_off[i] .. msg_off[i+1]).
+void hs_ed448_verify_chain(int32_t *status, const uint8_t *sig, const uint8_t *pk, const uint8_t *msgs, const uint64_t *msg_off,
+                           uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, size_t n, const uint64_t *comb_table) {
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    FixedComb<HostComb> fb{comb};
+    HostTable ta;
+    HostStage stage;
+    HostMkBits mk;
+    VerifyPending pend;
+    verify_pending_clear(pend);
+    for (size_t i = 0; i < n; i++) {
+        Ed448Msg m = ed448_challenge_string(sig + 114 * i, pk + 57 * i, msgs + msg_off[i], (uint32_t)(msg_off[i + 1] - msg_off[i]),
+                                            prehashed, ctx, ctxlen);
+        uint32_t done_index[2];
+        bool done_ok[2];
+        const int nd = ed448_verify_chained(m, (uint32_t)i, pend, fb, ta, stage, mk, done_index, done_ok);
+        for (int k = 0; k < nd; k++) status[done_index[k]] = done_ok[k] ? -1 : 0;
+    }
+    if (pend.live) {
+        uint32_t idx;
+        const bool v = ed448_verify_chain_flush(pend, idx);
+        status[idx] = v ? -1 : 0;
+    }
+}
+
+void hs_mac_counter_reset(void) { gf_mac_counter() = 0; }
+unsigned long long hs_mac_counter_get(void) { return gf_mac_counter(); }
+
 void hs_ed448_derive_public_key(uint8_t *pk, const uint8_t *sk, const uint64_t *comb_table) {
     static HostComb comb;
     for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
