@@ -61,9 +61,9 @@ WORKLOADS = {
     "base": dict(metric="Ed448 base-point scalarmuls/sec", unit="scalarmuls/s", bytes=312, macs=36_480,
                  macs_index_independent=138_848,
                  desc="goldilocks_448_precomputed_scalarmul(precomputed_base), 16-bit window table"),
-    # ONE exponentiation (the key's decoding, sharing it with the previous signature's 1/K) + variable-base
-    # ladder + 28 base-point additions + the L^2 v == K^2 u test: steady state of a lane's chain
-    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=766_184,
+    # half-size scalars (csrc/lattice.hpp): two decodings + two window tables + one 46-window ladder over both
+    # points (the average longest pair of a wave; 8 864 MACs per window) + 28 base-point additions
+    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=618_808,
                    desc="goldilocks_ed448_verify, 32-byte messages, 1% corrupted"),
     "sign": dict(metric="Ed448 signatures/sec", unit="signatures/s", bytes=260, macs=None,
                  desc="goldilocks_ed448_sign, 32-byte messages, no context"),

@@ -7,6 +7,7 @@
 // (src/goldilocks.c:1260-1330); only accept/reject is observable, so the lanes run
 // the lane-uniform fixed-window double-base ladder instead (no divergence).
 #pragma once
+#include "lattice.hpp"
 #include "scalarmul.hpp"
 
 namespace gd {
@@ -445,6 +446,81 @@ GD_FN bool ed448_verify_chain_flush(VerifyPending &pend, uint32_t &done_index) {
     return v;
 }
 
+// ------------------------------------------------------------------ verification with half-size scalars
+// (lattice.hpp)  Accept iff  V = (|tau| S)*B + rho*PA + |tau|*PR  lies in the 2-torsion point_eq quotients by
+// (V.x == 0), with (rho, tau) the short pair of the challenge, PA = -+A by the sign of tau, PR = -R: both
+// variable points share one ladder of about 45 windows instead of A alone taking 90.  An even rho is
+// walked as rho + 1 and one subtraction of PA (signed odd digits represent odd integers only; the scalars
+// act as INTEGERS here, not mod q, because A and R may carry torsion).
+// WAVEMAX: wavemax(x) = the largest x of the wave (the window count must be uniform); identity on the host.
+// MKBITS: mkbits.words(w15, slot) turns 15 words into a BITS reader.
+template <class FB, class AT, class STAGE, class MKBITS, class WAVEMAX>
+GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &r_tab, STAGE &stage, MKBITS &mkbits,
+                                const WAVEMAX &wavemax) {
+    uint32_t w[29];
+    shake256_114(w, m, m.total(), stage);
+    const sc h = sc_decode_long_words<114>(w);                                // the challenge, mod q
+    load_bytes_as_words(w, m.a + 57, 57, 15);
+    const sc response = sc_decode_long_words<57>(w);                          // S mod q, no range check
+    wide15 rho;
+    int8w tau;
+#if defined(GD_LATTICE_FAKE)   // timing experiment only: a pair of the right size without the reduction (wrong verdicts)
+#pragma unroll
+    for (int i = 0; i < 15; i++) rho.w[i] = i < 7 ? h.w[i] : 0u;
+#pragma unroll
+    for (int i = 0; i < 8; i++) tau.w[i] = i < 7 ? h.w[i + 7] | 1u : 0u;
+#else
+    half_size_pair(rho, tau, h);
+#endif
+    const bool tau_pos = !is_negative(tau);
+    const sc tau_mag = magnitude_as_scalar(tau);
+    const bool rho_even = (rho.w[0] & 1u) == 0;
+    rho.w[0] |= 1u;                                                           // rho + 1 when even; fixed up below
+    wide15 tw;
+#pragma unroll
+    for (int i = 0; i < 15; i++) tw.w[i] = i < 14 ? tau_mag.w[i] : 0u;
+    const int bl_r = bitlen15(rho), bl_t = bitlen15(tw);
+    const int nw = wavemax(((bl_r > bl_t ? bl_r : bl_t) + 4) / 5);            // >= 1: tau is odd, hence nonzero
+
+    bool ok;
+    {
+        pt A;
+        load_bytes_as_words(w, m.b, 57, 15);                                  // public key
+        ok = pt_decode_eddsa_words(A, w);
+        build_window_table(a_tab, tau_pos ? pt_negate(A) : A);                // PA
+    }
+    {
+        pt R;
+        load_bytes_as_words(w, m.a, 57, 15);                                  // R = sig[0:57]
+        ok = pt_decode_eddsa_words(R, w) && ok;
+        build_window_table(r_tab, pt_negate(R));                              // PR
+    }
+    uint32_t b1[15], b2[15];
+    recode_odd_base(b1, rho);
+    recode_odd_base(b2, tw);
+    const int top = 5 * nw - 1;                                               // uniform in the wave
+#pragma unroll
+    for (int i = 0; i < 15; i++) {
+        const uint32_t bit = (top >> 5) == i ? 1u << (top & 31) : 0u;
+        b1[i] |= bit;
+        b2[i] |= bit;
+    }
+    auto bits1 = mkbits.words(b1, 0);
+    auto bits2 = mkbits.words(b2, 1);
+    pt V = ladder_double_var(bits1, a_tab, bits2, r_tab, nw);
+    {   // rho was even: one PA too many
+        const pniels one_pa = a_tab.load(0);
+        pt W = V;
+        pt_add_pniels(W, one_pa, true, true);
+        V.x = fe_select(V.x, W.x, rho_even);
+        V.y = fe_select(V.y, W.y, rho_even);
+        V.z = fe_select(V.z, W.z, rho_even);
+        V.t = fe_select(V.t, W.t, rho_even);
+    }
+    fb.add_to(V, sc_mul(tau_mag, response), mkbits);                          // + (|tau| S)*B
+    return ok && fe_is_zero(V.x);
+}
+
 // ------------------------------------------------------------------ key derivation and signing
 // ("next" row f1 of SURVEY.md section 8; restates src/eddsa.c:34-48, 98-230)
 
@@ -566,6 +642,11 @@ struct HostBitsV {
     uint32_t word(int k) const { return w[k]; }
 };
 struct HostMkBits {
+    HostBitsV words(const uint32_t (&w)[15], int) const {
+        HostBitsV b;
+        for (int i = 0; i < 15; i++) b.w[i] = w[i];
+        return b;
+    }
     HostBitsV operator()(const sc &s, int) const {
         HostBitsV b;
         for (int i = 0; i < 14; i++) b.w[i] = s.w[i];

@@ -431,6 +431,12 @@ struct LdsMkBits {
     __device__ __forceinline__ LdsBits operator()(const sc &s, int which) const {
         return lds_put_bits(slot0 + which * 15 * BLOCK, s);
     }
+    __device__ __forceinline__ LdsBits words(const uint32_t (&w)[15], int which) const {
+        uint32_t *slot = slot0 + which * 15 * BLOCK;
+#pragma unroll
+        for (int k = 0; k < 15; k++) slot[k * BLOCK] = w[k];
+        return LdsBits{slot};
+    }
 };
 
 #define GD_KERNEL extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)

@@ -1,6 +1,13 @@
 // kernels_verify.hip -- kernel definitions (see kernels.hpp for the memory plan and policies).
 #include "varbase_bodies.hpp"
 
+// 1: half-size scalars, A and R in one ladder of about 46 windows (ed448_verify_lattice; the default).
+// 0: the full-length ladder with one exponentiation per signature (ed448_verify_chained): 13 % slower,
+//    kept as the measured alternative (profiles/r02/experiments.md).
+#ifndef GD_VERIFY_LATTICE
+#define GD_VERIFY_LATTICE 1
+#endif
+
 namespace gd {
 
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i]; b1 == nullptr: b1 is the base point (shared table)
@@ -20,11 +27,36 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
     __shared__ uint32_t s_stage[34 * BLOCK];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
-    LaneTable a_tab{workspace + (size_t)lane * TABLE_U4};
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> b_tab{bwt_tab};
     LdsStage stage{s_stage + threadIdx.x};
     LdsMkBits mk{s_bits + threadIdx.x};
+#if GD_VERIFY_LATTICE
+    // Half-size scalars (lattice.hpp): A and R share one ladder of about 45 windows; two tables per lane.
+    LaneTable a_tab = VarTable<false>::at(workspace, 0, 2), r_tab = VarTable<false>::at(workspace, 1, 2);
+    const auto wavemax = [](int x) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int y = __shfl_xor(x, d, 64);
+            x = y > x ? y : x;
+        }
+        return x;
+    };
+    for (uint32_t i0 = blockIdx.x * BLOCK; i0 < n; i0 += stride) {   // whole waves enter the ladder together
+        const uint32_t i = i0 + threadIdx.x;
+        const bool live = i < n;
+        const uint32_t j = live ? i : n - 1;                          // idle lanes redo the last signature
+        const uint8_t *msg = msg_offsets ? msgs + msg_offsets[j] : msgs + (size_t)msg_len * j;
+        const uint64_t len64 = msg_offsets ? msg_offsets[j + 1] - msg_offsets[j] : (uint64_t)msg_len;
+        const bool fits = len64 < MAX_MESSAGE_BYTES;
+        const uint32_t mlen = fits ? (uint32_t)len64 : 0u;
+        Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)j, pk + 57 * (size_t)j, msg, mlen, prehashed, ctx,
+                                            ctx_len);
+        const bool ok = ed448_verify_lattice(m, b_tab, a_tab, r_tab, stage, mk, wavemax);
+        if (live) status[i] = ok && fits ? -1 : 0;
+    }
+#else
+    LaneTable a_tab{workspace + (size_t)lane * TABLE_U4};
     // One exponentiation per signature: each verification hands a pending quotient to the next one this
     // lane handles (ed448_verify_chained, eddsa.hpp).
     VerifyPending pend;
@@ -47,6 +79,7 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
         const bool v = ed448_verify_chain_flush(pend, idx);
         status[idx] = v ? -1 : 0;
     }
+#endif
 }
 
 }  // namespace gd

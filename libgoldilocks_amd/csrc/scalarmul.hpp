@@ -257,5 +257,40 @@ template <class BITS, class TABLE1, class TABLE2>
 GD_FN pt ladder_double(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2) {
     return ladder_double_w<5>(bits1, t1, bits2, t2);
 }
+#ifndef GD_LATTICE_PREFETCH
+#define GD_LATTICE_PREFETCH 1
+#endif
+// The same with `nw` 5-bit windows instead of 90 (nw must be the same in every lane of a wave): for the
+// half-size scalars of verification (lattice.hpp).  bits: words of (s + 2^(5 nw) - 1) / 2 for odd INTEGER s.
+template <class BITS, class TABLE1, class TABLE2>
+GD_FN pt ladder_double_var(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2, int nw) {
+    uint32_t idx;
+    bool neg;
+    signed_digit(window5(bits1, 5 * (nw - 1)), idx, neg);
+    pt acc = pniels_to_pt(t1.lookup(idx), neg);
+    signed_digit(window5(bits2, 5 * (nw - 1)), idx, neg);
+    pt_add_pniels(acc, t2.lookup(idx), neg, false);
+#pragma unroll 1
+    for (int pos = 5 * (nw - 2); pos >= 0; pos -= 5) {
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) pt_double(acc, j == 4);
+#if GD_LATTICE_PREFETCH   // both entries' loads are issued before the first addition (1 % faster than one at a time)
+        uint32_t idx2;
+        bool neg2;
+        signed_digit(window5(bits1, pos), idx, neg);
+        signed_digit(window5(bits2, pos), idx2, neg2);
+        const pniels e1 = t1.lookup(idx);
+        const pniels e2 = t2.lookup(idx2);
+        pt_add_pniels(acc, e1, neg, true);
+        pt_add_pniels(acc, e2, neg2, true);
+#else
+        signed_digit(window5(bits1, pos), idx, neg);
+        pt_add_pniels(acc, t1.lookup(idx), neg, true);
+        signed_digit(window5(bits2, pos), idx, neg);
+        pt_add_pniels(acc, t2.lookup(idx), neg, true);
+#endif
+    }
+    return acc;
+}
 
 }  // namespace gd
