@@ -401,6 +401,13 @@ GOLDILOCKS_AMD_API int goldilocks_amd_field_op_dev(void *out, void *status, cons
 GOLDILOCKS_AMD_API int goldilocks_amd_wave_field_op_dev(void *out, void *status, const void *a, const void *b,
         int op, size_t n, void *stream);
 
+/* Test hook for verification's half-size scalars (csrc/lattice.hpp; no counterpart in the reference, which
+ * walks the full challenge, src/eddsa.c:283-327): for each challenge h[i] < q (goldilocks_448_scalar_s)
+ * rho[i] = 15 little-endian uint32 words, >= 0, and tau[i] = 8 words, two's complement, odd, with
+ * rho == tau * h (mod 4q), both about 224 bits for a random h. */
+GOLDILOCKS_AMD_API int goldilocks_amd_half_size_pair_dev(void *rho /* n*15 uint32 */, void *tau /* n*8 uint32 */,
+        const void *h, size_t n, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,6 +96,7 @@ FUNCTIONS = {
     "goldilocks_amd_ed448_verify_dev": (C.c_int, "pppppzBpBzp"),
     "goldilocks_amd_field_op_dev": (C.c_int, "ppppizp"),
     "goldilocks_amd_wave_field_op_dev": (C.c_int, "ppppizp"),
+    "goldilocks_amd_half_size_pair_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_ed448_derive_public_key_dev": (C.c_int, "ppzp"),
     "goldilocks_amd_ed448_sign_dev": (C.c_int, "pppppzBpBzp"),
     "goldilocks_amd_direct_scalarmul_dev": (C.c_int, "ppppiizp"),

@@ -489,6 +489,8 @@ GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, con
 GD_KERNEL_CT k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                    uint4 *__restrict__ workspace);
+GD_KERNEL k_half_size_pair(uint32_t *__restrict__ rho, uint32_t *__restrict__ tau, const uint64_t *__restrict__ h,
+                           uint32_t n);
 GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
                          const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                          const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,

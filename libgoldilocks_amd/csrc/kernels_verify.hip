@@ -17,6 +17,21 @@ GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, con
     double_scalarmul_body<false>(out, b1, s1, b2, s2, n, workspace, base_tab);
 }
 
+// test hook: the short pair (rho, tau) of verification's half-size scalars for challenge h[i] (lattice.hpp)
+GD_KERNEL k_half_size_pair(uint32_t *__restrict__ rho, uint32_t *__restrict__ tau, const uint64_t *__restrict__ h,
+                           uint32_t n) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        wide15 r;
+        int8w t;
+        half_size_pair(r, t, sc_load_abi(h + 7 * (size_t)i));
+#pragma unroll
+        for (int k = 0; k < 15; k++) rho[15 * (size_t)i + k] = r.w[k];
+#pragma unroll
+        for (int k = 0; k < 8; k++) tau[8 * (size_t)i + k] = t.w[k];
+    }
+}
+
 // config 4: status[i] = ed448_verify(sig[i], pk[i], msg[i])   (ref: goldilocks_ed448_verify)
 GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
                          const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,

@@ -10,6 +10,7 @@ import os
 import numpy as np
 import pytest
 
+import _gen
 from _libs import Gf, P
 
 pytestmark = pytest.mark.gpu
@@ -169,3 +170,48 @@ def test_products_at_the_magnitude_limits(ga):
         run(ga, OP["mulmag"] | 9 << 8 | 1 << 16, a, b)
     with pytest.raises(ga.GoldilocksAmdError):
         run(ga, 14, a, b)
+
+
+def test_half_size_pair_of_verification(ga):
+    """csrc/lattice.hpp on the device (its quotient estimate is a v_rcp_f64 there, an exact division in the
+    host checker): rho == tau * h (mod 4q), tau odd, and the pair no longer than the plain rule's and no
+    shorter than the best pair of the exact remainder sequence, for random and degenerate challenges."""
+    import random
+    import torch
+    from _libs import Q
+    rnd = random.Random(29)
+    hs = [0, 1, 2, 3, Q - 1, Q - 2, 2**224, 2**224 - 1, 2**224 + 1, 2**225, (Q - 1) // 2, (Q + 1) // 2, 2**445, 2**300 + 1]
+    hs += [rnd.getrandbits(b) for b in (10, 64, 100, 223, 224, 225, 226, 300, 440)]
+    hs += [(4 * Q // k) % Q for k in (3, 5, 7, 2**30 + 1, 2**31 - 1, 2**62 + 1, 2**100 + 7, 2**223 + 1)]   # huge first quotients
+    hs += [rnd.getrandbits(446) % Q for _ in range(20480)]
+    n = len(hs)
+    h = torch.from_numpy(_gen.scalars_from_ints(hs).view(np.int64)).cuda()
+    rho = torch.zeros((n, 15), dtype=torch.int32, device="cuda")
+    tau = torch.zeros((n, 8), dtype=torch.int32, device="cuda")
+    ga.dev("half_size_pair", rho.data_ptr(), tau.data_ptr(), h.data_ptr(), n, None)
+    torch.cuda.synchronize()
+    rw = rho.cpu().numpy().view(np.uint32)
+    tw = tau.cpu().numpy().view(np.uint32)
+    ml = lambda r_, t_: max(abs(r_).bit_length(), abs(t_).bit_length())
+    lengths = []
+    for i, hv in enumerate(hs):
+        r = sum(int(rw[i, k]) << (32 * k) for k in range(15))
+        t = sum(int(tw[i, k]) << (32 * k) for k in range(8))
+        if t >> 255:
+            t -= 1 << 256
+        assert t & 1 and (r - t * hv) % (4 * Q) == 0 and abs(t) < 2**254, hex(hv)
+        r0, r1, t0, t1 = 4 * Q, hv, 0, 1
+        while r1 >= 2**224:
+            k = r0 // r1
+            r0, r1, t0, t1 = r1, r0 - k * r1, t1, t0 - k * t1
+        if t1 & 1:
+            assert (r, t) == (r1, t1), hex(hv)
+        else:
+            a = min((r0 - abs(t0)) // (r1 + abs(t1)), 2**30 - 1)
+            cands = [(r0 - aa * r1, t0 - aa * t1) for aa in (a - 1, a, a + 1) if 0 <= aa < 2**30] + [(r0, t0)]
+            assert min(ml(*c) for c in cands) <= ml(r, t) <= ml(r0, t0), hex(hv)
+        lengths.append(ml(r, t))
+    rand = np.array(lengths[-20480:])
+    assert rand.max() <= 245 and (rand <= 225).mean() > 0.6
+    waves = rand.reshape(-1, 64).max(axis=1)                   # the ladder is as long as the wave's longest pair
+    assert 45.5 < ((waves + 4) // 5).mean() < 46.5
