@@ -19,7 +19,7 @@ HS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
 @pytest.fixture(scope="module")
 def H():
     subprocess.check_call(["make", "-s", "-C", HS_DIR])
-    return C.CDLL(os.path.join(HS_DIR, "libhostsim.so"))
+    return C.CDLL(os.environ.get("GOLDILOCKS_HOSTSIM_LIB") or os.path.join(HS_DIR, "libhostsim.so"))   # or the sanitizer build
 
 
 def _ser(O, g):
