@@ -452,11 +452,19 @@ GD_FN bool ed448_verify_chain_flush(VerifyPending &pend, uint32_t &done_index) {
 // variable points share one ladder of about 45 windows instead of A alone taking 90.  An even rho is
 // walked as rho + 1 and one subtraction of PA (signed odd digits represent odd integers only; the scalars
 // act as INTEGERS here, not mod q, because A and R may carry torsion).
-// WAVEMAX: wavemax(x) = the largest x of the wave (the window count must be uniform); identity on the host.
-// MKBITS: mkbits.words(w15, slot) turns 15 words into a BITS reader.
-template <class FB, class AT, class STAGE, class MKBITS, class WAVEMAX>
-GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &r_tab, STAGE &stage, MKBITS &mkbits,
-                                const WAVEMAX &wavemax) {
+// Two phases, so that a kernel may hand the second one to ANOTHER lane (k_ed448_verify groups the
+// signatures of a block by the length of their pairs before walking them: a wave's ladder is as long as
+// its longest pair).
+struct LatticePair {
+    uint32_t b1[15], b2[15];   // rho (made odd) and |tau|, each >> 1: signed-window words but for the top bit
+    sc ts;                     // |tau| * S mod q, the base point's scalar
+    bool tau_pos, rho_even;
+    int bits;                  // length of the longer of the two
+};
+// phase 1: challenge hash, the short pair, everything the walk needs except the points
+template <class STAGE>
+GD_FN LatticePair ed448_verify_lattice_pair(const Ed448Msg &m, STAGE &stage) {
+    LatticePair pr;
     uint32_t w[29];
     shake256_114(w, m, m.total(), stage);
     const sc h = sc_decode_long_words<114>(w);                                // the challenge, mod q
@@ -472,16 +480,33 @@ GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &
 #else
     half_size_pair(rho, tau, h);
 #endif
-    const bool tau_pos = !is_negative(tau);
+    pr.tau_pos = !is_negative(tau);
     const sc tau_mag = magnitude_as_scalar(tau);
-    const bool rho_even = (rho.w[0] & 1u) == 0;
-    rho.w[0] |= 1u;                                                           // rho + 1 when even; fixed up below
+    pr.rho_even = (rho.w[0] & 1u) == 0;
+    rho.w[0] |= 1u;                                                           // rho + 1 when even; the walk fixes it up
     wide15 tw;
 #pragma unroll
     for (int i = 0; i < 15; i++) tw.w[i] = i < 14 ? tau_mag.w[i] : 0u;
     const int bl_r = bitlen15(rho), bl_t = bitlen15(tw);
-    const int nw = wavemax(((bl_r > bl_t ? bl_r : bl_t) + 4) / 5);            // >= 1: tau is odd, hence nonzero
-
+    pr.bits = bl_r > bl_t ? bl_r : bl_t;                                      // >= 1: tau is odd, hence nonzero
+    recode_odd_base(pr.b1, rho);
+    recode_odd_base(pr.b2, tw);
+    pr.ts = sc_mul(tau_mag, response);
+    return pr;
+}
+GD_FN int lattice_windows(int bits) { return (bits + 4) / 5; }
+// bit 5 nw - 1 completes the recoding for a ladder of nw windows: (word, mask)
+GD_FN void lattice_top_bit(int nw, int &word, uint32_t &mask) {
+    const int top = 5 * nw - 1;
+    word = top >> 5;
+    mask = 1u << (top & 31);
+}
+// phase 2: decode A and R (of the signature m points at), walk, add the base point's part, test.
+// bits1 / bits2: the pair's words WITH the top bit of an nw-window ladder (nw uniform in the wave).
+template <class FB, class AT, class BITS, class MKBITS>
+GD_FN bool ed448_verify_lattice_walk(const Ed448Msg &m, bool tau_pos, bool rho_even, const sc &ts, const BITS &bits1,
+                                     const BITS &bits2, int nw, const FB &fb, AT &a_tab, AT &r_tab, MKBITS &mkbits) {
+    uint32_t w[15];
     bool ok;
     {
         pt A;
@@ -495,18 +520,6 @@ GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &
         ok = pt_decode_eddsa_words(R, w) && ok;
         build_window_table(r_tab, pt_negate(R));                              // PR
     }
-    uint32_t b1[15], b2[15];
-    recode_odd_base(b1, rho);
-    recode_odd_base(b2, tw);
-    const int top = 5 * nw - 1;                                               // uniform in the wave
-#pragma unroll
-    for (int i = 0; i < 15; i++) {
-        const uint32_t bit = (top >> 5) == i ? 1u << (top & 31) : 0u;
-        b1[i] |= bit;
-        b2[i] |= bit;
-    }
-    auto bits1 = mkbits.words(b1, 0);
-    auto bits2 = mkbits.words(b2, 1);
     pt V = ladder_double_var(bits1, a_tab, bits2, r_tab, nw);
     {   // rho was even: one PA too many
         const pniels one_pa = a_tab.load(0);
@@ -517,8 +530,27 @@ GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &
         V.z = fe_select(V.z, W.z, rho_even);
         V.t = fe_select(V.t, W.t, rho_even);
     }
-    fb.add_to(V, sc_mul(tau_mag, response), mkbits);                          // + (|tau| S)*B
+    fb.add_to(V, ts, mkbits);                                                 // + (|tau| S)*B
     return ok && fe_is_zero(V.x);
+}
+// Both phases in one lane.  WAVEMAX: wavemax(x) = the largest x of the wave (the window count must be
+// uniform); identity on the host.  MKBITS: mkbits.words(w15, slot) turns 15 words into a BITS reader.
+template <class FB, class AT, class STAGE, class MKBITS, class WAVEMAX>
+GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &r_tab, STAGE &stage, MKBITS &mkbits,
+                                const WAVEMAX &wavemax) {
+    LatticePair pr = ed448_verify_lattice_pair(m, stage);
+    const int nw = wavemax(lattice_windows(pr.bits));
+    int word;
+    uint32_t mask;
+    lattice_top_bit(nw, word, mask);
+#pragma unroll
+    for (int i = 0; i < 15; i++) {
+        pr.b1[i] |= word == i ? mask : 0u;
+        pr.b2[i] |= word == i ? mask : 0u;
+    }
+    auto bits1 = mkbits.words(pr.b1, 0);
+    auto bits2 = mkbits.words(pr.b2, 1);
+    return ed448_verify_lattice_walk(m, pr.tau_pos, pr.rho_even, pr.ts, bits1, bits2, nw, fb, a_tab, r_tab, mkbits);
 }
 
 // ------------------------------------------------------------------ key derivation and signing

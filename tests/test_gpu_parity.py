@@ -262,6 +262,27 @@ def test_verify_vs_oracle(ga, O):
         assert got[0] == -1 and got[1] == 0 and got[2] == 0 and got[8] == -1
 
 
+def test_verify_ragged_batches_through_the_lane_kernel(ga, O):
+    """k_ed448_verify regroups the signatures of each 256-lane block by the length of their half-size pairs
+    before walking them (kernels_verify.hip): batch sizes around the wave and block boundaries, with the
+    one-operation-per-wave path off so that they reach it, a third of the signatures corrupted and
+    variable-length messages; every verdict must land on its own signature."""
+    default = ga.get_wave_batch_max()
+    ga.set_wave_batch_max(0)
+    try:
+        for n in (1, 2, 63, 64, 65, 255, 256, 257, 511, 1000):
+            sigs, pks, msgs = _gen.signatures(O, n, msglen=20, seed=b"t-ragged-ver%d" % n, nkeys=5)
+            rng = np.random.default_rng(n)
+            bad = rng.random(n) < 0.33
+            sigs[bad, rng.integers(0, 114, bad.sum())] ^= (1 << rng.integers(0, 8, bad.sum())).astype(np.uint8)
+            got = ga.ed448_verify_batch(sigs, pks, msgs)
+            want = _gen.oracle_verify(O, sigs, pks, msgs)
+            assert (got == want).all(), (n, np.nonzero(got != want)[0][:8])
+            assert (got[~bad] == -1).all() and (got[bad] == 0).sum() >= bad.sum() - 2
+    finally:
+        ga.set_wave_batch_max(default)
+
+
 def test_verify_single_and_class(ga, O):
     sigs, pks, msgs = _gen.signatures(O, 2, msglen=17, seed=b"t-single")
     assert ga.ed448_verify(sigs[0].tobytes(), pks[0].tobytes(), msgs[0])
