@@ -227,30 +227,30 @@ GD_FN void half_size_pair(wide15 &rho, int8w &tau, const sc &h) {
         const uint64_t T = (1ull << 31) + (sh <= 224 ? 1ull << (224 - sh) : 0ull);
         int32_t A = 1, B = 0, C = 0, D = 1;                              // |.| < 2^30
         for (int it = 0; it < 48; it++) {
+            // one candidate step, computed unconditionally; `go` collects what the exactness argument needs
             const uint64_t yc = y + (uint64_t)(int64_t)C, yd = y + (uint64_t)(int64_t)D;
-            if (yc == 0 || yd == 0) break;
             const uint64_t xa = x + (uint64_t)(int64_t)A, xb = x + (uint64_t)(int64_t)B;
+            bool go = yc != 0 && yd != 0;
             // q = floor(xa / yc) when below 2^20: a double-precision estimate, then made exact by its remainder
             const double qd = (double)xa * fast_rcp((double)yc);
-            if (!(qd < 1048576.0)) break;
-            uint32_t q = (uint32_t)qd;
+            go = go && qd < 1048576.0;                                     // false for NaN / infinity too
+            uint32_t q = go ? (uint32_t)qd : 0u;
             int64_t rem = (int64_t)(xa - (uint64_t)q * yc);
-            if (rem < 0) {
-                q -= 1;
-                rem += (int64_t)yc;
-            }
-            if (rem >= (int64_t)yc) {
-                q += 1;
-                rem -= (int64_t)yc;
-            }
-            if (rem < 0 || rem >= (int64_t)yc) break;                     // not reached: the estimate is within one
-            const int64_t rem2 = (int64_t)(xb - (uint64_t)q * yd);       // q == floor(xb / yd) ?   (no overflow: q*yd < 2^64)
-            if (rem2 < 0 || rem2 >= (int64_t)yd) break;
+            const bool under = rem < 0;
+            q -= under ? 1u : 0u;
+            rem += under ? (int64_t)yc : 0;
+            const bool over = rem >= (int64_t)yc;
+            q += over ? 1u : 0u;
+            rem -= over ? (int64_t)yc : 0;
+            go = go && rem >= 0 && rem < (int64_t)yc;                      // always: the estimate is within one
+            const int64_t rem2 = (int64_t)(xb - (uint64_t)q * yd);        // q == floor(xb / yd) ?   (no overflow: q*yd < 2^64)
+            go = go && rem2 >= 0 && rem2 < (int64_t)yd;
             const uint64_t ny = x - (uint64_t)q * y;
-            if (ny < T) break;
+            go = go && ny >= T;
             const int64_t nC = (int64_t)A - (int64_t)q * C, nD = (int64_t)B - (int64_t)q * D;
             const int64_t lim = 1ll << 30;
-            if (nC >= lim || nC <= -lim || nD >= lim || nD <= -lim) break;
+            go = go && nC < lim && nC > -lim && nD < lim && nD > -lim;
+            if (!go) break;
             A = C;
             C = (int32_t)nC;
             B = D;
