@@ -403,8 +403,8 @@ GOLDILOCKS_AMD_API int goldilocks_amd_wave_field_op_dev(void *out, void *status,
 
 /* Test hook for verification's half-size scalars (csrc/lattice.hpp; no counterpart in the reference, which
  * walks the full challenge, src/eddsa.c:283-327): for each challenge h[i] < q (goldilocks_448_scalar_s)
- * rho[i] = 15 little-endian uint32 words, >= 0, and tau[i] = 8 words, two's complement, odd, with
- * rho == tau * h (mod 4q), both about 224 bits for a random h. */
+ * rho[i] = 15 little-endian uint32 words, 0 <= rho < 2^223, and tau[i] = 8 words, two's complement,
+ * 0 < |tau| < 2^223, with rho == tau * h (mod q): the first pair below 2^223 of the remainder sequence of (q, h). */
 GOLDILOCKS_AMD_API int goldilocks_amd_half_size_pair_dev(void *rho /* n*15 uint32 */, void *tau /* n*8 uint32 */,
         const void *h, size_t n, void *stream);
 

@@ -447,19 +447,16 @@ GD_FN bool ed448_verify_chain_flush(VerifyPending &pend, uint32_t &done_index) {
 }
 
 // ------------------------------------------------------------------ verification with half-size scalars
-// (lattice.hpp)  Accept iff  V = (|tau| S)*B + rho*PA + |tau|*PR  lies in the 2-torsion point_eq quotients by
-// (V.x == 0), with (rho, tau) the short pair of the challenge, PA = -+A by the sign of tau, PR = -R: both
-// variable points share one ladder of about 45 windows instead of A alone taking 90.  An even rho is
-// walked as rho + 1 and one subtraction of PA (signed odd digits represent odd integers only; the scalars
-// act as INTEGERS here, not mod q, because A and R may carry torsion).
-// Two phases, so that a kernel may hand the second one to ANOTHER lane (k_ed448_verify groups the
-// signatures of a block by the length of their pairs before walking them: a wave's ladder is as long as
-// its longest pair).
+// (lattice.hpp)  Accept iff  V = (|tau| S)*B + rho*PA + |tau|*PR  is the identity (V.x == 0: all of this
+// happens in the subgroup of prime order q), with (rho, tau) the short pair of the challenge,
+// PA = -+A by the sign of tau and PR = -R: both variable points share one ladder of 45 windows instead of A
+// alone taking 90.  Signed odd digits represent odd integers only: an even rho or |tau| is walked as the
+// next odd number and one copy of its point is subtracted afterwards.
+// Two phases with little live state in common (the split costs nothing and spills less).
 struct LatticePair {
-    uint32_t b1[15], b2[15];   // rho (made odd) and |tau|, each >> 1: signed-window words but for the top bit
+    uint32_t b1[15], b2[15];   // signed-window words of rho and |tau| (each made odd) for a 45-window ladder
     sc ts;                     // |tau| * S mod q, the base point's scalar
-    bool tau_pos, rho_even;
-    int bits;                  // length of the longer of the two
+    bool tau_pos, rho_even, tau_even;
 };
 // phase 1: challenge hash, the short pair, everything the walk needs except the points
 template <class STAGE>
@@ -474,45 +471,50 @@ GD_FN LatticePair ed448_verify_lattice_pair(const Ed448Msg &m, STAGE &stage) {
     int8w tau;
 #if defined(GD_LATTICE_FAKE)   // timing experiment only: a pair of the right size without the reduction (wrong verdicts)
 #pragma unroll
-    for (int i = 0; i < 15; i++) rho.w[i] = i < 7 ? h.w[i] : 0u;
+    for (int i = 0; i < 15; i++) rho.w[i] = i < 6 ? h.w[i] : 0u;
 #pragma unroll
-    for (int i = 0; i < 8; i++) tau.w[i] = i < 7 ? h.w[i + 7] | 1u : 0u;
+    for (int i = 0; i < 8; i++) tau.w[i] = i < 6 ? h.w[i + 7] | 1u : 0u;
 #else
     half_size_pair(rho, tau, h);
 #endif
     pr.tau_pos = !is_negative(tau);
     const sc tau_mag = magnitude_as_scalar(tau);
-    pr.rho_even = (rho.w[0] & 1u) == 0;
-    rho.w[0] |= 1u;                                                           // rho + 1 when even; the walk fixes it up
+    pr.ts = sc_mul(tau_mag, response);
     wide15 tw;
 #pragma unroll
     for (int i = 0; i < 15; i++) tw.w[i] = i < 14 ? tau_mag.w[i] : 0u;
-    const int bl_r = bitlen15(rho), bl_t = bitlen15(tw);
-    pr.bits = bl_r > bl_t ? bl_r : bl_t;                                      // >= 1: tau is odd, hence nonzero
+    pr.rho_even = (rho.w[0] & 1u) == 0;
+    pr.tau_even = (tw.w[0] & 1u) == 0;
+    rho.w[0] |= 1u;                                                           // the next odd number; the walk fixes it up
+    tw.w[0] |= 1u;
     recode_odd_base(pr.b1, rho);
     recode_odd_base(pr.b2, tw);
-    pr.ts = sc_mul(tau_mag, response);
+    constexpr int TOP = 5 * LATTICE_WINDOWS - 1;                              // completes the recoding
+    pr.b1[TOP >> 5] |= 1u << (TOP & 31);
+    pr.b2[TOP >> 5] |= 1u << (TOP & 31);
     return pr;
 }
-GD_FN int lattice_windows(int bits) { return (bits + 4) / 5; }
-// bit 5 nw - 1 completes the recoding for a ladder of nw windows: (word, mask)
-GD_FN void lattice_top_bit(int nw, int &word, uint32_t &mask) {
-    const int top = 5 * nw - 1;
-    word = top >> 5;
-    mask = 1u << (top & 31);
+// V - [doit] * (entry 0 of the table)
+template <class AT>
+GD_FN void lattice_subtract_once(pt &V, const AT &tab, bool doit) {
+    pt W = V;
+    pt_add_pniels(W, tab.load(0), true, true);
+    V.x = fe_select(V.x, W.x, doit);
+    V.y = fe_select(V.y, W.y, doit);
+    V.z = fe_select(V.z, W.z, doit);
+    V.t = fe_select(V.t, W.t, doit);
 }
-// phase 2: decode A and R (of the signature m points at), walk, add the base point's part, test.
-// bits1 / bits2: the pair's words WITH the top bit of an nw-window ladder (nw uniform in the wave).
+// phase 2: decode A and R, walk, add the base point's part, test
 template <class FB, class AT, class BITS, class MKBITS>
-GD_FN bool ed448_verify_lattice_walk(const Ed448Msg &m, bool tau_pos, bool rho_even, const sc &ts, const BITS &bits1,
-                                     const BITS &bits2, int nw, const FB &fb, AT &a_tab, AT &r_tab, MKBITS &mkbits) {
+GD_FN bool ed448_verify_lattice_walk(const Ed448Msg &m, const LatticePair &pr, const BITS &bits1, const BITS &bits2,
+                                     const FB &fb, AT &a_tab, AT &r_tab, MKBITS &mkbits) {
     uint32_t w[15];
     bool ok;
     {
         pt A;
         load_bytes_as_words(w, m.b, 57, 15);                                  // public key
         ok = pt_decode_eddsa_words(A, w);
-        build_window_table(a_tab, tau_pos ? pt_negate(A) : A);                // PA
+        build_window_table(a_tab, pr.tau_pos ? pt_negate(A) : A);             // PA
     }
     {
         pt R;
@@ -520,37 +522,19 @@ GD_FN bool ed448_verify_lattice_walk(const Ed448Msg &m, bool tau_pos, bool rho_e
         ok = pt_decode_eddsa_words(R, w) && ok;
         build_window_table(r_tab, pt_negate(R));                              // PR
     }
-    pt V = ladder_double_var(bits1, a_tab, bits2, r_tab, nw);
-    {   // rho was even: one PA too many
-        const pniels one_pa = a_tab.load(0);
-        pt W = V;
-        pt_add_pniels(W, one_pa, true, true);
-        V.x = fe_select(V.x, W.x, rho_even);
-        V.y = fe_select(V.y, W.y, rho_even);
-        V.z = fe_select(V.z, W.z, rho_even);
-        V.t = fe_select(V.t, W.t, rho_even);
-    }
-    fb.add_to(V, ts, mkbits);                                                 // + (|tau| S)*B
+    pt V = ladder_double_var(bits1, a_tab, bits2, r_tab, LATTICE_WINDOWS);
+    lattice_subtract_once(V, a_tab, pr.rho_even);
+    lattice_subtract_once(V, r_tab, pr.tau_even);
+    fb.add_to(V, pr.ts, mkbits);                                              // + (|tau| S)*B
     return ok && fe_is_zero(V.x);
 }
-// Both phases in one lane.  WAVEMAX: wavemax(x) = the largest x of the wave (the window count must be
-// uniform); identity on the host.  MKBITS: mkbits.words(w15, slot) turns 15 words into a BITS reader.
-template <class FB, class AT, class STAGE, class MKBITS, class WAVEMAX>
-GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &r_tab, STAGE &stage, MKBITS &mkbits,
-                                const WAVEMAX &wavemax) {
-    LatticePair pr = ed448_verify_lattice_pair(m, stage);
-    const int nw = wavemax(lattice_windows(pr.bits));
-    int word;
-    uint32_t mask;
-    lattice_top_bit(nw, word, mask);
-#pragma unroll
-    for (int i = 0; i < 15; i++) {
-        pr.b1[i] |= word == i ? mask : 0u;
-        pr.b2[i] |= word == i ? mask : 0u;
-    }
+// MKBITS: mkbits.words(w15, slot) turns 15 words into a BITS reader.
+template <class FB, class AT, class STAGE, class MKBITS>
+GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &r_tab, STAGE &stage, MKBITS &mkbits) {
+    const LatticePair pr = ed448_verify_lattice_pair(m, stage);
     auto bits1 = mkbits.words(pr.b1, 0);
     auto bits2 = mkbits.words(pr.b2, 1);
-    return ed448_verify_lattice_walk(m, pr.tau_pos, pr.rho_even, pr.ts, bits1, bits2, nw, fb, a_tab, r_tab, mkbits);
+    return ed448_verify_lattice_walk(m, pr, bits1, bits2, fb, a_tab, r_tab, mkbits);
 }
 
 // ------------------------------------------------------------------ key derivation and signing

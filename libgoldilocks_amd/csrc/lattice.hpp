@@ -1,23 +1,26 @@
 // lattice.hpp -- half-size scalars for signature verification (per lane, integer arithmetic only).
 //
-// Verification checks  S*B - h*A == R  (up to 2-torsion) with a 446-bit h: one variable-base ladder of
-// 446 doublings.  Following Antipa, Brown, Gallant, Lambert, Struik and Vanstone ("Accelerated verification
-// of ECDSA signatures", SAC 2005; for EdDSA: Pornin, "Optimized lattice basis reduction in dimension 2, and
-// fast Schnorr and EdDSA signature verification", 2020) the equation is multiplied by a small tau:
-//       (tau*S)*B - rho*A - tau*R == 0,        rho == tau*h  (mod 4q),   |rho|, |tau| about 2^224,
-// so that the two variable points A and R share ONE ladder of about 225 doublings (the base-point term costs
-// no doublings at all here).  (rho, tau) is a short vector of the lattice {(r, t): r == t*h mod 4q}; the
-// modulus is 4q -- the exponent of the whole curve group -- and not q, so that rho*A is EXACTLY
-// tau*(h mod q)*A for a key with a torsion component too (the reference multiplies by h mod q,
-// src/eddsa.c:51-74 and src/scalar.c:257-293), and tau is taken ODD, so that tau*D lies in the 2-torsion
-// the reference's point_eq quotients by (src/goldilocks.c:644-653) exactly when D = S*B - h*A - R does.
-// The accept set is therefore the reference's, bit for bit (fixtures F3 and F7).
+// Verification checks  S*B - h*A == R  with a 446-bit h: one variable-base ladder of 446 doublings.
+// Following Antipa, Brown, Gallant, Lambert, Struik and Vanstone ("Accelerated verification of ECDSA
+// signatures", SAC 2005; for EdDSA: Pornin, "Optimized lattice basis reduction in dimension 2, and fast
+// Schnorr and EdDSA signature verification", 2020) the equation is multiplied by a small nonzero tau:
+//       (tau*S)*B - rho*A - tau*R == 0,        rho == tau*h  (mod q),   0 <= rho < 2^223, 0 < |tau| < 2^223,
+// so that the two variable points A and R share ONE ladder of 225 doublings (45 five-bit windows; the
+// base-point term costs no doublings at all here).
 //
-// The pair comes from the Euclidean remainder sequence of (4q, h) with its cofactors, stopped at the first
-// remainder below 2^224: r_i == t_i*h (mod 4q), |t_i| <= 4q / r_(i-1) < 2^224.  If t_i is even, t_(i-1) is odd
-// (consecutive cofactors are coprime) and (r_(i-1), t_(i-1)) is used: tau is then shorter and rho may be
-// longer than 2^224 -- rarely by more than a few bits for a hash h, and however long it is the result is
-// exact: the ladder runs as many windows as the longest scalar of the wave needs.
+// Why the accept set is the reference's, bit for bit: every point the verification handles lies in the
+// subgroup of PRIME order q of the internal twisted curve.  The decoding applies the 4-isogeny whose
+// kernel is the whole rational torsion of Ed448 (src/goldilocks.c:949-1004 -- "decode_like_eddsa_and_mul_
+// by_ratio", ratio 4, which src/eddsa.c:283-300 compensates by multiplying S by 4), so an encoding with a
+// torsion component decodes to the same internal point as the one without (fixture F7: the reference
+// accepts those signatures) and the image, of order 4q/4, is the subgroup of order q; the base point
+// generates it.  There point_eq's "equal up to 2-torsion" (src/goldilocks.c:644-653) is plain equality,
+// D = S*B - h*A - R is the identity iff tau*D is for any tau prime to q, and scalars act modulo q.
+// (tests/test_oracle_golden.py checks q*P = 0 for every decodable point of F7, torsion-shifted and
+// small-order encodings included.)
+//
+// The pair comes from the Euclidean remainder sequence of (q, h) with its cofactors, stopped at the first
+// remainder below 2^223: r_i == t_i*h (mod q) and |t_i| <= q / r_(i-1) < 2^223.
 #pragma once
 #include "sc14.hpp"
 
@@ -30,10 +33,7 @@ struct int8w {    // signed two's complement, 256 bits
     uint32_t w[8];
 };
 
-// 4q, little-endian words (449 bits)
-GD_CONST uint32_t SC_4Q[15] = {0xad6113ccu, 0x8de30a4au, 0x37163d54u, 0x85b309cau, 0xbb58da40u, 0x113b6d26u,
-                               0xf3288fa7u, 0xfffffffdu, 0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu,
-                               0xffffffffu, 0xffffffffu, 0x00000000u};
+constexpr int LATTICE_WINDOWS = 45;   // 225 bits hold both halves of a pair
 
 GD_FN int bitlen15(const wide15 &a) {
     int n = 0;
@@ -42,8 +42,8 @@ GD_FN int bitlen15(const wide15 &a) {
         if (a.w[i]) n = 32 * i + (32 - __builtin_clz(a.w[i]));
     return n;
 }
-GD_FN bool at_least_2_224(const wide15 &a) {   // a >= 2^224
-    uint32_t acc = 0;
+GD_FN bool at_least_2_223(const wide15 &a) {   // a >= 2^223
+    uint32_t acc = a.w[6] >> 31;
 #pragma unroll
     for (int i = 7; i < 15; i++) acc |= a.w[i];
     return acc != 0;
@@ -117,14 +117,6 @@ GD_FN void euclid_step_exact(wide15 &r0, int8w &t0, wide15 &r1, int8w &t1) {
     t1 = tt;
 }
 
-GD_FN double pow2_double(int e) {   // 2^e, 0 <= e < 1024
-    union {
-        uint64_t u;
-        double d;
-    } v;
-    v.u = (uint64_t)(1023 + e) << 52;
-    return v.d;
-}
 GD_FN double fast_rcp(double v) {   // relative error far below 2^-21 is all that is asked of it
 #if defined(__HIPCC__)
     return __builtin_amdgcn_rcp(v);
@@ -179,33 +171,13 @@ GD_FN void negate_if(uint32_t (&w)[N], bool doit) {   // two's complement
         n >>= 32;
     }
 }
-GD_FN int max_int(int a, int b) { return a > b ? a : b; }
-GD_FN wide15 magnitude_wide(const int8w &a) {   // |a|
-    wide15 m;
-#pragma unroll
-    for (int i = 0; i < 15; i++) m.w[i] = i < 8 ? a.w[i] : 0u;
-    uint32_t lo[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) lo[i] = a.w[i];
-    negate_if<8>(lo, (int32_t)a.w[7] < 0);
-#pragma unroll
-    for (int i = 0; i < 8; i++) m.w[i] = lo[i];
-    return m;
-}
-GD_FN double approx_double(const wide15 &a) {   // the leading 63 bits, scaled back
-    const int bl = bitlen15(a);
-    const int sh = bl > 63 ? bl - 63 : 0;
-    return (double)window63(a, sh) * pow2_double(sh);
-}
-
-// The short pair for challenge h (< q):  rho >= 0 (up to 449 bits in degenerate cases), tau odd, |tau| < 2^254,
-// rho == tau * h (mod 4q).
+// The short pair for challenge h (< q):  0 <= rho < 2^223, 0 < |tau| < 2^223, rho == tau * h (mod q).
 //
 // Lehmer's method (Knuth, TAOCP vol. 2, 4.5.2, Algorithm L): the quotients of the remainder sequence are
 // found on the leading 63 bits of (r0, r1) -- a quotient is taken only while the two bracketing single-
 // precision quotients agree, which makes it the exact one -- and about 30 bits' worth of steps are then
 // applied to the long numbers as one 2x2 matrix with entries below 2^30.  The single-precision run also
-// stops short of the 2^224 line (the threshold T leaves room for the truncation error), so the crossing
+// stops short of the 2^223 line (the threshold T leaves room for the truncation error), so the crossing
 // itself is always an exact full-precision step and the stopping rule is the one stated above.
 // The host checker compares the pair with the remainder sequence computed in Python integers.
 GD_FN void half_size_pair(wide15 &rho, int8w &tau, const sc &h) {
@@ -213,7 +185,7 @@ GD_FN void half_size_pair(wide15 &rho, int8w &tau, const sc &h) {
     int8w t0, t1;
 #pragma unroll
     for (int i = 0; i < 15; i++) {
-        r0.w[i] = SC_4Q[i];
+        r0.w[i] = i < 14 ? SC_Q[i] : 0u;
         r1.w[i] = i < 14 ? h.w[i] : 0u;
     }
 #pragma unroll
@@ -221,10 +193,10 @@ GD_FN void half_size_pair(wide15 &rho, int8w &tau, const sc &h) {
         t0.w[i] = 0;
         t1.w[i] = i == 0 ? 1u : 0u;
     }
-    while (at_least_2_224(r1)) {
-        const int sh = bitlen15(r0) - 63;                                // >= 162
+    while (at_least_2_223(r1)) {
+        const int sh = bitlen15(r0) - 63;                                // >= 161
         uint64_t x = window63(r0, sh), y = window63(r1, sh);
-        const uint64_t T = (1ull << 31) + (sh <= 224 ? 1ull << (224 - sh) : 0ull);
+        const uint64_t T = (1ull << 31) + (sh <= 223 ? 1ull << (223 - sh) : 0ull);
         int32_t A = 1, B = 0, C = 0, D = 1;                              // |.| < 2^30
         for (int it = 0; it < 48; it++) {
             // one candidate step, computed unconditionally; `go` collects what the exactness argument needs
@@ -277,39 +249,12 @@ GD_FN void half_size_pair(wide15 &rho, int8w &tau, const sc &h) {
             t1 = u1;
         }
     }
-    // tau must be odd.  t1 odd: (r1, t1), both below 2^224.  t1 even: t0 is odd, and so is every
-    // (r0, t0) - a (r1, t1); the a that balances the two coordinates (a semiconvergent of the next step)
-    // is only estimated -- any a gives a valid pair -- and kept when it is the shorter one.
-    const bool odd1 = (t1.w[0] & 1u) != 0;
-    wide15 cr = r0;
-    int8w ct = t0;
-    {
-        const double num = approx_double(r0) - approx_double(magnitude_wide(t0));
-        const double den = approx_double(r1) + approx_double(magnitude_wide(t1));
-        const double ad = num * fast_rcp(den);
-        const uint32_t a = ad >= 1.0 ? (ad < 1073741823.0 ? (uint32_t)ad : 1073741823u) : 0u;   // NaN -> 0
-        wide15 xr;
-        int8w xt;
-        lincomb_words<15>(xr.w, r0.w, 1u, r1.w, a, false);
-        lincomb_words<8>(xt.w, t0.w, 1u, t1.w, a, false);
-        const bool minus = (int32_t)xr.w[14] < 0;                        // the estimate overshot: (-r, -t) instead
-        negate_if<15>(xr.w, minus);
-        negate_if<8>(xt.w, minus);
-        const int len_x = max_int(bitlen15(xr), bitlen15(magnitude_wide(xt)));
-        const int len_0 = max_int(bitlen15(r0), bitlen15(magnitude_wide(t0)));
-        if (len_x < len_0) {
-            cr = xr;
-            ct = xt;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < 15; i++) rho.w[i] = odd1 ? r1.w[i] : cr.w[i];
-#pragma unroll
-    for (int i = 0; i < 8; i++) tau.w[i] = odd1 ? t1.w[i] : ct.w[i];
+    rho = r1;
+    tau = t1;
 }
 
 GD_FN bool is_negative(const int8w &a) { return (int32_t)a.w[7] < 0; }
-GD_FN sc magnitude_as_scalar(const int8w &a) {   // |a| < 2^254 < q, as a scalar
+GD_FN sc magnitude_as_scalar(const int8w &a) {   // |a| < 2^223, as a scalar
     const bool neg = is_negative(a);
     sc s = sc_zero();
     uint64_t c = neg ? 1 : 0;
@@ -323,8 +268,8 @@ GD_FN sc magnitude_as_scalar(const int8w &a) {   // |a| < 2^254 < q, as a scalar
 }
 
 // Signed 5-bit windows of an ODD positive integer s < 2^(5 nw): the words of s' = (s + 2^(5 nw) - 1) / 2, whose
-// window digits w_i give s = sum (2 w_i - 31) 32^i (src/goldilocks.c:420-438 without the reduction mod q:
-// the scalars here must act as integers).  Everything but the top bit: s >> 1; the caller sets bit 5 nw - 1.
+// window digits w_i give s = sum (2 w_i - 31) 32^i (src/goldilocks.c:420-438 without the reduction mod q,
+// which would bring all 446 bits back).  Everything but the top bit: s >> 1; the caller sets bit 5 nw - 1.
 GD_FN void recode_odd_base(uint32_t out[15], const wide15 &s) {
 #pragma unroll
     for (int i = 0; i < 14; i++) out[i] = s.w[i] >> 1 | s.w[i + 1] << 31;

@@ -255,10 +255,9 @@ void hs_ed448_verify_chain(int32_t *status, const uint8_t *sig, const uint8_t *p
     }
 }
 
-// one verification with half-size scalars (lattice.hpp); *windows_out = the window count this signature needs
+// one verification with half-size scalars (lattice.hpp)
 int hs_ed448_verify_lattice(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen, uint8_t prehashed,
-                            const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table, int min_windows,
-                            int *windows_out) {
+                            const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
     static HostComb comb;
     for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
     FixedComb<HostComb> fb{comb};
@@ -266,12 +265,7 @@ int hs_ed448_verify_lattice(const uint8_t *sig, const uint8_t *pk, const uint8_t
     HostStage stage;
     HostMkBits mk;
     Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
-    int nw_seen = 0;
-    // min_windows plays the other lanes of the wave: the ladder is as long as the wave's longest pair needs
-    auto wavemax = [&](int x) { nw_seen = x; return x > min_windows ? x : min_windows; };
-    const bool ok = ed448_verify_lattice(m, fb, ta, tr, stage, mk, wavemax);
-    if (windows_out) *windows_out = nw_seen;
-    return ok ? -1 : 0;
+    return ed448_verify_lattice(m, fb, ta, tr, stage, mk) ? -1 : 0;
 }
 // the short pair of a challenge: rho (15 words), tau (8 words, two's complement)
 void hs_half_size_pair(uint32_t *rho, uint32_t *tau, const uint64_t *h) {

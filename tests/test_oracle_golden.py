@@ -115,6 +115,30 @@ def test_f7_verify_torsion(O):
     assert kinds["R+T2,A+none"] == -1 and kinds["R+none,A+T4"] == -1 and kinds["R=T2"] == 0 and kinds["pk=none"] == 0
 
 
+def test_decoded_points_have_prime_order(O):
+    """What verification with half-size scalars rests on (csrc/lattice.hpp): every point decode_like_eddsa
+    yields lies in the subgroup of prime order q of the internal curve -- the 4-isogeny of the decoding
+    (src/goldilocks.c:949-1004) kills the whole rational torsion of Ed448 -- torsion-shifted and small-order
+    encodings of fixture F7 included (the real reference's oracle path: the oracle is pinned against it)."""
+    cases = json.load(open(os.path.join(G, "f7_verify_torsion.json")))["cases"]
+    f3 = json.load(open(os.path.join(G, "f3_verify.json")))["cases"]
+    encs = {bytes.fromhex(c["pk"]) for c in cases + f3[:40]} | {bytes.fromhex(c["sig"])[:57] for c in cases + f3[:40]}
+    O.orc_point_decode_like_eddsa.restype = C.c_int
+    decoded = 0
+    for enc in sorted(encs):
+        p = Point()
+        if O.orc_point_decode_like_eddsa(C.byref(p), buf(enc)) != -1:
+            continue
+        decoded += 1
+        r, t = Point(), Point()
+        O.orc_point_scalarmul(C.byref(r), C.byref(p), C.byref(Scalar.from_int(Q - 1)))
+        O.orc_point_add(C.byref(t), C.byref(r), C.byref(p))                 # (q - 1) P + P
+        e = (C.c_uint8 * 56)()
+        O.orc_point_encode(e, C.byref(t))
+        assert bytes(e) == bytes(56), enc.hex()                             # the identity
+    assert decoded >= 40
+
+
 def test_f4_field(O):
     d = np.load(os.path.join(G, "f4_field.npz"))
     ser = (C.c_uint8 * 56)()
