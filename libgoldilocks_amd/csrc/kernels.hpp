@@ -199,6 +199,7 @@ __device__ __forceinline__ pniels pniels_load(const uint4 *q) {
 #define GD_FAST_PACKED 0   // experiment: 224-byte bit-packed entries in the digit-addressed table (profiles/r02/experiments.md)
 #endif
 struct LaneTable {  // this lane's window table in the HBM workspace, lane-contiguous; the digit picks the address
+    static constexpr bool direct = true;   // lookup = one entry's loads (a two-table ladder may issue both entries' at once)
     uint4 *p;
 #if GD_FAST_PACKED
     __device__ __forceinline__ void store(int k, const pniels &e) const {
@@ -238,6 +239,7 @@ struct LaneTable {  // this lane's window table in the HBM workspace, lane-conti
 // (global_load_lds_dwordx4, no registers held) before the window's doublings and read back with
 // ds_read_b128 for the addition, so its HBM latency hides behind the doublings.
 struct LaneTableLdsPrefetch {
+    static constexpr bool direct = true;
     uint4 *p;     // this lane's table
     uint4 *lds;   // the WAVE's 16-KiB staging region (16 rows x 64 lanes x 16 B)
     __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
@@ -260,6 +262,7 @@ struct LaneTableLdsPrefetch {
     }
 };
 struct SharedTable {  // read-only 16-entry table shared by all lanes (base point; public scalars only)
+    static constexpr bool direct = true;
     const uint4 *p;
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
@@ -280,6 +283,7 @@ struct SharedTable {  // read-only 16-entry table shared by all lanes (base poin
 constexpr int SCAN_ROWS = 14;   // uint4 per packed entry
 template <int ENTRIES>
 struct ScanTable {
+    static constexpr bool direct = false;   // lookup = a scan of the whole table
     uint4 *p;   // the wave's region + lane: row r of entry k of this lane at p[(SCAN_ROWS * k + r) * 64]
     __device__ __forceinline__ void store(int k, const pniels &e) const {
         uint32_t w[56];

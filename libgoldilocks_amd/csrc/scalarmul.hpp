@@ -246,10 +246,21 @@ GD_FN pt ladder_double_w(const BITS &bits1, const TABLE1 &t1, const BITS &bits2,
     for (int pos = window_plan<W>::TOP - W; pos >= 0; pos -= W) {
 #pragma unroll 1
         for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
-        signed_digit_w<W>(window_w<W>(bits1, pos), idx, neg);
-        pt_add_pniels(acc, t1.lookup(idx), neg, true);
-        signed_digit_w<W>(window_w<W>(bits2, pos), idx, neg);
-        pt_add_pniels(acc, t2.lookup(idx), neg, pos == 0);
+        if constexpr (TABLE1::direct && TABLE2::direct) {   // both entries' loads are issued before the first addition
+            uint32_t idx2;
+            bool neg2;
+            signed_digit_w<W>(window_w<W>(bits1, pos), idx, neg);
+            signed_digit_w<W>(window_w<W>(bits2, pos), idx2, neg2);
+            const pniels e1 = t1.lookup(idx);
+            const pniels e2 = t2.lookup(idx2);
+            pt_add_pniels(acc, e1, neg, true);
+            pt_add_pniels(acc, e2, neg2, pos == 0);
+        } else {
+            signed_digit_w<W>(window_w<W>(bits1, pos), idx, neg);
+            pt_add_pniels(acc, t1.lookup(idx), neg, true);
+            signed_digit_w<W>(window_w<W>(bits2, pos), idx, neg);
+            pt_add_pniels(acc, t2.lookup(idx), neg, pos == 0);
+        }
     }
     return acc;
 }

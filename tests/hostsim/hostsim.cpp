@@ -28,6 +28,7 @@ HostBits make_bits(const sc &s) {
     return b;
 }
 struct HostTable {
+    static constexpr bool direct = true;
     pniels e[17];
     void store(int k, const pniels &p) { e[k] = p; }
     pniels load(uint32_t k) const { return e[k]; }
