@@ -166,15 +166,17 @@ def make_workload(name, cx):
 
         def check():
             # s*B once more through a kernel that is not timed anywhere in this run (so the rocprofv3 averages
-            # of the timed kernels stay clean): the two-base ladder, s*B + 0*B over the shared window table
+            # of the timed kernels stay clean) and shares no table with them: the two-point ladder s*P + 0*P
+            # with the generator handed over as an ordinary caller's point
             m = min(n, 1 << 14)
             base_pt = torch.from_numpy(np.repeat(ga.point_base().reshape(1, 32), m, axis=0).view(np.int64)).cuda()
             zero = torch.zeros((m, 7), dtype=torch.int64, device="cuda")
             alt = torch.empty((m, 32), dtype=torch.int64, device="cuda")
-            ga.dev("base_double_scalarmul", alt.data_ptr(), scalars.data_ptr(), base_pt.data_ptr(), zero.data_ptr(), m, None)
+            ga.dev("point_double_scalarmul", alt.data_ptr(), base_pt.data_ptr(), scalars.data_ptr(), base_pt.data_ptr(),
+                   zero.data_ptr(), m, None)
             st = torch.empty(m, dtype=torch.int32, device="cuda")
             ga.dev("point_pred", st.data_ptr(), alt.data_ptr(), out.data_ptr(), 0, m, None)
-            return int((st == -1).sum()) == m, "first %d results equal s*B + 0*B from the two-base window ladder" % m, {}
+            return int((st == -1).sum()) == m, "first %d results equal s*P + 0*P from the two-point window ladder, P = the generator as a caller's point" % m, {}
         return dict(step=step, kernel=kernel, check=check, keep=[tab])
     if name == "direct":       # wire format in and out: 56-byte encodings, decode + ladder + encode fused
         bases, scalars = cx.pairs()

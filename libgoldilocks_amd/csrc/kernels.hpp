@@ -261,14 +261,6 @@ struct LaneTableLdsPrefetch {
         return e;
     }
 };
-struct SharedTable {  // read-only 16-entry table shared by all lanes (base point; public scalars only)
-    static constexpr bool direct = true;
-    const uint4 *p;
-    __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
-    __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
-    __device__ __forceinline__ void prefetch(uint32_t) const {}
-    __device__ __forceinline__ pniels fetch(uint32_t idx) const { return load(idx); }
-};
 // The index-independent window table: the counterpart of the reference's constant_time_lookup
 // (src/include/constant_time.h:134-183, used at src/goldilocks.c:440): every lookup reads EVERY entry
 // and keeps the wanted one with v_cndmask, so neither the addresses issued nor the number of
@@ -489,7 +481,7 @@ GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__
                            const uint64_t *__restrict__ scalar, uint32_t n);
 GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                              const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
-                             uint4 *__restrict__ workspace, const uint4 *__restrict__ base_tab);
+                             uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt);
 GD_KERNEL_CT k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                    uint4 *__restrict__ workspace);
@@ -545,7 +537,6 @@ GD_KERNEL k_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, c
                      const uint64_t *__restrict__ b, uint32_t n, int op, uint32_t aux);
 GD_KERNEL k_import_comb(uint4 *__restrict__ dst, const uint64_t *__restrict__ src, uint32_t ntables);
 GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb);
-GD_KERNEL k_build_shared_table(uint4 *__restrict__ dst, const uint64_t *__restrict__ point);
 GD_KERNEL k_precompute(uint64_t *__restrict__ tables, const uint64_t *__restrict__ base, uint32_t n,
                        uint4 *__restrict__ workspace);
 

@@ -176,14 +176,6 @@ GD_KERNEL k_import_comb(uint4 *__restrict__ dst, const uint64_t *__restrict__ sr
     }
 }
 
-// 16-entry window table (our pniels form) of one point, by lane 0
-GD_KERNEL k_build_shared_table(uint4 *__restrict__ dst, const uint64_t *__restrict__ point) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        LaneTable t{dst};
-        build_window_table(t, pt_load_abi(point));
-    }
-}
-
 // ref: goldilocks_448_precompute (src/goldilocks.c:755-818).  One table per lane.
 // work: PRECOMP_U4 per lane of HBM workspace: 80 x {Y-X, Y+X, T, 2Z, prefix product} + 4 teeth.
 GD_KERNEL k_precompute(uint64_t *__restrict__ tables, const uint64_t *__restrict__ base, uint32_t n,

@@ -168,15 +168,17 @@ __device__ __forceinline__ void point_dual_scalarmul_body(uint64_t *out1, uint64
 }
 
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i]   (ref: goldilocks_448_point_double_scalarmul, constant time there:
-// src/goldilocks.c:467-541).  b1 == nullptr (CT = false only): b1 is the base point through the shared
-// table -- goldilocks_448_base_double_scalarmul_non_secret, public scalars by contract.
+// src/goldilocks.c:467-541).  b1 == nullptr (CT = false only): b1 is the base point --
+// goldilocks_448_base_double_scalarmul_non_secret, public scalars by contract (src/goldilocks.c:1260-1330):
+// s2*b2 by the one-table ladder, then s1*B as 28 additions from the base point's 16-bit window table onto the
+// same accumulator (no doublings for the base point's half).
 // out may alias b2.
 template <bool CT>
 __device__ __forceinline__ void double_scalarmul_body(uint64_t *out, const uint64_t *__restrict__ b1,
                                                       const uint64_t *__restrict__ s1, const uint64_t *b2,
                                                       const uint64_t *__restrict__ s2, uint32_t n,
                                                       uint4 *__restrict__ workspace,
-                                                      const uint4 *__restrict__ base_tab) {
+                                                      const uint4 *__restrict__ bwt) {
     constexpr int W = VarTable<CT>::W;
     __shared__ uint32_t s_bits[30 * BLOCK];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
@@ -184,16 +186,20 @@ __device__ __forceinline__ void double_scalarmul_body(uint64_t *out, const uint6
     auto t2 = VarTable<CT>::at(workspace, 0, 2);
     auto t1 = VarTable<CT>::at(workspace, 1, 2);
     for (uint32_t i = lane; i < n; i += stride) {
-        LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(sc_load_abi(s1 + 7 * (size_t)i)));
         LdsBits bits2 =
             lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_window<W>(sc_load_abi(s2 + 7 * (size_t)i)));
         build_window_table_w<W>(t2, pt_load_abi(b2 + 32 * (size_t)i));
         pt r;
         if (CT || b1) {  // uniform
+            LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(sc_load_abi(s1 + 7 * (size_t)i)));
             build_window_table_w<W>(t1, pt_load_abi(b1 + 32 * (size_t)i));
             r = ladder_double_w<W>(bits1, t1, bits2, t2);
         } else {
-            if constexpr (!CT) r = ladder_double_w<W>(bits1, SharedTable{base_tab}, bits2, t2);
+            if constexpr (!CT) {
+                r = ladder_varbase_w<W>(bits2, t2);
+                LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(sc_load_abi(s1 + 7 * (size_t)i)));
+                ladder_bwt_onto(r, bits1, GlobalBwt{bwt});
+            }
         }
         pt_store_abi(out + 32 * (size_t)i, r);
     }
