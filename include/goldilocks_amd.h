@@ -290,9 +290,10 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  * them derive_public_key, sign and x448_derive_public_key.  This library keeps that contract BY DEFAULT:
  *
  *   GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT (default)
- *     - base-point multiplications (derive, sign, X448 key generation, precomputed_scalarmul): the
- *       reference's 5x5x18 comb staged in LDS, every lookup a wavefront-shuffle gather whose
- *       addresses and timing do not depend on the digit;
+ *     - base-point multiplications (derive, sign, X448 key generation, precomputed_scalarmul on the
+ *       built-in table): a signed comb of the base point staged in LDS (4 combs x 7 teeth x spacing 16,
+ *       the structure of the reference's 5x5x18 with fewer additions), every lookup a
+ *       wavefront-shuffle gather whose addresses and timing do not depend on the digit;
  *     - variable-base multiplications (point_scalarmul, direct_scalarmul, double_scalarmul,
  *       dual_scalarmul): 4-bit signed windows, every lookup reads all 8 entries of the lane's table
  *       and keeps the wanted one with a select.
@@ -302,7 +303,7 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  *
  * Not affected: verification and base_double_scalarmul_non_secret (public by contract: always the
  * fast tables), goldilocks_x448 with a peer's point (a Montgomery ladder with selects, no table),
- * caller-supplied precomputed_s tables (always the LDS comb).  Process-wide; returns 0, or nonzero
+ * caller-supplied precomputed_s tables (always the reference's 5x5x18 comb, in LDS with the same gather).  Process-wide; returns 0, or nonzero
  * for an unknown mode. */
 #define GOLDILOCKS_AMD_TABLES_FAST 0
 #define GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT 1

@@ -14,14 +14,38 @@ namespace gd {
 // recomputes the last operation with live = false and stores nothing.
 template <bool CT>
 __device__ __forceinline__ uint32_t *fixed_base_stage(const uint4 *table) {
-    if constexpr (CT) {
-        __shared__ uint32_t s_comb[COMB_LDS_WORDS];
-        stage_comb_lds(s_comb, table);
+    if constexpr (CT) {   // the library's own 4 x 7 x 16 comb of the base point (k_build_comb_big)
+        __shared__ uint32_t s_comb[COMB_BIG_LDS_WORDS];
+        stage_comb_lds<comb_big::ENTRIES>(s_comb, table);
         return s_comb;
     } else {
         return nullptr;
     }
 }
+// Key derivation and signing hash (a 136-byte SHAKE block staged per lane, 34 KiB per block) and multiply the
+// base point (the 48-KiB comb) by turns, never at once: the two take turns in ONE LDS region, so that two
+// blocks still fit a CU.  Every lane of the block calls mul() the same number of times in uniform control
+// flow (for_each_op<true>), which makes the barriers legal: the first one says every lane is done hashing,
+// the last one that nobody still gathers from the comb.  Restaging costs 48 cached loads per lane per call.
+static_assert(COMB_BIG_LDS_WORDS >= 34 * BLOCK, "the SHAKE stage lives inside the comb's region");
+struct RestagedCombBig {
+    using plan = comb_big;
+    uint32_t *region;
+    const uint4 *table;
+    template <class MK>
+    __device__ __forceinline__ pt mul(const sc &s, MK &mk) const {
+        auto bits = mk(plan::recode(s), 0);
+        __syncthreads();
+        stage_comb_lds<comb_big::ENTRIES>(region, table);   // ends with a barrier
+        LdsShuffleCombBig comb{region, threadIdx.x & 63u};
+        const pt r = ladder_comb(bits, comb);
+        __syncthreads();
+        return r;
+    }
+    template <class MK>
+    __device__ __forceinline__ void add_to(pt &acc, const sc &s, MK &mk) const { acc = pt_add(acc, mul(s, mk), false); }
+};
+
 // body(index, live) for every operation this lane owns, in ascending / descending order
 template <bool CT, class BODY>
 __device__ __forceinline__ void for_each_op(uint32_t n, BODY body) {
@@ -101,8 +125,7 @@ template <bool CT>
 __device__ __forceinline__ void derive_body(uint8_t *pk, const uint8_t *sk, uint32_t n, const uint4 *table,
                                             uint4 *ws) {
     __shared__ uint32_t s_bits[15 * BLOCK];
-    __shared__ uint32_t s_stage[34 * BLOCK];
-    uint32_t *s_comb = fixed_base_stage<CT>(table);
+    __shared__ uint32_t s_stage[CT ? COMB_BIG_LDS_WORDS : 34 * BLOCK];   // CT: the comb's region too (RestagedCombBig)
     LdsStage stage{s_stage + threadIdx.x};
     LdsMkBits mk{s_bits + threadIdx.x};
     InvChain ch;
@@ -118,8 +141,7 @@ __device__ __forceinline__ void derive_body(uint8_t *pk, const uint8_t *sk, uint
         ch.push(slot + 8, zn, live);
     };
     if constexpr (CT) {
-        LdsShuffleComb comb{s_comb, threadIdx.x & 63u};
-        FixedComb<LdsShuffleComb> fb{comb};
+        RestagedCombBig fb{s_stage, table};
         for_each_op<CT>(n, [&](uint32_t i, bool live) { first(i, live, fb); });
     } else {
         GlobalBwt bwt_tab{table};
@@ -149,8 +171,7 @@ __device__ __forceinline__ void sign_body(uint8_t *sig, const uint8_t *sk, const
                                           const uint8_t *ctx, uint32_t ctx_len, uint32_t n, const uint4 *table,
                                           uint4 *ws) {
     __shared__ uint32_t s_bits[15 * BLOCK];
-    __shared__ uint32_t s_stage[34 * BLOCK];
-    uint32_t *s_comb = fixed_base_stage<CT>(table);
+    __shared__ uint32_t s_stage[CT ? COMB_BIG_LDS_WORDS : 34 * BLOCK];   // CT: the comb's region too (RestagedCombBig)
     LdsStage stage{s_stage + threadIdx.x};
     LdsMkBits mk{s_bits + threadIdx.x};
     uint8_t *scratch = reinterpret_cast<uint8_t *>(ws + (size_t)SIGN_SLOT_U4 * n) +
@@ -182,8 +203,7 @@ __device__ __forceinline__ void sign_body(uint8_t *sig, const uint8_t *sk, const
         ch.push(slot + 8, zn, live);
     };
     if constexpr (CT) {
-        LdsShuffleComb comb{s_comb, threadIdx.x & 63u};
-        FixedComb<LdsShuffleComb> fb{comb};
+        RestagedCombBig fb{s_stage, table};
         for_each_op<CT>(n, [&](uint32_t i, bool live) { first(i, live, fb); });
     } else {
         GlobalBwt bwt_tab{table};
@@ -249,8 +269,8 @@ __device__ __forceinline__ void x448_body(uint8_t *shared, int32_t *status, cons
             LdsBits bits = lds_put_bits(s_bits + threadIdx.x, raw);
             x448_ladder(num, den, b, bits);
         } else if constexpr (CT) {
-            LdsShuffleComb comb{s_comb, threadIdx.x & 63u};
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(x448_public_scalar(w)));
+            LdsShuffleCombBig comb{s_comb, threadIdx.x & 63u};
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, comb_big::recode(x448_public_scalar(w)));
             const pt p = ladder_comb(bits, comb);
             num = p.y;
             den = p.x;

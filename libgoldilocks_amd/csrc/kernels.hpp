@@ -367,6 +367,7 @@ constexpr int scan_table_wave_u4() { return (ENTRIES + 1) * SCAN_ROWS * 64; }
 constexpr int COMB_LDS_STRIDE = 49;
 constexpr int COMB_LDS_WORDS = 80 * COMB_LDS_STRIDE;
 struct LdsShuffleComb {
+    using plan = comb_ref;
     const uint32_t *lds;
     uint32_t lane;  // lane within the wave
     __device__ __forceinline__ niels load(int j, uint32_t idx) const {
@@ -391,11 +392,40 @@ struct LdsShuffleComb {
         return e;
     }
 };
+template <int ENTRIES = 80>
 __device__ __forceinline__ void stage_comb_lds(uint32_t *lds, const uint4 *comb) {
     const uint32_t *g = reinterpret_cast<const uint32_t *>(comb);
-    for (int i = threadIdx.x; i < 80 * 48; i += BLOCK) lds[(i / 48) * COMB_LDS_STRIDE + (i % 48)] = g[i];
+    for (int i = threadIdx.x; i < ENTRIES * 48; i += BLOCK) lds[(i / 48) * COMB_LDS_STRIDE + (i % 48)] = g[i];
     __syncthreads();
 }
+// The same for the library's own 4 x 7 x 16 comb of the base point (scalarmul.hpp comb_big; built once per
+// device by k_build_comb_big): a comb has 64 entries, so lane l reads ALL 48 words of entry 64j + l -- a
+// lane-dependent, index-independent address, conflict-free with the odd stride -- and the wanted entry's
+// words come from lane idx through ds_bpermute_b32.
+constexpr int COMB_BIG_LDS_WORDS = comb_big::ENTRIES * COMB_LDS_STRIDE;
+struct LdsShuffleCombBig {
+    using plan = comb_big;
+    const uint32_t *lds;
+    uint32_t lane;  // lane within the wave
+    __device__ __forceinline__ fe gather(const uint32_t *src, int a0) const {
+        uint32_t r[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) r[q] = src[q];
+        fe v;
+#pragma unroll
+        for (int q = 0; q < 16; q++) v.v[q] = (uint32_t)__builtin_amdgcn_ds_bpermute(a0, (int)r[q]);
+        return v;
+    }
+    __device__ __forceinline__ niels load(int j, uint32_t idx) const {
+        const uint32_t *src = lds + (64 * j + lane) * COMB_LDS_STRIDE;
+        const int a0 = (int)(idx << 2);  // bpermute takes a byte address: 4 * source lane
+        niels e;
+        e.a = gather(src, a0);
+        e.b = gather(src + 16, a0);
+        e.cn = gather(src + 32, a0);
+        return e;
+    }
+};
 
 // Fixed-base window table of the base point: BWT_WINDOWS x BWT_PER_WINDOW affine niels (12 uint4 each) in
 // global memory, built once per device (k_build_bwt), cache-resident (L2 / Infinity Cache): every lane
@@ -485,6 +515,9 @@ GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, con
 GD_KERNEL_CT k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                    uint4 *__restrict__ workspace);
+GD_KERNEL k_build_comb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ comb);
+GD_KERNEL k_base_scalarmul_ct(uint64_t *__restrict__ out, const uint4 *__restrict__ comb_big_tab,
+                              const uint64_t *__restrict__ scalar, uint32_t n);
 GD_KERNEL k_half_size_pair(uint32_t *__restrict__ rho, uint32_t *__restrict__ tau, const uint64_t *__restrict__ h,
                            uint32_t n);
 GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,

@@ -30,6 +30,29 @@ GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__res
     for (int k = 0; k < WAVE_STAGE_U4 / 64; k++) stage[k * 64 + l] = make_uint4(0, 0, 0, 0);
 }
 
+// scaled[i] = scalar[i] * B for the built-in base point with index-independent table access: the library's
+// own 4 x 7 x 16 comb, staged in LDS and gathered with wavefront shuffles (kernels.hpp LdsShuffleCombBig)
+GD_KERNEL k_base_scalarmul_ct(uint64_t *__restrict__ out, const uint4 *__restrict__ comb_big_tab,
+                              const uint64_t *__restrict__ scalar, uint32_t n) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint32_t s_comb[COMB_BIG_LDS_WORDS];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    stage_comb_lds<comb_big::ENTRIES>(s_comb, comb_big_tab);
+    LdsShuffleCombBig tab{s_comb, threadIdx.x & 63u};
+    // every lane of a wave must take part in the shuffles: the loop is wave-uniform and lanes past the end
+    // redo the last operation without storing it
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t i = lane + r * stride;
+        const uint32_t j = i < n ? i : n - 1;
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, comb_big::recode(sc_load_abi(scalar + 7 * (size_t)j)));
+        const pt res = ladder_comb(bits, tab);
+        if (i < n) pt_store_abi(out + 32 * (size_t)i, res);
+    }
+    lds_wipe_lane(s_bits + threadIdx.x, 15);   // the scalar may have been secret
+}
+
 // scaled[i] = scalar[i] * B for the built-in base point, through the window table
 GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ bwt,
                            const uint64_t *__restrict__ scalar, uint32_t n) {
@@ -79,6 +102,36 @@ GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) {
     }
     v = sc_reduce(v);
     for (uint32_t k = 0; k < extra; k++) v = sc_add(v, v);
+    LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(v));
+    pt p = ladder_comb(bits, tab);
+    fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
+    uint4 *q = dst + 12 * (size_t)e;
+    fe_store(q, fe_mul(fe_weak(fe_sub<2>(p.y, p.x)), zi));
+    fe_store(q + 4, fe_mul(fe_weak(fe_add(p.x, p.y)), zi));
+    fe_store(q + 8, fe_mul(fe_mulw(p.t, TWO_EFF_D), zi));
+}
+
+// entry e = 64 j + idx of the 4 x 7 x 16 comb: (2^(16(6+7j)) + sum_{k<6} (+-) 2^(16(k+7j))) * B, + iff bit k of idx,
+// as affine niels in our form; computed like the window table above.  Launch with exactly comb_big::ENTRIES lanes.
+GD_KERNEL k_build_comb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint32_t s_comb[COMB_LDS_WORDS];
+    stage_comb_lds(s_comb, comb);
+    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
+    const uint32_t e = blockIdx.x * BLOCK + threadIdx.x;   // < comb_big::ENTRIES by construction
+    const uint32_t j = e / comb_big::PER_COMB, idx = e % comb_big::PER_COMB;
+    const auto power = [](uint32_t bit) {
+        sc v = sc_zero();
+#pragma unroll
+        for (int w = 0; w < 14; w++) v.w[w] = (uint32_t)w == (bit >> 5) ? 1u << (bit & 31) : 0u;
+        return v;
+    };
+    sc v = power(comb_big::SPACING * (comb_big::TEETH - 1 + comb_big::TEETH * j));
+#pragma unroll 1
+    for (uint32_t k = 0; k + 1 < (uint32_t)comb_big::TEETH; k++) {
+        const sc term = power(comb_big::SPACING * (k + comb_big::TEETH * j));
+        v = (idx >> k) & 1u ? sc_add(v, term) : sc_sub(v, term);
+    }
     LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(v));
     pt p = ladder_comb(bits, tab);
     fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));

@@ -116,36 +116,53 @@ GD_FN void ladder_dual(pt &out1, pt &out2, const BITS &bits1, const BITS &bits2,
     ladder_dual_w<5>(out1, out2, bits1, bits2, table);
 }
 
-// Comb: 18 rounds; round i adds, for each of the 5 combs j, the entry selected by
-// bits i + 18*(k + 5j), k < 5, of s'  (src/goldilocks.c:846-873).
-// COMB: comb.load(j, idx) -> affine niels entry 16*j + idx (our sign convention).
-template <class BITS>
-GD_FN uint32_t comb_teeth(const BITS &bits, int i, int j) {
+// Comb: S rounds; round i adds, for each of the N combs j, the entry selected by the T bits
+// i + S*(k + T*j), k < T, of s' = (s + 2^(N*T*S) - 1)/2 mod q  (src/goldilocks.c:846-873 with the
+// reference's N = T = 5, S = 18).  Entry idx of comb j is sum_k (+-) 2^(S(k + T j)) B, tooth T-1 always +,
+// tooth k < T-1 + iff bit k of idx.
+// COMB: comb.load(j, idx) -> affine niels entry 2^(T-1)*j + idx (our sign convention); COMB::plan says which comb.
+template <int T, int N, int S>
+struct comb_plan {
+    static constexpr int TEETH = T, COMBS = N, SPACING = S, PER_COMB = 1 << (T - 1), ENTRIES = N << (T - 1);
+    static_assert(T * N * S == 450 || T * N * S == 448, "recoding constants exist for 450 and 448 bits");
+    static GD_MFN sc recode(const sc &s) { return T * N * S == 450 ? sc_recode_signed(s) : sc_recode_signed8(s); }
+};
+using comb_ref = comb_plan<5, 5, 18>;   // the reference's: 80 entries, 17 doublings + 89 additions
+// 4 combs of 7 teeth, spacing 16: 256 entries (48 KiB as affine niels), 15 doublings + 63 additions -- 26 % fewer
+// multiplications; for the library's own base point where the table has to be index-independent (kernels.hpp)
+using comb_big = comb_plan<7, 4, 16>;
+
+template <class PLAN, class BITS>
+GD_FN uint32_t comb_teeth_of(const BITS &bits, int i, int j) {
     uint32_t tab = 0;
 #pragma unroll
-    for (int k = 0; k < 5; k++) {
-        const int bit = i + 18 * (k + 5 * j);
+    for (int k = 0; k < PLAN::TEETH; k++) {
+        const int bit = i + PLAN::SPACING * (k + PLAN::TEETH * j);
         if (bit < 446) tab |= ((bits.word(bit >> 5) >> (bit & 31)) & 1u) << k;
     }
     return tab;
 }
+template <class BITS>
+GD_FN uint32_t comb_teeth(const BITS &bits, int i, int j) { return comb_teeth_of<comb_ref>(bits, i, j); }
 
 template <class BITS, class COMB>
 GD_FN pt ladder_comb(const BITS &bits, const COMB &comb) {
+    using PLAN = typename COMB::plan;
+    constexpr int S = PLAN::SPACING, N = PLAN::COMBS, T = PLAN::TEETH;
     uint32_t idx;
     bool neg;
-    signed_digit(comb_teeth(bits, 17, 0), idx, neg);
+    signed_digit_w<T>(comb_teeth_of<PLAN>(bits, S - 1, 0), idx, neg);
     pt acc = niels_to_pt(comb.load(0, idx), neg);
 #pragma unroll 1
-    for (int i = 17; i >= 0; i--) {
-        if (i != 17) pt_double(acc, true);
+    for (int i = S - 1; i >= 0; i--) {
+        if (i != S - 1) pt_double(acc, true);
 #pragma unroll 1
-        for (int j = (i == 17 ? 1 : 0); j < 5; j++) {
-            signed_digit(comb_teeth(bits, i, j), idx, neg);
+        for (int j = (i == S - 1 ? 1 : 0); j < N; j++) {
+            signed_digit_w<T>(comb_teeth_of<PLAN>(bits, i, j), idx, neg);
             niels e = comb.load(j, idx);
             // T feeds the next addition; the last add of a round is followed by a
             // doubling (which ignores T) unless it is the very last one.
-            pt_add_niels(acc, e, neg, !(j == 4 && i));
+            pt_add_niels(acc, e, neg, !(j == N - 1 && i));
         }
     }
     return acc;
@@ -212,7 +229,7 @@ struct FixedComb {
     const COMB &comb;
     template <class MK>
     GD_MFN pt mul(const sc &s, MK &mk) const {
-        auto bits = mk(sc_recode_signed(s), 0);
+        auto bits = mk(COMB::plan::recode(s), 0);
         return ladder_comb(bits, comb);
     }
     template <class MK>

@@ -37,6 +37,7 @@ struct HostTable {
     pniels fetch(uint32_t k) const { return e[k]; }
 };
 struct HostComb {
+    using plan = comb_ref;
     niels e[80];
     niels load(int j, uint32_t idx) const { return e[16 * j + idx]; }
 };
@@ -125,9 +126,10 @@ void hs_point_scalarmul_w4(uint64_t *out, const uint64_t *base, const uint64_t *
 // Multiply-accumulates (v_mad_u64_u32 on the device) of one call of a building block; the counts
 // do not depend on the data.  what: 0 fe_mul, 1 fe_sqr, 2 fe_mulw, 3 pt_double, 4 pt_double + T,
 // 5 pt_add_niels + T, 6 niels_to_pt, 7 fe_isr, 8 pt_decode_eddsa, 9 pt_add (full), 10 pt_eq,
-// 11 variable base W = 5 (table + ladder), 12 variable base W = 4, 13 comb ladder
+// 11 variable base W = 5 (table + ladder), 12 variable base W = 4, 13 comb ladder, 14 the 4 x 7 x 16 comb ladder
 void hs_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *scalar);
 void hs_precomputed_scalarmul(uint64_t *out, const uint64_t *table, const uint64_t *scalar);
+void hs_comb_big_scalarmul(uint64_t *out, const uint64_t *table, const uint64_t *scalar);
 unsigned long long hs_mac_count_of(int what, const uint64_t *point, const uint64_t *scalar, const uint64_t *comb_table) {
     pt p = pt_from_abi(point), q = p;
     uint64_t out[32];
@@ -152,6 +154,7 @@ unsigned long long hs_mac_count_of(int what, const uint64_t *point, const uint64
     case 11: hs_point_scalarmul(out, point, scalar); break;
     case 12: hs_point_scalarmul_w4(out, point, scalar); break;
     case 13: hs_precomputed_scalarmul(out, comb_table, scalar); break;
+    case 14: hs_comb_big_scalarmul(out, comb_table, scalar); c = 0; hs_comb_big_scalarmul(out, comb_table, scalar); break;   // the table is built by the first call
     default: return 0;
     }
     return c;
@@ -168,6 +171,42 @@ void hs_precomputed_scalarmul(uint64_t *out, const uint64_t *table /*80*24 limbs
     static HostComb comb;
     for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(table + 24 * i);
     pt_to_abi(out, ladder_comb(bits, comb));
+}
+// The library's own 4 x 7 x 16 comb of the base point (scalarmul.hpp comb_big): the table is built the way
+// k_build_comb_big builds it on the device -- every entry is a scalar multiple of B computed with the
+// reference comb -- and walked by the same ladder_comb.
+struct HostCombBig {
+    using plan = comb_big;
+    niels e[comb_big::ENTRIES];
+    niels load(int j, uint32_t idx) const { return e[comb_big::PER_COMB * j + idx]; }
+};
+void hs_comb_big_scalarmul(uint64_t *out, const uint64_t *table /*80*24 limbs: the reference comb*/, const uint64_t *scalar) {
+    static HostComb ref;
+    static HostCombBig big;
+    static bool built = false;
+    if (!built) {
+        for (int i = 0; i < 80; i++) ref.e[i] = niels_from_abi(table + 24 * i);
+        auto power = [](uint32_t bit) {
+            sc v = sc_zero();
+            v.w[bit >> 5] = 1u << (bit & 31);
+            return v;
+        };
+        for (int j = 0; j < comb_big::COMBS; j++)
+            for (uint32_t idx = 0; idx < (uint32_t)comb_big::PER_COMB; idx++) {
+                sc v = power(comb_big::SPACING * (comb_big::TEETH - 1 + comb_big::TEETH * j));
+                for (int k = 0; k + 1 < comb_big::TEETH; k++) {
+                    const sc term = power(comb_big::SPACING * (k + comb_big::TEETH * j));
+                    v = (idx >> k) & 1u ? sc_add(v, term) : sc_sub(v, term);
+                }
+                big.e[comb_big::PER_COMB * j + idx] = host_affine_niels(ladder_comb(make_bits(v), ref));
+            }
+        built = true;
+    }
+    HostBits bits;
+    const sc r = comb_big::recode(sc_from_abi(scalar));
+    for (int i = 0; i < 14; i++) bits.w[i] = r.w[i];
+    bits.w[14] = 0;
+    pt_to_abi(out, ladder_comb(bits, big));
 }
 void hs_point_double_scalarmul(uint64_t *out, const uint64_t *b, const uint64_t *sb, const uint64_t *c,
                                const uint64_t *scc) {

@@ -182,14 +182,16 @@ def test_mac_counts_match_bench(H, O):
     s = _gen.stream_scalars(1, b"mac-count")[0].copy()
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     names = ["fe_mul", "fe_sqr", "fe_mulw", "dbl", "dbl_t", "add_niels_t", "niels_to_pt", "isr", "decode_eddsa",
-             "pt_add", "pt_eq", "varbase5", "varbase4", "comb"]
+             "pt_add", "pt_eq", "varbase5", "varbase4", "comb", "comb_big"]
     c = {name: H.hs_mac_count_of(i, p(base), p(s), p(comb)) for i, name in enumerate(names)}
     assert (c["fe_mul"], c["fe_sqr"], c["fe_mulw"]) == (192, 136, 16)
     assert c["dbl"] == 4 * 136 + 3 * 192 and c["dbl_t"] == c["dbl"] + 192
     W = bench.WORKLOADS
     assert W["varbase"]["macs"] == c["varbase5"] == 2175 * 192 + 1785 * 136 + 17 * 16
     assert W["varbase"]["macs_index_independent"] == c["varbase4"]
-    assert W["fixed"]["macs"] == W["base"]["macs_index_independent"] == c["comb"]
+    assert W["fixed"]["macs"] == c["comb"] == c["niels_to_pt"] + 89 * c["add_niels_t"] - 17 * 192 + 17 * c["dbl_t"]
+    # the built-in base point with index-independent access: the library's 4 x 7 x 16 comb
+    assert W["base"]["macs_index_independent"] == c["comb_big"] == c["niels_to_pt"] + 63 * c["add_niels_t"] - 15 * 192 + 15 * c["dbl_t"]
     # base-point window table, 16-bit digits: one conversion + 27 mixed additions
     assert W["base"]["macs"] == c["niels_to_pt"] + 27 * c["add_niels_t"]
     # verification with half-size scalars (ed448_verify_lattice): two decodings, two window tables, a 45-window
@@ -222,6 +224,21 @@ def test_mac_counts_match_bench(H, O):
     assert (counts[9] - counts[1]) % 8 == 0
     assert 766_184 == steady - (c["comb"] + c["pt_add"]) + 28 * c["add_niels_t"]
     assert steady < 2 * c["decode_eddsa"] + c["varbase5"] + c["comb"] + c["pt_add"] + c["pt_eq"] - 55_000   # one isr gone
+
+
+def test_big_comb_of_the_base_point_matches_oracle(H, O):
+    """The 4 x 7 x 16 comb the index-independent base-point kernels walk (scalarmul.hpp comb_big; the table built
+    as k_build_comb_big builds it, entry by entry as scalar multiples of B): s * B against the oracle for edge
+    and random scalars."""
+    rnd = random.Random(31)
+    comb = np.frombuffer(bytes(O.orc_precomputed_base().contents), np.uint64).copy()
+    vals = [0, 1, 2, 3, Q - 1, Q - 2, 2**445, 2**444 - 1, 2**16, 2**16 - 1, 2**112, (Q - 1) // 2] + [rnd.getrandbits(446) % Q for _ in range(40)]
+    scal = _gen.scalars_from_ints(vals)
+    want = _gen.oracle_encode(_gen.oracle_fixed(O, scal))
+    for i in range(len(vals)):
+        out = np.zeros(32, np.uint64)
+        H.hs_comb_big_scalarmul(out.ctypes.data_as(C.c_void_p), comb.ctypes.data_as(C.c_void_p), scal[i].ctypes.data_as(C.c_void_p))
+        assert (_gen.oracle_encode(out.reshape(1, 32))[0] == want[i]).all(), hex(vals[i])
 
 
 def test_four_bit_window_ladder_matches_oracle(H, O):
