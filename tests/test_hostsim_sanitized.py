@@ -11,7 +11,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HS_DIR = os.path.join(HERE, "hostsim")
-SELECT = "ladders_and_codecs or verify or half_size or four_bit_window or fixed_base_window"
+SELECT = "ladders_and_codecs or verify or half_size or four_bit_window or fixed_base_window or big_comb"
 
 
 def test_lane_arithmetic_under_asan_and_ubsan():
