@@ -303,7 +303,8 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  *
  * Not affected: verification and base_double_scalarmul_non_secret (public by contract: always the
  * fast tables), goldilocks_x448 with a peer's point (a Montgomery ladder with selects, no table),
- * caller-supplied precomputed_s tables (always the reference's 5x5x18 comb, in LDS with the same gather).  Process-wide; returns 0, or nonzero
+ * caller-supplied precomputed_s tables (always an LDS comb with the same gather: the reference's 5x5x18,
+ * re-combed to 4x7x16 per call for batches of 2^18 operations or more).  Process-wide; returns 0, or nonzero
  * for an unknown mode. */
 #define GOLDILOCKS_AMD_TABLES_FAST 0
 #define GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT 1

@@ -517,7 +517,8 @@ GD_KERNEL_CT k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b
                                    uint4 *__restrict__ workspace);
 GD_KERNEL k_build_comb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ comb);
 GD_KERNEL k_base_scalarmul_ct(uint64_t *__restrict__ out, const uint4 *__restrict__ comb_big_tab,
-                              const uint64_t *__restrict__ scalar, uint32_t n);
+                              const uint64_t *__restrict__ scalar, uint32_t n, uint32_t halve);
+GD_KERNEL k_recomb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ comb);
 GD_KERNEL k_half_size_pair(uint32_t *__restrict__ rho, uint32_t *__restrict__ tau, const uint64_t *__restrict__ h,
                            uint32_t n);
 GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,

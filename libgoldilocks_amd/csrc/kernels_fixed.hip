@@ -32,8 +32,9 @@ GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__res
 
 // scaled[i] = scalar[i] * B for the built-in base point with index-independent table access: the library's
 // own 4 x 7 x 16 comb, staged in LDS and gathered with wavefront shuffles (kernels.hpp LdsShuffleCombBig)
+// halve != 0: the comb is one of 2G (k_recomb_big, a caller's table re-combed): the scalar is halved first.
 GD_KERNEL k_base_scalarmul_ct(uint64_t *__restrict__ out, const uint4 *__restrict__ comb_big_tab,
-                              const uint64_t *__restrict__ scalar, uint32_t n) {
+                              const uint64_t *__restrict__ scalar, uint32_t n, uint32_t halve) {
     __shared__ uint32_t s_bits[15 * BLOCK];
     __shared__ uint32_t s_comb[COMB_BIG_LDS_WORDS];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
@@ -46,7 +47,9 @@ GD_KERNEL k_base_scalarmul_ct(uint64_t *__restrict__ out, const uint4 *__restric
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t i = lane + r * stride;
         const uint32_t j = i < n ? i : n - 1;
-        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, comb_big::recode(sc_load_abi(scalar + 7 * (size_t)j)));
+        sc k = sc_load_abi(scalar + 7 * (size_t)j);
+        if (halve) k = sc_halve(k);   // uniform
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, comb_big::recode(k));
         const pt res = ladder_comb(bits, tab);
         if (i < n) pt_store_abi(out + 32 * (size_t)i, res);
     }
@@ -134,6 +137,46 @@ GD_KERNEL k_build_comb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ co
     }
     LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(v));
     pt p = ladder_comb(bits, tab);
+    fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
+    uint4 *q = dst + 12 * (size_t)e;
+    fe_store(q, fe_mul(fe_weak(fe_sub<2>(p.y, p.x)), zi));
+    fe_store(q + 4, fe_mul(fe_weak(fe_add(p.x, p.y)), zi));
+    fe_store(q + 8, fe_mul(fe_mulw(p.t, TWO_EFF_D), zi));
+}
+
+// A caller's 5 x 5 x 18 comb (our form, k_import_comb) -> the 4 x 7 x 16 comb of TWICE its base point, without a
+// single scalar multiplication: the reference comb's entries are signed sums of the teeth T_a = 2^(18a) G, so
+//     entry(j, 1 << k) - entry(j, 0) = 2 T_(k+5j)  (k < 4),      entry(j, 15) + entry(j, 0) = 2 T_(4+5j);
+// tooth m of the new comb, 2^(16m) * 2G, is 2 T_a doubled 16m - 18a <= 17 times (28 lanes), every entry is
+// the signed sum of 7 teeth (256 lanes, 6 additions) and one inversion per lane makes it an affine niels.
+// About 0.4 ms of latency on one block: worth it from 2^18 operations on (goldilocks_amd.hip).  The base
+// is 2G, so the multiplying kernel halves its scalars.  Launch with exactly one block of comb_big::ENTRIES lanes.
+GD_KERNEL k_recomb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) {
+    static_assert(comb_big::ENTRIES == BLOCK, "one lane per entry, one block");
+    __shared__ uint4 s_teeth[comb_big::TEETH * comb_big::COMBS * 16];
+    const uint32_t e = threadIdx.x;
+    const auto ref_entry = [&](uint32_t j, uint32_t idx) {
+        const uint4 *q = comb + 12 * (16 * j + idx);
+        niels n;
+        n.a = fe_load(q);
+        n.b = fe_load(q + 4);
+        n.cn = fe_load(q + 8);
+        return n;
+    };
+    if (e < (uint32_t)(comb_big::TEETH * comb_big::COMBS)) {
+        const uint32_t bit = comb_big::SPACING * e, a = bit / 18, extra = bit - 18 * a, j = a / 5, k = a % 5;
+        pt t = niels_to_pt(ref_entry(j, k < 4 ? 1u << k : 15u), false);
+        pt_add_niels(t, ref_entry(j, 0), k < 4, true);              // 2 T_a
+#pragma unroll 1
+        for (uint32_t d = 0; d < extra; d++) pt_double(t, true);
+        pniels_store(s_teeth + 16 * e, pt_to_pniels(t));
+    }
+    __syncthreads();
+    const uint32_t j = e / comb_big::PER_COMB, idx = e % comb_big::PER_COMB;
+    pt p = pniels_to_pt(pniels_load(s_teeth + 16 * (comb_big::TEETH - 1 + comb_big::TEETH * j)), false);
+#pragma unroll 1
+    for (uint32_t k = 0; k + 1 < (uint32_t)comb_big::TEETH; k++)
+        pt_add_pniels(p, pniels_load(s_teeth + 16 * (k + comb_big::TEETH * j)), ((idx >> k) & 1u) == 0, true);
     fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
     uint4 *q = dst + 12 * (size_t)e;
     fe_store(q, fe_mul(fe_weak(fe_sub<2>(p.y, p.x)), zi));

@@ -39,6 +39,40 @@ def test_full_size_fixed_base_three_ways(ga, O):
     assert (got == _gen.oracle_encode(_gen.oracle_fixed(O, s[idx]))).all()
 
 
+def test_large_batches_on_a_callers_table_are_recombed(ga, O):
+    """From 2^18 operations on, goldilocks_448_precomputed_scalarmul re-combs the caller's 5 x 5 x 18 table to the
+    4 x 7 x 16 comb of twice its base point (k_recomb_big) and halves the scalars: the same group elements as the
+    reference comb (a batch just below the threshold), as the variable-base ladder on the table's point, and as
+    the oracle; edge scalars first."""
+    import torch
+    from _libs import Q
+    n = (1 << 18) + 77
+    point = _gen.oracle_fixed(O, _gen.scalars_from_ints([0x1234567 ** 9 % Q]))[0]
+    tab = ga.precompute(point)
+    edge = [0, 1, 2, 3, Q - 1, Q - 2, (Q - 1) // 2, (Q + 1) // 2, 2**445, 2**16, 2**16 - 1, 2**432, 2**433 - 1]
+    s = _gen.stream_scalars(n, b"full/recomb")
+    s[:len(edge)] = _gen.scalars_from_ints(edge)
+    ds = torch.from_numpy(s.view(np.int64)).cuda()
+    dtab = torch.from_numpy(np.ascontiguousarray(tab).view(np.uint8)).cuda()
+    base = torch.from_numpy(np.repeat(point.reshape(1, 32), n, axis=0).view(np.int64)).cuda()
+    a, b, c = (torch.empty((n, 32), dtype=torch.int64, device="cuda") for _ in range(3))
+    ga.dev("precomputed_scalarmul", a.data_ptr(), dtab.data_ptr(), ds.data_ptr(), n, None)              # re-combed
+    m = (1 << 18) - 1
+    ga.dev("precomputed_scalarmul", b.data_ptr(), dtab.data_ptr(), ds.data_ptr(), m, None)              # the reference comb
+    ga.dev("point_scalarmul", c.data_ptr(), base.data_ptr(), ds.data_ptr(), n, None)
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    ga.dev("point_pred", st.data_ptr(), a.data_ptr(), c.data_ptr(), 0, n, None)
+    assert int((st == -1).sum()) == n
+    ga.dev("point_pred", st.data_ptr(), a.data_ptr(), b.data_ptr(), 0, m, None)
+    assert int((st[:m] == -1).sum()) == m
+    ga.dev("point_pred", st.data_ptr(), a.data_ptr(), None, 1, n, None)     # on the curve
+    assert int((st == -1).sum()) == n
+    k = 300
+    got = ga.point_encode_batch(a[:k].cpu().numpy().view(np.uint64))
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, np.repeat(point.reshape(1, 32), k, axis=0), s[:k]))
+    assert (got == want).all()
+
+
 def test_full_size_sign_verify_round_trip(ga, O):
     """derive -> sign -> verify on 2^20 independent keys: every signature verifies, exactly the lanes
     whose signature, key or message was corrupted are rejected; a sample is bit-exact vs the oracle."""
