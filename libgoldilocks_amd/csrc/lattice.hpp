@@ -16,7 +16,7 @@
 // accepts those signatures) and the image, of order 4q/4, is the subgroup of order q; the base point
 // generates it.  There point_eq's "equal up to 2-torsion" (src/goldilocks.c:644-653) is plain equality,
 // D = S*B - h*A - R is the identity iff tau*D is for any tau prime to q, and scalars act modulo q.
-// (tests/test_oracle_golden.py checks q*P = 0 for every decodable point of F7, torsion-shifted and
+// (A CPU test checks q*P = 0 for every decodable point of fixtures F7 and F3, torsion-shifted and
 // small-order encodings included.)
 //
 // The pair comes from the Euclidean remainder sequence of (q, h) with its cofactors, stopped at the first
@@ -161,16 +161,6 @@ GD_FN void lincomb_words(uint32_t (&out)[N], const uint32_t (&x)[N], uint32_t a,
     }
 }
 
-template <int N>
-GD_FN void negate_if(uint32_t (&w)[N], bool doit) {   // two's complement
-    uint64_t n = 1;
-#pragma unroll
-    for (int i = 0; i < N; i++) {
-        n += (uint32_t)~w[i];
-        w[i] = doit ? (uint32_t)n : w[i];
-        n >>= 32;
-    }
-}
 // The short pair for challenge h (< q):  0 <= rho < 2^223, 0 < |tau| < 2^223, rho == tau * h (mod q).
 //
 // Lehmer's method (Knuth, TAOCP vol. 2, 4.5.2, Algorithm L): the quotients of the remainder sequence are
