@@ -27,8 +27,69 @@ using namespace gd;
         }                                                              \
     } while (0)
 
+// ---- variant: the same square as the library's with the cross terms doubled on the OPERANDS (2x arrays, 24
+// shifts per square) instead of once per finished column -- the library's version until round 2
+namespace opdbl {
+struct sq8 {
+    uint32_t x[8], x2[8];
+};
+template <int COL>
+GD_FN void sq_col(acc_t &acc, const sq8 &s) {  // acc += column COL (0..14) of x^2
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = COL - j;
+        if (k < 0 || k > 7 || j > k) continue;
+        if (j == k) acc.mac(s.x[j], s.x[j]);
+        else acc.mac(s.x2[j], s.x[k]);
+    }
+}
+template <int I>
+GD_FN void sqr_column(fe &c, acc_t &lo, acc_t &hi, const sq8 &u, const sq8 &v, const sq8 &s, const uint32_t (&t)[8]) {
+    sq_col<I>(lo, u);
+    sq_col<I>(lo, v);
+    mul_col<I>(hi, v.x, t);
+    if (I < 7) {
+        mul_col<I + 8>(lo, v.x, t);
+        sq_col<I + 8>(hi, s);
+        sq_col<I + 8>(hi, v);
+    }
+    c.v[I] = lo.lo28();
+    c.v[I + 8] = hi.lo28();
+    lo.shr28();
+    hi.shr28();
+}
+GD_FN fe fe_sqr(const fe &a) {
+    sq8 u, v, s;
+    uint32_t t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u.x[j] = a.v[j];
+        v.x[j] = a.v[j + 8];
+        s.x[j] = a.v[j] + a.v[j + 8];
+        u.x2[j] = u.x[j] << 1;
+        v.x2[j] = v.x[j] << 1;
+        s.x2[j] = s.x[j] << 1;
+        t[j] = u.x2[j] + v.x[j];
+    }
+    fe c;
+    acc_t lo, hi;
+    sqr_column<0>(c, lo, hi, u, v, s, t);
+    sqr_column<1>(c, lo, hi, u, v, s, t);
+    sqr_column<2>(c, lo, hi, u, v, s, t);
+    sqr_column<3>(c, lo, hi, u, v, s, t);
+    sqr_column<4>(c, lo, hi, u, v, s, t);
+    sqr_column<5>(c, lo, hi, u, v, s, t);
+    sqr_column<6>(c, lo, hi, u, v, s, t);
+    sqr_column<7>(c, lo, hi, u, v, s, t);
+    fe_fold_tails(c, lo, hi);
+    return c;
+}
+}  // namespace opdbl
+
 // ---- variant: Karatsuba square, 108 MACs + 7 64-bit add/sub per column pair (round-1 original)
 namespace kar {
+using opdbl::sq8;
+using opdbl::sq_col;
 template <int I>
 GD_FN void sqr_column(fe &c, acc_t &lo, acc_t &hi, const sq8 &u, const sq8 &v, const sq8 &s) {
     acc_t A, Cw, E;
@@ -117,7 +178,7 @@ GD_FN fe fe_mul(const fe &a, const fe &b) {
 }
 }  // namespace direct
 
-enum Op { MUL, SQR, SQR_KAR, MUL_DIRECT, DBL, ADD_WEAK };
+enum Op { MUL, SQR, SQR_KAR, MUL_DIRECT, DBL, ADD_WEAK, SQR_OPDBL };
 
 template <int OP>
 __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
@@ -138,6 +199,7 @@ __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
             if (OP == MUL) x = fe_mul(x, y);
             if (OP == SQR) x = fe_sqr(x);
             if (OP == SQR_KAR) x = kar::fe_sqr(x);
+            if (OP == SQR_OPDBL) x = opdbl::fe_sqr(x);
             if (OP == MUL_DIRECT) x = direct::fe_mul(x, y);
             if (OP == ADD_WEAK) x = fe_weak(fe_add(x, y));
         }
@@ -183,6 +245,7 @@ int main() {
         run<MUL_DIRECT>("mul_direct", d, 256, w);
         run<SQR>("sqr", d, 136, w);
         run<SQR_KAR>("sqr_kar", d, 108, w);
+        run<SQR_OPDBL>("sqr_opdbl", d, 136, w);
         run<DBL>("pt_double", d, 4 * 136 + 3 * 192, w);
         run<ADD_WEAK>("add+weak", d, 0, w);
     }
