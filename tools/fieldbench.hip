@@ -178,7 +178,171 @@ GD_FN fe fe_mul(const fe &a, const fe &b) {
 }
 }  // namespace direct
 
-enum Op { MUL, SQR, SQR_KAR, MUL_DIRECT, DBL, ADD_WEAK, SQR_OPDBL };
+// ---- prototype (timing only): SIGNED limbs.  Differences need no bias (a - b instead of a + K p - b: one
+// instruction per limb instead of two), products are v_mad_i64_i32, carries arithmetic shifts.  The doubling
+// below has the library's shape (4 squarings, 3 products, one weak reduction) without the three bias additions.
+namespace sgn {
+struct sfe {
+    int32_t v[16];
+};
+struct sacc {
+    int64_t x = 0;
+    GD_MFN void mac(int32_t a, int32_t b) {
+        x += (int64_t)a * b;
+        asm("" : "+v"(x));
+    }
+    GD_MFN void add(const sacc &o) { x += o.x; }
+    GD_MFN void add_doubled(const sacc &o) { x += o.x << 1; }
+    GD_MFN void sub(const sacc &o) { x -= o.x; }
+    GD_MFN int32_t lo28() const { return (int32_t)((uint32_t)x & M28); }
+    GD_MFN void shr28() { x >>= 28; }
+};
+GD_FN void fold_tails(sfe &c, sacc lo, sacc hi) {
+    lo.add(hi);
+    lo.x += c.v[8];
+    hi.x += c.v[0];
+    c.v[8] = lo.lo28();
+    c.v[0] = hi.lo28();
+    lo.shr28();
+    hi.shr28();
+    c.v[9] += (int32_t)lo.x;
+    c.v[1] += (int32_t)hi.x;
+}
+GD_FN sfe mul(const sfe &a, const sfe &b) {
+    int32_t sa[8], sb[8], sbb[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        sa[j] = a.v[j] + a.v[j + 8];
+        sb[j] = b.v[j] + b.v[j + 8];
+        sbb[j] = sb[j] + b.v[j + 8];
+    }
+    sfe c;
+    sacc lo, hi;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        sacc cross;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (j <= i) {
+                cross.mac(a.v[j], b.v[i - j]);
+                hi.mac(sa[j], sb[i - j]);
+                lo.mac(a.v[j + 8], b.v[i - j + 8]);
+            } else {
+                cross.mac(a.v[j], b.v[i - j + 16]);
+                hi.mac(sa[j], sbb[i - j + 8]);
+                lo.mac(a.v[j + 8], sb[i - j + 8]);
+            }
+        }
+        hi.sub(cross);
+        lo.add(cross);
+        c.v[i] = lo.lo28();
+        c.v[i + 8] = hi.lo28();
+        lo.shr28();
+        hi.shr28();
+    }
+    fold_tails(c, lo, hi);
+    return c;
+}
+template <int COL>
+GD_FN void sq_col(sacc &cross, sacc &rest, const int32_t (&x)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = COL - j;
+        if (k < 0 || k > 7 || j > k) continue;
+        if (j == k) rest.mac(x[j], x[j]);
+        else cross.mac(x[j], x[k]);
+    }
+}
+template <int COL>
+GD_FN void mul_col(sacc &acc, const int32_t (&x)[8], const int32_t (&y)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int k = COL - j;
+        if (k < 0 || k > 7) continue;
+        acc.mac(x[j], y[k]);
+    }
+}
+template <int I>
+GD_FN void sqr_column(sfe &c, sacc &lo, sacc &hi, const int32_t (&u)[8], const int32_t (&v)[8], const int32_t (&s)[8],
+                      const int32_t (&t)[8]) {
+    sacc lo_cross, hi_cross;
+    sq_col<I>(lo_cross, lo, u);
+    sq_col<I>(lo_cross, lo, v);
+    mul_col<I>(hi, v, t);
+    if (I < 7) {
+        mul_col<I + 8>(lo, v, t);
+        sq_col<I + 8>(hi_cross, hi, s);
+        sq_col<I + 8>(hi_cross, hi, v);
+    }
+    if (I > 0) lo.add_doubled(lo_cross);
+    if (I < 7) hi.add_doubled(hi_cross);
+    c.v[I] = lo.lo28();
+    c.v[I + 8] = hi.lo28();
+    lo.shr28();
+    hi.shr28();
+}
+GD_FN sfe sqr(const sfe &a) {
+    int32_t u[8], v[8], s[8], t[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        u[j] = a.v[j];
+        v[j] = a.v[j + 8];
+        s[j] = a.v[j] + a.v[j + 8];
+        t[j] = (a.v[j] << 1) + a.v[j + 8];
+    }
+    sfe c;
+    sacc lo, hi;
+    sqr_column<0>(c, lo, hi, u, v, s, t);
+    sqr_column<1>(c, lo, hi, u, v, s, t);
+    sqr_column<2>(c, lo, hi, u, v, s, t);
+    sqr_column<3>(c, lo, hi, u, v, s, t);
+    sqr_column<4>(c, lo, hi, u, v, s, t);
+    sqr_column<5>(c, lo, hi, u, v, s, t);
+    sqr_column<6>(c, lo, hi, u, v, s, t);
+    sqr_column<7>(c, lo, hi, u, v, s, t);
+    fold_tails(c, lo, hi);
+    return c;
+}
+GD_FN sfe add(const sfe &a, const sfe &b) {
+    sfe c;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c.v[i] = a.v[i] + b.v[i];
+    return c;
+}
+GD_FN sfe sub(const sfe &a, const sfe &b) {
+    sfe c;
+#pragma unroll
+    for (int i = 0; i < 16; i++) c.v[i] = a.v[i] - b.v[i];
+    return c;
+}
+GD_FN sfe weak(const sfe &a) {
+    sfe c;
+    const int32_t top = a.v[15] >> 28;
+    c.v[0] = (a.v[0] & (int32_t)M28) + top;
+#pragma unroll
+    for (int i = 1; i < 16; i++) c.v[i] = (a.v[i] & (int32_t)M28) + (a.v[i - 1] >> 28);
+    c.v[8] += top;
+    return c;
+}
+struct spt {
+    sfe x, y, z, t;
+};
+GD_FN void dbl(spt &p) {
+    sfe c = sqr(p.x);
+    sfe a = sqr(p.y);
+    sfe d = add(c, a);
+    sfe s = add(p.x, p.y);
+    sfe b = sub(sqr(s), d);
+    sfe tt = sub(a, c);
+    sfe zz = sqr(p.z);
+    sfe e = weak(sub(add(zz, zz), tt));
+    p.x = mul(e, b);
+    p.z = mul(e, tt);
+    p.y = mul(d, tt);
+}
+}  // namespace sgn
+
+enum Op { MUL, SQR, SQR_KAR, MUL_DIRECT, DBL, ADD_WEAK, SQR_OPDBL, DBL_SIGNED };
 
 template <int OP>
 __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
@@ -189,7 +353,18 @@ __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
         x.v[i] = io[t * 32 + i] & M28;
         y.v[i] = io[t * 32 + 16 + i] & M28;
     }
-    if (OP == DBL) {
+    if (OP == DBL_SIGNED) {
+        sgn::spt p;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            p.x.v[i] = (int32_t)x.v[i];
+            p.y.v[i] = (int32_t)y.v[i];
+            p.z.v[i] = (int32_t)((x.v[i] + y.v[i]) & M28);
+        }
+        for (int k = 0; k < n; k++) sgn::dbl(p);
+#pragma unroll
+        for (int i = 0; i < 16; i++) x.v[i] = (uint32_t)(p.x.v[i] + p.y.v[i] + p.z.v[i]);
+    } else if (OP == DBL) {
         pt p;
         p.x = x; p.y = y; p.z = fe_add(x, y); p.z = fe_weak(p.z); p.t = x;
         for (int k = 0; k < n; k++) pt_double(p, false);
@@ -247,6 +422,7 @@ int main() {
         run<SQR_KAR>("sqr_kar", d, 108, w);
         run<SQR_OPDBL>("sqr_opdbl", d, 136, w);
         run<DBL>("pt_double", d, 4 * 136 + 3 * 192, w);
+        run<DBL_SIGNED>("dbl_signed", d, 4 * 136 + 3 * 192, w);
         run<ADD_WEAK>("add+weak", d, 0, w);
     }
     return 0;
