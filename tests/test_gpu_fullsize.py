@@ -73,6 +73,35 @@ def test_large_batches_on_a_callers_table_are_recombed(ga, O):
     assert (got == want).all()
 
 
+def test_index_independent_sign_over_several_rounds_of_one_launch(ga, O):
+    """Key derivation and signing in the library's default mode through the device entry points, 400 017
+    operations in ONE launch: every lane handles four operations, and between them the block re-stages the base
+    point's comb over the LDS region its SHAKE blocks were hashed in (RestagedCombBig).  Every signature must
+    verify; a sample is byte-exact against the oracle (RFC 8032 signing is deterministic)."""
+    import ctypes as C
+    import torch
+    assert ga.get_table_access() == ga.TABLES_INDEX_INDEPENDENT
+    n = 400017
+    sk_h = np.frombuffer(_gen.stream(b"full/ct-sign/sk", 57 * n), np.uint8).reshape(n, 57).copy()
+    msg_h = np.frombuffer(_gen.stream(b"full/ct-sign/msg", 32 * n), np.uint8).reshape(n, 32).copy()
+    sk, msg = torch.from_numpy(sk_h).cuda(), torch.from_numpy(msg_h).cuda()
+    pk = torch.empty((n, 57), dtype=torch.uint8, device="cuda")
+    sig = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    ga.dev("ed448_derive_public_key", pk.data_ptr(), sk.data_ptr(), n, None)
+    ga.dev("ed448_sign", sig.data_ptr(), sk.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0, None, 0, n, None)
+    ga.dev("ed448_verify", st.data_ptr(), sig.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0, None, 0, n, None)
+    assert int((st == -1).sum()) == n
+    idx = np.concatenate([np.arange(4), np.random.default_rng(19).integers(0, n, 120), np.arange(n - 4, n)])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    sub_sk, sub_msg = np.ascontiguousarray(sk_h[idx]), np.ascontiguousarray(msg_h[idx])
+    want_pk = np.empty((len(idx), 57), np.uint8)
+    want_sig = np.empty((len(idx), 114), np.uint8)
+    O.orc_ed448_derive_public_key_batch(p(want_pk), p(sub_sk), len(idx), _gen.NTHREADS)
+    O.orc_ed448_sign_batch(p(want_sig), p(sub_sk), p(want_pk), p(sub_msg), 32, 0, None, 0, len(idx), _gen.NTHREADS)
+    assert (pk.cpu().numpy()[idx] == want_pk).all() and (sig.cpu().numpy()[idx] == want_sig).all()
+
+
 def test_full_size_sign_verify_round_trip(ga, O):
     """derive -> sign -> verify on 2^20 independent keys: every signature verifies, exactly the lanes
     whose signature, key or message was corrupted are rejected; a sample is bit-exact vs the oracle."""
