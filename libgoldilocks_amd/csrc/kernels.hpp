@@ -498,6 +498,13 @@ extern "C" __global__ void k_ed448_sign_wave(uint8_t *__restrict__ sig, const ui
                                              const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets,
                                              uint32_t msg_len, uint32_t prehashed, const uint8_t *__restrict__ ctx, uint32_t ctx_len,
                                              uint32_t n, const uint4 *__restrict__ comb);
+extern "C" __global__ void k_direct_scalarmul_wave(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                                                   const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar,
+                                                   uint32_t n, int allow_identity, int short_circuit,
+                                                   const uint64_t *__restrict__ point_base_abi);
+extern "C" __global__ void k_point_dual_scalarmul_wave(uint64_t *a1, uint64_t *a2, const uint64_t *base,
+                                                       const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2,
+                                                       uint32_t n);
 extern "C" __global__ void k_wave_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, const uint64_t *__restrict__ a,
                                            const uint64_t *__restrict__ b, uint32_t n, int op);
 extern "C" __global__ void k_ed448_verify_wave(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,

@@ -25,6 +25,53 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_point_scalarmul_wave(uint6
     if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
 }
 
+// scaled[i] = encode(scalar[i] * decode(base[i])), one operation per wave; an encoding that does not decode gives
+// status 0 and (unless short_circuit) the base point is multiplied instead   (ref: goldilocks_448_direct_scalarmul,
+// src/goldilocks.c:888-903)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_direct_scalarmul_wave(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                                                                            const uint8_t *__restrict__ base,
+                                                                            const uint64_t *__restrict__ scalar, uint32_t n,
+                                                                            int allow_identity, int short_circuit,
+                                                                            const uint64_t *__restrict__ point_base_abi) {
+    __shared__ uint32_t s_tab[BLOCK / 64][wc::TABLE_WORDS];
+    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    const wc::Lane L = wc::make_lane();
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    const wc::WaveTable tab{s_tab[w]};
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + w; op < n; op += nwaves) {   // wave-uniform
+        wc::wfe P;
+        const bool ok = wc::decode(L, base + 56 * (size_t)op, allow_identity != 0, P);
+        if ((threadIdx.x & 63u) == 0) status[op] = ok ? -1 : 0;
+        if (!ok && short_circuit) continue;                 // the encoding is public: so is this branch
+        if (!ok) P = wc::load_point(L, point_base_abi);     // src/goldilocks.c:898
+        const wc::wfe r = wc::scalarmul(L, tab, s_bits[w], P, sc_load_abi(scalar + 7 * (size_t)op));
+        wc::encode(L, scaled + 56 * (size_t)op, r);
+    }
+    if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
+}
+
+// (a1[i], a2[i]) = (s1[i], s2[i]) * base[i], one operation per wave: the table is built once and walked twice
+// (ref: goldilocks_448_point_dual_scalarmul, src/goldilocks.c:543-642).  a1 may alias base.
+extern "C" __global__ void __launch_bounds__(BLOCK) k_point_dual_scalarmul_wave(uint64_t *a1, uint64_t *a2, const uint64_t *base,
+                                                                                const uint64_t *__restrict__ s1,
+                                                                                const uint64_t *__restrict__ s2, uint32_t n) {
+    __shared__ uint32_t s_tab[BLOCK / 64][wc::TABLE_WORDS];
+    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    const wc::Lane L = wc::make_lane();
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    const wc::WaveTable tab{s_tab[w]};
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + w; op < n; op += nwaves) {   // wave-uniform
+        wc::build_table(L, tab, wc::load_point(L, base + 32 * (size_t)op));
+        const wc::wfe r1 = wc::walk_table(L, tab, s_bits[w], sc_load_abi(s1 + 7 * (size_t)op));
+        const wc::wfe r2 = wc::walk_table(L, tab, s_bits[w], sc_load_abi(s2 + 7 * (size_t)op));
+        wc::store_point(L, a1 + 32 * (size_t)op, r1);
+        wc::store_point(L, a2 + 32 * (size_t)op, r2);
+    }
+    if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
+}
+
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i], one operation per wave; b1 == nullptr: b1 is the base point through
 // its window table (goldilocks_448_base_double_scalarmul_non_secret: public scalars by contract).
 // (ref: goldilocks_448_point_double_scalarmul, src/goldilocks.c:467-541, :1260-1330).  out may alias b2.

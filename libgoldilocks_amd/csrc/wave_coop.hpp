@@ -234,14 +234,9 @@ struct WaveTable {
     }
 };
 
-// out = scalar * base for ONE operation handled by this wave.  bits: the wave's 15-word LDS slot.
-__device__ __forceinline__ wfe scalarmul(const Lane &L, const WaveTable &tab, uint32_t *bits, wfe B, const sc &k) {
+// The 16 odd multiples of B as projective niels into the wave's LDS table (src/goldilocks.c:382-403).
+__device__ __forceinline__ void build_table(const Lane &L, const WaveTable &tab, wfe B) {
     const uint32_t swap_row = L.row ^ 1u;    // rows (1, 0, 3, 2)
-    const sc r = sc_recode_signed(k);
-#pragma unroll
-    for (int w = 0; w < 14; w++) bits[w] = r.w[w];    // every lane writes the same words
-    bits[14] = 0;
-    // table of odd multiples (src/goldilocks.c:382-403)
     tab.store(L, 16, to_pniels(L, dbl(L, B), swap_row));
     tab.store(L, 0, to_pniels(L, B, swap_row));
     wfe acc = B;
@@ -253,6 +248,15 @@ __device__ __forceinline__ wfe scalarmul(const Lane &L, const WaveTable &tab, ui
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// scalar * (the table's point): 90 signed 5-bit windows over the table (index-independent lookups).
+// bits: the wave's 15-word LDS slot.
+__device__ __forceinline__ wfe walk_table(const Lane &L, const WaveTable &tab, uint32_t *bits, const sc &k) {
+    const uint32_t swap_row = L.row ^ 1u;
+    const sc r = sc_recode_signed(k);
+#pragma unroll
+    for (int w = 0; w < 14; w++) bits[w] = r.w[w];    // every lane writes the same words
+    bits[14] = 0;
     struct Bits {
         const uint32_t *p;
         __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
@@ -260,7 +264,7 @@ __device__ __forceinline__ wfe scalarmul(const Lane &L, const WaveTable &tab, ui
     uint32_t idx;
     bool neg;
     signed_digit(window5(rb, 445), idx, neg);
-    acc = add_entry(L, identity(L), tab.lookup(L, idx, neg), neg, swap_row);
+    wfe acc = add_entry(L, identity(L), tab.lookup(L, idx, neg), neg, swap_row);
 #pragma unroll 1
     for (int pos = 440; pos >= 0; pos -= 5) {
         signed_digit(window5(rb, pos), idx, neg);
@@ -269,6 +273,11 @@ __device__ __forceinline__ wfe scalarmul(const Lane &L, const WaveTable &tab, ui
         acc = add_entry(L, acc, tab.lookup(L, idx, neg), neg, swap_row);
     }
     return acc;
+}
+// out = scalar * base for ONE operation handled by this wave.
+__device__ __forceinline__ wfe scalarmul(const Lane &L, const WaveTable &tab, uint32_t *bits, wfe B, const sc &k) {
+    build_table(L, tab, B);
+    return walk_table(L, tab, bits, k);
 }
 
 // ---------------------------------------------------------------- canonical form, predicates (per row)
@@ -578,6 +587,63 @@ __device__ __forceinline__ void encode_x448(const Lane &L, uint8_t *out56, wfe P
     const wfe xi = invert(L, from_row<0>(L, P));
     const wfe r = mul(L, from_row<1>(L, P), xi);
     store_bytes<0>(L, out56, strong(L, mul(L, r, r)));
+}
+
+// ---------------------------------------------------------------- decaf wire format (direct_scalarmul)
+
+__device__ __forceinline__ wfe factor(const Lane &L) { return FACTOR28[L.i]; }   // 1/sqrt(39082/39081 - 1), point.hpp
+
+// Decaf decoding (cf. pt_decode_words, src/goldilocks.c:142-176): every row computes the same field
+// elements; P = rows (X, Y, 1, T).  Returns success (wave-uniform).
+__device__ __forceinline__ bool decode(const Lane &L, const uint8_t *ser56, bool allow_identity, wfe &P) {
+    bool below, sq;
+    const wfe s = deserialize(L, ser56, below);
+    const bool zero = is_zero(L, s), odd = lobit(L, s);
+    bool ok = below && (allow_identity || !zero) && !odd;
+    const wfe s2 = mul(L, s, s);
+    const wfe den = weak(L, sub<2>(L, one(L), s2));                  // 1 - s^2
+    const wfe ynum = one(L) + s2;                                    // 1 + s^2       mag 2
+    const wfe den2 = mul(L, den, den);
+    const wfe num = weak(L, den2 + mulw(L, s2, FOUR_EFF_D));         // den^2 - 4 d' s^2
+    const wfe r = isr(L, mul(L, num, den2), sq);
+    ok = ok && sq;
+    const wfe tmp = mul(L, r, den);
+    const wfe y = mul(L, tmp, ynum);
+    wfe w = mul(L, tmp, s);
+    w = w + w;                                                       // 2 s isr den   mag 2
+    wfe x = mul(L, mul(L, w, r), num);
+    {   // cross-lane operations with every lane active: both candidates, then a plain select
+        const wfe nx = neg(L, x);
+        const bool flip = lobit(L, mul(L, w, factor(L)));
+        x = weak(L, flip ? nx : x);
+    }
+    const wfe t = mul(L, x, y);
+    P = L.row == 0 ? x : (L.row == 1 ? y : (L.row == 2 ? one(L) : t));
+    return ok;
+}
+// Decaf encoding (cf. pt_encode_words, src/goldilocks.c:98-140): 56 canonical bytes at out
+__device__ __forceinline__ void encode(const Lane &L, uint8_t *out56, wfe P) {
+    const wfe x = from_row<0>(L, P), z = from_row<2>(L, P), t = from_row<3>(L, P);
+    const wfe num = mul(L, x + t, weak(L, sub<2>(L, x, t)));         // (X+T)(X-T)
+    const wfe x2 = mul(L, x, x);
+    const wfe t2 = mulw(L, mul(L, x2, num), NEG_EDWARDS_D);          // 39081 X^2 num
+    bool sq;
+    const wfe r = isr(L, t2, sq);
+    wfe ratio = mul(L, r, num);
+    {
+        const wfe nr = neg(L, ratio);
+        const bool negx = lobit(L, mul(L, ratio, factor(L)));
+        ratio = weak(L, negx ? nr : ratio);
+    }
+    const wfe t3 = weak(L, sub<2>(L, mul(L, ratio, z), t));
+    const wfe t4 = mulw(L, mul(L, t3, x), NEG_EDWARDS_D);
+    wfe sres = mul(L, t4, r);
+    {
+        const wfe ns = neg(L, sres);
+        const bool lo = lobit(L, sres);
+        sres = lo ? ns : sres;
+    }
+    store_bytes<0>(L, out56, strong(L, sres));
 }
 
 struct WaveBits {   // the wave's recoded scalar in LDS

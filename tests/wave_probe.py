@@ -78,7 +78,8 @@ for mx, name in ((8192, "wave"), (0, "lane")):
                       (lambda: ga.ed448_derive_public_key_batch(sk1), "ed448_derive_public_key"),
                       (lambda: ga.ed448_sign_batch(sk1, pk1, [b"hello"]), "ed448_sign"),
                       (lambda: ga.x448_batch(xs1), "x448_derive_public_key"),
-                      (lambda: ga.x448_batch(xs1, pub1), "x448")):
+                      (lambda: ga.x448_batch(xs1, pub1), "x448"),
+                      (lambda: ga.point_dual_scalarmul_batch(pt, sc1, sc1), "point_dual_scalarmul")):   # direct_scalarmul: tests/direct_probe.py
         fn(); t0 = time.perf_counter()
         for _ in range(20): fn()
         print("single call %-24s %-5s %.3f ms" % (label, name, (time.perf_counter() - t0) / 20 * 1e3), flush=True)
