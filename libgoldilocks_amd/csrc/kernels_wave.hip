@@ -25,6 +25,17 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_point_scalarmul_wave(uint6
     if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
 }
 
+// tables[i] = the 5 x 5 x 18 comb of base[i] in the reference's format, one table per wave (ref: goldilocks_448_precompute)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_precompute_wave(uint64_t *__restrict__ tables, const uint64_t *__restrict__ base,
+                                                                      uint32_t n) {
+    __shared__ uint32_t s_work[BLOCK / 64][wc::PRECOMP_WAVE_WORDS];
+    const wc::Lane L = wc::make_lane();
+    const uint32_t w = threadIdx.x >> 6;
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + w; op < n; op += nwaves)   // wave-uniform
+        wc::precompute(L, s_work[w], tables + (size_t)op * (80 * 24), wc::load_point(L, base + 32 * (size_t)op));
+}
+
 // scaled[i] = encode(scalar[i] * decode(base[i])), one operation per wave; an encoding that does not decode gives
 // status 0 and (unless short_circuit) the base point is multiplied instead   (ref: goldilocks_448_direct_scalarmul,
 // src/goldilocks.c:888-903)

@@ -589,6 +589,72 @@ __device__ __forceinline__ void encode_x448(const Lane &L, uint8_t *out56, wfe P
     store_bytes<0>(L, out56, strong(L, mul(L, r, r)));
 }
 
+// ---------------------------------------------------------------- precompute: the 5 x 5 x 18 comb of one point
+
+// goldilocks_448_precompute by ONE wave (cf. k_precompute, src/goldilocks.c:755-818): the chain of 449 doublings
+// through the teeth 2^(18a) P, a Gray-code walk over the 16 sign patterns of each comb (one addition of a
+// doubled tooth per entry), then Montgomery's trick over the 80 values 2Z and the reference's table format
+// (80 x {a, b, c}, canonical 56-bit limbs).  lds: 80 entries + 4 doubled teeth of 64 words, 80 prefixes of 16.
+constexpr int PRECOMP_WAVE_WORDS = 84 * 64 + 80 * 16;
+__device__ __forceinline__ void precompute(const Lane &L, uint32_t *lds, uint64_t *table, wfe P) {
+    const uint32_t swap_row = L.row ^ 1u, me = threadIdx.x & 63u;
+    uint32_t *entry = lds, *teeth = lds + 80 * 64, *prefix = lds + 84 * 64;
+    wfe working = P;
+#pragma unroll 1
+    for (int j = 0; j < 5; j++) {
+        wfe start = working;   // becomes tooth_0 + ... + tooth_4 of this comb
+#pragma unroll 1
+        for (int k = 0; k < 5; k++) {
+            if (k) start = add_entry(L, start, to_pniels(L, working, swap_row), false, swap_row);
+            if (k == 4 && j == 4) break;
+            working = dbl(L, working);
+            if (k < 4) teeth[k * 64 + me] = to_pniels(L, working, swap_row);   // 2 * tooth_k
+#pragma unroll 1
+            for (int d = 0; d < 17; d++) working = dbl(L, working);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+        for (uint32_t g = 0;; g++) {
+            const uint32_t gray = g ^ (g >> 1);
+            const uint32_t idx = (((j + 1) << 4) - 1) ^ gray;
+            entry[idx * 64 + me] = to_pniels(L, start, swap_row);              // rows (Y-X, Y+X, 2*39082*T, 2Z)
+            if (g >= 15) break;
+            const uint32_t delta = (g + 1) ^ ((g + 1) >> 1) ^ gray;            // the Gray bit that flips
+            const uint32_t k = 31 - __clz(delta);
+            const bool neg = (gray & (1u << k)) == 0;
+            const uint32_t frow = (neg && L.row < 2) ? (L.row ^ 1u) : L.row;   // a / b exchanged for a subtraction
+            start = add_entry(L, start, teeth[k * 64 + frow * 16 + L.i], neg, swap_row);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // Montgomery's trick over the 80 values 2Z (src/goldilocks.c:703-726); every row carries the same element
+    wfe acc = one(L);
+#pragma unroll 1
+    for (int e = 0; e < 80; e++) {
+        if (L.row == 0) prefix[e * 16 + L.i] = acc;
+        acc = mul(L, acc, entry[e * 64 + 48 + L.i]);                           // row 3 of the entry: 2Z
+    }
+    wfe inv = invert(L, acc);
+#pragma unroll 1
+    for (int e = 79; e >= 0; e--) {
+        const wfe zi = mul(L, inv, prefix[e * 16 + L.i]);
+        inv = mul(L, inv, entry[e * 64 + 48 + L.i]);
+        const wfe ev = entry[e * 64 + me];
+        wfe abc = mul(L, ev, zi);                                              // ((Y-X)/2Z, (Y+X)/2Z, 78164 T / 2Z, .)
+        {   // c = 2 d' T / 2Z = -(78164 T / 2Z)
+            const wfe n = neg(L, abc);
+            abc = L.row == 2 ? n : abc;
+        }
+        const wfe can = strong(L, abc);
+        const uint32_t nb = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)can, 0x101, 0xF, 0xF, false);   // lane l+1's limb
+        if (L.row < 3 && !(L.i & 1u)) table[24 * e + 8 * L.row + (L.i >> 1)] = (uint64_t)can | ((uint64_t)nb << 28);
+    }
+}
+
 // ---------------------------------------------------------------- decaf wire format (direct_scalarmul)
 
 __device__ __forceinline__ wfe factor(const Lane &L) { return FACTOR28[L.i]; }   // 1/sqrt(39082/39081 - 1), point.hpp

@@ -285,3 +285,32 @@ def test_fixed_base_keygen_and_signing_through_both_paths(ga, O, paths):
                                                prehashed=bool(c["prehashed"]), context=bytes.fromhex(c["context"]))))
         for name in ("wave", "lane"):
             assert r[name][0].tobytes().hex() == c["pk"] and r[name][1].tobytes().hex() == c["sig"], name
+
+
+def test_precompute_by_one_wave_per_table(ga, O):
+    """goldilocks_448_precompute for a handful of points through both paths (one table per wave; one table per
+    lane with the wave path off): 15 360 bytes each, identical to the oracle's table -- which is the reference's."""
+    import ctypes as C
+    import torch
+    from _libs import Point, Precomputed
+    n = 9
+    pts = _gen.oracle_fixed(O, _gen.stream_scalars(n, b"wave/precompute"))
+    pts[0] = ga.point_base()
+    want = []
+    for i in range(n):
+        w = Precomputed()
+        O.orc_precompute(C.byref(w), C.cast(pts[i].ctypes.data_as(C.c_void_p), C.POINTER(Point)))
+        want.append(bytes(w))
+    dp = torch.from_numpy(pts.view(np.int64)).cuda()
+    default = ga.get_wave_batch_max()
+    try:
+        for mx in (default, 0):
+            ga.set_wave_batch_max(mx)
+            tabs = torch.zeros((n, 1920), dtype=torch.int64, device="cuda")
+            ga.dev("precompute", tabs.data_ptr(), dp.data_ptr(), n, None)
+            got = tabs.cpu().numpy()
+            for i in range(n):
+                assert got[i].tobytes() == want[i], (mx, i)
+    finally:
+        ga.set_wave_batch_max(default)
+    assert want[0] == ga.precomputed_base().tobytes()
