@@ -523,6 +523,8 @@ GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, con
 GD_KERNEL_CT k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                    uint4 *__restrict__ workspace);
+GD_KERNEL k_point_encode_eddsa_shared(uint8_t *__restrict__ enc, const uint64_t *__restrict__ pts, uint32_t n,
+                                      uint4 *__restrict__ ws);
 GD_KERNEL k_build_comb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ comb);
 GD_KERNEL k_base_scalarmul_ct(uint64_t *__restrict__ out, const uint4 *__restrict__ comb_big_tab,
                               const uint64_t *__restrict__ scalar, uint32_t n, uint32_t halve);

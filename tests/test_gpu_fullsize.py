@@ -102,6 +102,37 @@ def test_index_independent_sign_over_several_rounds_of_one_launch(ga, O):
     assert (pk.cpu().numpy()[idx] == want_pk).all() and (sig.cpu().numpy()[idx] == want_sig).all()
 
 
+def test_large_eddsa_encode_batches_share_their_inversions(ga, O):
+    """goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa over 2^19 + 5 points: from two residencies on, the
+    points a lane handles share one field inversion (k_point_encode_eddsa_shared).  Same 57 bytes as the
+    one-inversion-per-point kernel (a batch below the threshold), and as the oracle on a sample; the identity and
+    the points of small order are in the batch."""
+    import ctypes as C
+    import torch
+    from _libs import Point
+    n = (1 << 19) + 5
+    k = _gen.stream_scalars(n, b"full/eddsa-enc")
+    k[:3] = _gen.scalars_from_ints([0, 1, 2])
+    dk = torch.from_numpy(k.view(np.int64)).cuda()
+    pts = torch.empty((n, 32), dtype=torch.int64, device="cuda")
+    ga.dev("precomputed_scalarmul", pts.data_ptr(), None, dk.data_ptr(), n, None)
+    a = torch.zeros((n, 57), dtype=torch.uint8, device="cuda")
+    b = torch.zeros((n, 57), dtype=torch.uint8, device="cuda")
+    ga.dev("point_encode_eddsa", a.data_ptr(), pts.data_ptr(), n, None)                 # shared inversions
+    m = 100000
+    for lo in range(0, n, m):                                                            # one inversion per point
+        cnt = min(m, n - lo)
+        ga.dev("point_encode_eddsa", b.data_ptr() + 57 * lo, pts.data_ptr() + 256 * lo, cnt, None)
+    assert bool((a == b).all())
+    idx = np.concatenate([np.arange(6), np.random.default_rng(23).integers(0, n, 100)])
+    ph = pts.cpu().numpy().view(np.uint64)
+    got = a.cpu().numpy()
+    for i in idx:
+        out = (C.c_uint8 * 57)()
+        O.orc_point_encode_like_eddsa(out, C.cast(ph[i].ctypes.data_as(C.c_void_p), C.POINTER(Point)))
+        assert bytes(out) == got[i].tobytes(), int(i)
+
+
 def test_full_size_sign_verify_round_trip(ga, O):
     """derive -> sign -> verify on 2^20 independent keys: every signature verifies, exactly the lanes
     whose signature, key or message was corrupted are rejected; a sample is bit-exact vs the oracle."""
