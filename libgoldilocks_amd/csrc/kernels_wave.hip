@@ -240,13 +240,13 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_ed448_verify_wave(
     int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ pk,
     const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
     const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n, const uint4 *__restrict__ bwt) {
-    __shared__ uint32_t s_tab[BLOCK / 64][wc::TABLE_WORDS];
-    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    __shared__ uint32_t s_tab[BLOCK / 64][2][wc::TABLE_WORDS];
+    __shared__ uint32_t s_bits[BLOCK / 64][32];
     __shared__ uint32_t s_stage[34 * BLOCK];
     const wc::Lane L = wc::make_lane();
     const uint32_t w = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * (BLOCK / 64);
-    const wc::WaveTable tab{s_tab[w]};
+    const wc::WaveTable tab_a{s_tab[w][0]}, tab_r{s_tab[w][1]};
     LdsStage stage{s_stage + threadIdx.x};
     for (uint32_t i = blockIdx.x * (BLOCK / 64) + w; i < n; i += nwaves) {   // wave-uniform
         const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
@@ -254,7 +254,7 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_ed448_verify_wave(
         const bool fits = len64 < MAX_MESSAGE_BYTES;
         const uint32_t mlen = fits ? (uint32_t)len64 : 0u;
         const Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx, ctx_len);
-        const bool ok = wc::verify(L, tab, s_bits[w], m, stage, bwt);
+        const bool ok = wc::verify(L, tab_a, tab_r, s_bits[w], m, stage, bwt);
         if ((threadIdx.x & 63u) == 0) status[i] = ok && fits ? -1 : 0;
     }
 }

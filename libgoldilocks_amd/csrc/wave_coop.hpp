@@ -421,41 +421,66 @@ __device__ __forceinline__ wfe add_base_multiple(const Lane &L, wfe acc, const B
     return acc;
 }
 
-// One Ed448 verification by this wave (cf. ed448_verify_core, src/eddsa.c:253-306): the two point
-// decodings run in rows 0 and 1 of the same instruction stream, the hash and the scalars are computed
-// by every lane alike, the ladder and the base-point additions are the wave ladder above.
+// One Ed448 verification by this wave with half-size scalars (eddsa.hpp ed448_verify_lattice, lattice.hpp):
+// the two point decodings run in rows 0 and 1 of the same instruction stream; the hash and the short pair
+// (rho, tau) of the challenge are computed by every lane alike; then ONE ladder of 45 windows over the tables of
+// A and R (both in LDS, index-independent lookups), the base point's 28 additions, and V == identity.
+// The signs of the lattice method ride on the digits: rho * (-+A) and |tau| * (-R) flip the digits' signs
+// instead of negating the points.  bits: 2 x 16 words of the wave.
 template <class STAGE>
-__device__ __forceinline__ bool verify(const Lane &L, const WaveTable &tab, uint32_t *bits, const Ed448Msg &m, STAGE &stage,
-                                       const uint4 *bwt) {
+__device__ __forceinline__ bool verify(const Lane &L, const WaveTable &tab_a, const WaveTable &tab_r, uint32_t *bits,
+                                       const Ed448Msg &m, STAGE &stage, const uint4 *bwt) {
+    const uint32_t swap_row = L.row ^ 1u;
     // row 0 decodes the public key, row 1 R (the other rows run along on the key)
     const uint8_t *enc = L.row == 1 ? m.a : m.b;
     wfe X, Y, Z, T;
     const bool okrow = decode_eddsa_rows(L, enc, X, Y, Z, T);
     const uint64_t okmask = __builtin_amdgcn_ballot_w64(okrow);
     const bool ok = (okmask & 1u) && ((okmask >> 16) & 1u);
-    const wfe A = pack_point<0>(L, X, Y, Z, T), R = pack_point<1>(L, X, Y, Z, T);
+    build_table(L, tab_a, pack_point<0>(L, X, Y, Z, T));
+    build_table(L, tab_r, pack_point<1>(L, X, Y, Z, T));
 
-    uint32_t w[29];
-    shake256_114(w, m, m.total(), stage);
-    const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));   // -h mod q
-    load_bytes_as_words(w, m.a + 57, 57, 15);
-    const sc response = sc_decode_long_words<57>(w);                        // S mod q, no range check
-
-    wfe P = scalarmul(L, tab, bits, A, challenge);                          // -h*A
-    const sc rs = sc_recode_bwt(response);
+    const LatticePair pr = ed448_verify_lattice_pair(m, stage);      // the same in every lane
+    const bool flip_a = pr.tau_pos;                                  // PA = -A for a positive tau; PR = -R always
 #pragma unroll
-    for (int k = 0; k < 14; k++) bits[k] = rs.w[k];
-    bits[14] = 0;
+    for (int k = 0; k < 15; k++) {
+        bits[k] = pr.b1[k];
+        bits[16 + k] = pr.b2[k];
+    }
     struct Bits {
         const uint32_t *p;
         __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
-    } rb{bits};
-    P = add_base_multiple(L, P, rb, bwt);                                   // + S*B
-    // P == R up to 2-torsion: X_P Y_R == Y_P X_R  (src/goldilocks.c:644-653)
-    const wfe pswap = rows(L, P, L.row ^ 1u);                               // (Y_P, X_P, ...)
-    const wfe prod = mul(L, pswap, R);                                      // (Y_P X_R, X_P Y_R, ...)
-    const bool same = eq(L, from_row<0>(L, prod), from_row<1>(L, prod));
-    return ok && same;
+    } b1{bits}, b2{bits + 16};
+    uint32_t idx;
+    bool neg;
+    constexpr int TOP = 5 * (LATTICE_WINDOWS - 1);
+    signed_digit(window5(b1, TOP), idx, neg);
+    neg = neg != flip_a;
+    wfe V = add_entry(L, identity(L), tab_a.lookup(L, idx, neg), neg, swap_row);
+    signed_digit(window5(b2, TOP), idx, neg);
+    neg = !neg;
+    V = add_entry(L, V, tab_r.lookup(L, idx, neg), neg, swap_row);
+#pragma unroll 1
+    for (int pos = TOP - 5; pos >= 0; pos -= 5) {
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) V = dbl(L, V);
+        signed_digit(window5(b1, pos), idx, neg);
+        neg = neg != flip_a;
+        V = add_entry(L, V, tab_a.lookup(L, idx, neg), neg, swap_row);
+        signed_digit(window5(b2, pos), idx, neg);
+        neg = !neg;
+        V = add_entry(L, V, tab_r.lookup(L, idx, neg), neg, swap_row);
+    }
+    // an even rho or |tau| was walked as the next odd number: one copy of its point too many (wave-uniform)
+    if (pr.rho_even) V = add_entry(L, V, tab_a.lookup(L, 0, !flip_a), !flip_a, swap_row);   // - PA
+    if (pr.tau_even) V = add_entry(L, V, tab_r.lookup(L, 0, false), false, swap_row);       // - PR = + R
+    const sc rs = sc_recode_bwt(pr.ts);
+#pragma unroll
+    for (int k = 0; k < 14; k++) bits[k] = rs.w[k];
+    bits[14] = 0;
+    V = add_base_multiple(L, V, b1, bwt);                                  // + (|tau| S)*B
+    const uint64_t zmask = __builtin_amdgcn_ballot_w64(is_zero(L, V));     // row 0 is X
+    return ok && (zmask & 1u);
 }
 
 // ---------------------------------------------------------------- X448 (RFC 7748), one ladder per wave
