@@ -90,33 +90,42 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_double_scalarmul_wave(uint
                                                                             const uint64_t *__restrict__ s1, const uint64_t *b2,
                                                                             const uint64_t *__restrict__ s2, uint32_t n,
                                                                             const uint4 *__restrict__ bwt) {
-    __shared__ uint32_t s_tab[BLOCK / 64][wc::TABLE_WORDS];
-    __shared__ uint32_t s_bits[BLOCK / 64][16];
+    __shared__ uint32_t s_tab[BLOCK / 64][2][wc::TABLE_WORDS];
+    __shared__ uint32_t s_bits[BLOCK / 64][32];
     const wc::Lane L = wc::make_lane();
     const uint32_t w = threadIdx.x >> 6;
     const uint32_t nwaves = gridDim.x * (BLOCK / 64);
-    const wc::WaveTable tab{s_tab[w]};
+    const wc::WaveTable tab{s_tab[w][0]}, tab1{s_tab[w][1]};
     uint32_t *bits = s_bits[w];
+    struct Bits {
+        const uint32_t *p;
+        __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
+    };
     for (uint32_t op = blockIdx.x * (BLOCK / 64) + w; op < n; op += nwaves) {   // wave-uniform
-        wc::wfe P = wc::scalarmul(L, tab, bits, wc::load_point(L, b2 + 32 * (size_t)op), sc_load_abi(s2 + 7 * (size_t)op));
-        const sc k1 = sc_load_abi(s1 + 7 * (size_t)op);
-        if (b1) {   // uniform
-            const wc::wfe Q = wc::scalarmul(L, tab, bits, wc::load_point(L, b1 + 32 * (size_t)op), k1);
-            P = wc::add_entry(L, P, wc::to_pniels(L, Q, L.row ^ 1u), false, L.row ^ 1u);
+        const sc k1 = sc_load_abi(s1 + 7 * (size_t)op), k2 = sc_load_abi(s2 + 7 * (size_t)op);
+        wc::wfe P;
+        if (b1) {   // uniform: two caller points share one 90-window ladder
+            wc::build_table(L, tab, wc::load_point(L, b2 + 32 * (size_t)op));
+            wc::build_table(L, tab1, wc::load_point(L, b1 + 32 * (size_t)op));
+            const sc r1 = sc_recode_signed(k1), r2 = sc_recode_signed(k2);
+#pragma unroll
+            for (int k = 0; k < 14; k++) {
+                bits[k] = r1.w[k];
+                bits[16 + k] = r2.w[k];
+            }
+            bits[14] = bits[30] = 0;
+            P = wc::walk_two_tables(L, tab1, tab, Bits{bits}, Bits{bits + 16}, 90, false, false);
         } else {
+            P = wc::scalarmul(L, tab, bits, wc::load_point(L, b2 + 32 * (size_t)op), k2);
             const sc r = sc_recode_bwt(k1);
 #pragma unroll
             for (int k = 0; k < 14; k++) bits[k] = r.w[k];
             bits[14] = 0;
-            struct Bits {
-                const uint32_t *p;
-                __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
-            } rb{bits};
-            P = wc::add_base_multiple(L, P, rb, bwt);
+            P = wc::add_base_multiple(L, P, Bits{bits}, bwt);
         }
         wc::store_point(L, out + 32 * (size_t)op, P);
     }
-    if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
+    if ((threadIdx.x & 63u) < 32) s_bits[w][threadIdx.x & 31u] = 0;
 }
 
 // shared[i] = X448(scalar[i], base[i]), one ladder per wave   (ref: goldilocks_x448, src/goldilocks.c:1006-1076)

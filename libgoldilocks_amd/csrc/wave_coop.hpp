@@ -280,6 +280,35 @@ __device__ __forceinline__ wfe scalarmul(const Lane &L, const WaveTable &tab, ui
     return walk_table(L, tab, bits, k);
 }
 
+// s1 * P1 + s2 * P2 with both tables built: ONE ladder of `windows` 5-bit windows, two additions per window
+// (src/goldilocks.c:467-541).  b1 / b2: the recoded scalars' words; flip1 / flip2 negate a point by its digits.
+template <class BITS>
+__device__ __forceinline__ wfe walk_two_tables(const Lane &L, const WaveTable &tab1, const WaveTable &tab2, const BITS &b1,
+                                               const BITS &b2, int windows, bool flip1, bool flip2) {
+    const uint32_t swap_row = L.row ^ 1u;
+    uint32_t idx;
+    bool neg;
+    const int top = 5 * (windows - 1);
+    signed_digit(window5(b1, top), idx, neg);
+    neg = neg != flip1;
+    wfe V = add_entry(L, identity(L), tab1.lookup(L, idx, neg), neg, swap_row);
+    signed_digit(window5(b2, top), idx, neg);
+    neg = neg != flip2;
+    V = add_entry(L, V, tab2.lookup(L, idx, neg), neg, swap_row);
+#pragma unroll 1
+    for (int pos = top - 5; pos >= 0; pos -= 5) {
+#pragma unroll 1
+        for (int j = 0; j < 5; j++) V = dbl(L, V);
+        signed_digit(window5(b1, pos), idx, neg);
+        neg = neg != flip1;
+        V = add_entry(L, V, tab1.lookup(L, idx, neg), neg, swap_row);
+        signed_digit(window5(b2, pos), idx, neg);
+        neg = neg != flip2;
+        V = add_entry(L, V, tab2.lookup(L, idx, neg), neg, swap_row);
+    }
+    return V;
+}
+
 // ---------------------------------------------------------------- canonical form, predicates (per row)
 
 // dst[l] = src[l - 1], lane 0 of every row gets 0
@@ -451,26 +480,7 @@ __device__ __forceinline__ bool verify(const Lane &L, const WaveTable &tab_a, co
         const uint32_t *p;
         __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
     } b1{bits}, b2{bits + 16};
-    uint32_t idx;
-    bool neg;
-    constexpr int TOP = 5 * (LATTICE_WINDOWS - 1);
-    signed_digit(window5(b1, TOP), idx, neg);
-    neg = neg != flip_a;
-    wfe V = add_entry(L, identity(L), tab_a.lookup(L, idx, neg), neg, swap_row);
-    signed_digit(window5(b2, TOP), idx, neg);
-    neg = !neg;
-    V = add_entry(L, V, tab_r.lookup(L, idx, neg), neg, swap_row);
-#pragma unroll 1
-    for (int pos = TOP - 5; pos >= 0; pos -= 5) {
-#pragma unroll 1
-        for (int j = 0; j < 5; j++) V = dbl(L, V);
-        signed_digit(window5(b1, pos), idx, neg);
-        neg = neg != flip_a;
-        V = add_entry(L, V, tab_a.lookup(L, idx, neg), neg, swap_row);
-        signed_digit(window5(b2, pos), idx, neg);
-        neg = !neg;
-        V = add_entry(L, V, tab_r.lookup(L, idx, neg), neg, swap_row);
-    }
+    wfe V = walk_two_tables(L, tab_a, tab_r, b1, b2, LATTICE_WINDOWS, flip_a, true);
     // an even rho or |tau| was walked as the next odd number: one copy of its point too many (wave-uniform)
     if (pr.rho_even) V = add_entry(L, V, tab_a.lookup(L, 0, !flip_a), !flip_a, swap_row);   // - PA
     if (pr.tau_even) V = add_entry(L, V, tab_r.lookup(L, 0, false), false, swap_row);       // - PR = + R
