@@ -25,6 +25,41 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_point_scalarmul_wave(uint6
     if ((threadIdx.x & 63u) < 16) s_bits[w][threadIdx.x & 15u] = 0;
 }
 
+// ser[i] = the decaf (56 bytes) or RFC 8032 (57 bytes, 4 * pts[i]) encoding of pts[i], one point per wave
+// (ref: goldilocks_448_point_encode, goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_point_encode_wave(uint8_t *__restrict__ ser, const uint64_t *__restrict__ pts,
+                                                                        uint32_t n, int eddsa) {
+    const wc::Lane L = wc::make_lane();
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); op < n; op += nwaves) {   // wave-uniform
+        const wc::wfe P = wc::load_point(L, pts + 32 * (size_t)op);
+        if (eddsa) wc::encode_eddsa(L, ser + 57 * (size_t)op, P);   // uniform
+        else wc::encode(L, ser + 56 * (size_t)op, P);
+    }
+}
+// pts[i] = the point ser[i] encodes, status[i] = it decodes; one encoding per wave
+// (ref: goldilocks_448_point_decode, goldilocks_448_point_decode_like_eddsa_and_mul_by_ratio)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_point_decode_wave(uint64_t *__restrict__ pts, int32_t *__restrict__ status,
+                                                                        const uint8_t *__restrict__ ser, uint32_t n, int eddsa,
+                                                                        int allow_identity) {
+    const wc::Lane L = wc::make_lane();
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); op < n; op += nwaves) {   // wave-uniform
+        wc::wfe P;
+        bool ok;
+        if (eddsa) {   // uniform; every row decodes the same 57 bytes
+            wc::wfe X, Y, Z, T;
+            const bool okrow = wc::decode_eddsa_rows(L, ser + 57 * (size_t)op, X, Y, Z, T);
+            ok = (__builtin_amdgcn_ballot_w64(okrow) & 1u) != 0;
+            P = wc::pack_point<0>(L, X, Y, Z, T);
+        } else {
+            ok = wc::decode(L, ser + 56 * (size_t)op, allow_identity != 0, P);
+        }
+        wc::store_point(L, pts + 32 * (size_t)op, P);
+        if ((threadIdx.x & 63u) == 0) status[op] = ok ? -1 : 0;
+    }
+}
+
 // tables[i] = the 5 x 5 x 18 comb of base[i] in the reference's format, one table per wave (ref: goldilocks_448_precompute)
 extern "C" __global__ void __launch_bounds__(BLOCK) k_precompute_wave(uint64_t *__restrict__ tables, const uint64_t *__restrict__ base,
                                                                       uint32_t n) {
