@@ -313,7 +313,7 @@ GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the mode in f
 /* Small batches.  One lane's ladder takes 2.1-2.8 ms however few operations a call has, so batches of
  * up to `n` variable-base or fixed-base multiplications -- and up to n / 2 verifications, double-base,
  * dual or wire-format multiplications, key derivations, signatures, X448 operations or comb tables
- * (precompute), and up to 1024 encodings / decodings -- the single-operation drop-in names included,
+ * (precompute), and up to 1024 encodings, decodings or hash-to-curve maps -- the single-operation drop-in names included,
  * run ONE OPERATION PER WAVEFRONT instead: the 64 lanes share the operation (a field element spread
  * over the 16 lanes of a row, four field elements per register), 0.35 ms per multiplication call,
  * 0.57 ms per verification call, 0.43 ms per signature, 0.16 ms per encoding or decoding.

@@ -501,6 +501,8 @@ extern "C" __global__ void k_ed448_sign_wave(uint8_t *__restrict__ sig, const ui
 extern "C" __global__ void k_point_encode_wave(uint8_t *__restrict__ ser, const uint64_t *__restrict__ pts, uint32_t n, int eddsa);
 extern "C" __global__ void k_point_decode_wave(uint64_t *__restrict__ pts, int32_t *__restrict__ status,
                                                const uint8_t *__restrict__ ser, uint32_t n, int eddsa, int allow_identity);
+extern "C" __global__ void k_point_from_hash_wave(uint64_t *__restrict__ out, const uint8_t *__restrict__ hash, uint32_t n,
+                                                  int uniform);
 extern "C" __global__ void k_precompute_wave(uint64_t *__restrict__ tables, const uint64_t *__restrict__ base, uint32_t n);
 extern "C" __global__ void k_direct_scalarmul_wave(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
                                                    const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar,

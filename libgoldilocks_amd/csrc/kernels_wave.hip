@@ -60,6 +60,26 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_point_decode_wave(uint64_t
     }
 }
 
+// out[i] = Elligator 2 of hash[i] (56 bytes), or the sum of the maps of its two halves (112 bytes, uniform): one
+// output per wave, the two halves in rows 0 and 1 of the same instruction stream
+// (ref: goldilocks_448_point_from_hash_nonuniform / _uniform, src/elligator.c:32-94)
+extern "C" __global__ void __launch_bounds__(BLOCK) k_point_from_hash_wave(uint64_t *__restrict__ out, const uint8_t *__restrict__ hash,
+                                                                           uint32_t n, int uniform) {
+    const wc::Lane L = wc::make_lane();
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64), nb = uniform ? 112 : 56;
+    for (uint32_t op = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); op < n; op += nwaves) {   // wave-uniform
+        const uint8_t *str = hash + (size_t)nb * op + (uniform && (L.row & 1u) ? 56 : 0);
+        wc::wfe X, Y, Z, T;
+        wc::from_hash_rows(L, str, X, Y, Z, T);
+        wc::wfe P = wc::pack_point<0>(L, X, Y, Z, T);
+        if (uniform) {
+            const uint32_t swap_row = L.row ^ 1u;
+            P = wc::add_entry(L, P, wc::to_pniels(L, wc::pack_point<1>(L, X, Y, Z, T), swap_row), false, swap_row);
+        }
+        wc::store_point(L, out + 32 * (size_t)op, P);
+    }
+}
+
 // tables[i] = the 5 x 5 x 18 comb of base[i] in the reference's format, one table per wave (ref: goldilocks_448_precompute)
 extern "C" __global__ void __launch_bounds__(BLOCK) k_precompute_wave(uint64_t *__restrict__ tables, const uint64_t *__restrict__ base,
                                                                       uint32_t n) {

@@ -624,6 +624,45 @@ __device__ __forceinline__ void encode_x448(const Lane &L, uint8_t *out56, wfe P
     store_bytes<0>(L, out56, strong(L, mul(L, r, r)));
 }
 
+// ---------------------------------------------------------------- Elligator 2 hash-to-curve
+
+// One 56-byte string per ROW -> that row's point (X, Y, Z, T in four registers)   (cf. pt_from_hash_words,
+// src/elligator.c:32-83).  The rows may hash different strings: the uniform variant maps its two halves at once.
+__device__ __forceinline__ void from_hash_rows(const Lane &L, const uint8_t *str56, wfe &X, wfe &Y, wfe &Z, wfe &T) {
+    bool below, square;
+    const wfe r0 = strong(L, deserialize(L, str56, below));          // any 448-bit string, reduced mod p
+    const wfe r = weak(L, neg(L, mul(L, r0, r0)));                    // r = -r0^2 (qnr = -1)
+    const wfe rm1 = weak(L, sub<2>(L, r, one(L)));                    // r - 1
+    const wfe drd = weak(L, neg(L, mulw(L, rm1, NEG_EDWARDS_D)));     // d r - d, d = -39081
+    const wfe a = drd + one(L);                                       // mag 2
+    const wfe b = weak(L, sub<2>(L, drd, r));
+    const wfe D = mul(L, a, b);                                       // (dr - d + 1)(dr - d - r)
+    const wfe N = weak(L, mulw(L, r + one(L), 78163));                // (r + 1)(1 - 2d)
+    const wfe i = isr(L, mul(L, D, N), square);
+    const wfe e = mul(L, i, square ? one(L) : r0);
+    wfe s = mul(L, N, e);
+    {   // cross-lane operations with every lane active: both candidates, then a plain select
+        const wfe ns = neg(L, s);
+        const bool flip = lobit(L, s) != !square;                     // negate iff lobit(s) ^ ~square
+        s = weak(L, flip ? ns : s);
+    }
+    const wfe c = weak(L, mulw(L, e, 78163));
+    wfe t = mul(L, mul(L, mul(L, c, c), rm1), N);
+    {
+        const wfe nt = neg(L, t);
+        t = weak(L, square ? nt : t);
+    }
+    t = weak(L, sub<2>(L, t, one(L)));
+    const wfe s2 = mul(L, s, s);
+    const wfe two_s = s + s;                                          // mag 2
+    const wfe ep = s2 + one(L);                                       // 1 + s^2, mag 2
+    const wfe em = weak(L, sub<2>(L, one(L), s2));                    // 1 - s^2
+    T = mul(L, two_s, ep);
+    X = mul(L, two_s, t);
+    Y = mul(L, ep, em);
+    Z = mul(L, em, t);
+}
+
 // ---------------------------------------------------------------- precompute: the 5 x 5 x 18 comb of one point
 
 // goldilocks_448_precompute by ONE wave (cf. k_precompute, src/goldilocks.c:755-818): the chain of 449 doublings
