@@ -117,3 +117,30 @@ def test_soak_wave_path(ga, O, table_mode):
     ctx = (C.c_uint8 * 1).from_buffer_copy(b"w")
     O.orc_ed448_verify_batch(_p(want), _p(sigs), _p(pks), _p(msg_arr), 33, 0, ctx, 1, m, _gen.NTHREADS)
     assert (st == want).all() and (st[~bad] == -1).all() and (st == 0).sum() >= bad.sum() - 4
+    # the codecs and the hash-to-curve map, one operation per wave (at most 1 024 per call)
+    from _libs import Point
+    c = 1024
+    pts = got[:c]
+    e56, e57 = ga.point_encode_batch(pts), ga.point_encode_like_eddsa_batch(pts)
+    assert (e56 == _gen.oracle_encode(pts)).all()
+    d56, st56 = ga.point_decode_batch(e56)
+    assert (st56 == -1).sum() >= c - 2 and (ga.point_encode_batch(d56)[st56 == -1] == e56[st56 == -1]).all()
+    d57, st57 = ga.point_decode_like_eddsa_batch(e57)
+    four = ga.point_scalarmul_batch(pts, _gen.scalars_from_ints([4] * c))
+    ok57 = st57 == -1
+    assert ok57.sum() >= c - 2 and (ga.point_encode_batch(d57)[ok57] == ga.point_encode_batch(four)[ok57]).all()
+    for i in range(0, c, 41):
+        out = (C.c_uint8 * 57)()
+        O.orc_point_encode_like_eddsa(out, C.cast(_p(np.ascontiguousarray(pts[i])), C.POINTER(Point)))
+        assert bytes(out) == e57[i].tobytes()
+    h = np.frombuffer(_gen.stream(SEED + b"soak/wave/elligator", 112 * c), np.uint8).reshape(c, 112).copy()
+    for uniform in (False, True):
+        hp = ga.point_from_hash_batch(h if uniform else h[:, :56].copy(), uniform=uniform)
+        w = np.empty((c, 32), np.uint64)
+        sel = np.arange(0, c, 13)
+        for i in sel:
+            if uniform:
+                O.orc_point_from_hash_uniform(C.cast(_p(w[i]), C.POINTER(Point)), _p(h[i]))
+            else:
+                O.orc_point_from_hash_nonuniform(C.cast(_p(w[i]), C.POINTER(Point)), _p(np.ascontiguousarray(h[i, :56])))
+        assert (ga.point_encode_batch(hp[sel]) == _gen.oracle_encode(w[sel])).all()
