@@ -311,9 +311,10 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
 GOLDILOCKS_AMD_API int goldilocks_amd_set_table_access(int mode);
 GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the mode in force */
 /* Small batches.  One lane's ladder takes 2.1-2.8 ms however few operations a call has, so batches of
- * up to `n` variable-base or fixed-base multiplications -- and up to n / 2 verifications, double-base,
- * dual or wire-format multiplications, key derivations, signatures, X448 operations or comb tables
- * (precompute), and up to 1024 encodings, decodings or hash-to-curve maps -- the single-operation drop-in names included,
+ * up to `n` variable-base, double-base or dual multiplications -- 3n/4 fixed-base multiplications or X448
+ * shared secrets, n/2 verifications, wire-format multiplications, key derivations, X448 key generations
+ * or comb tables (precompute), n/4 signatures: the measured crossovers, tests/crossover_probe.py -- and
+ * up to 1024 encodings, decodings or hash-to-curve maps, the single-operation drop-in names included,
  * run ONE OPERATION PER WAVEFRONT instead: the 64 lanes share the operation (a field element spread
  * over the 16 lanes of a row, four field elements per register), 0.35 ms per multiplication call,
  * 0.57 ms per verification call, 0.43 ms per signature, 0.16 ms per encoding or decoding.
