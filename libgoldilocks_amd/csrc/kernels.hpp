@@ -42,6 +42,7 @@ constexpr int PRECOMP_U4 = 80 * 20 + 64;  // uint4 per lane for k_precompute: 80
 // per-OPERATION workspace of the kernels that share one inversion between a lane's operations
 // (fixed_bodies.hpp): numerator(s) | denominator | prefix product [| nonce | secret scalar]
 constexpr int DERIVE_SLOT_U4 = 16, SIGN_SLOT_U4 = 24, X448_SLOT_U4 = 12;
+constexpr int ML_SLOT_U4 = 8;   // the table-free variable-base ladder: denominator | prefix product
 constexpr int SHARED_INV_OPS_PER_LANE = 8;   // a launch covers at most this many operations per resident lane
 constexpr uint64_t MAX_MESSAGE_BYTES = 0x7fffff00ull;   // GOLDILOCKS_AMD_MAX_MESSAGE_BYTES: byte counters are 32-bit
 

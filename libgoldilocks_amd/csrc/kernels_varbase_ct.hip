@@ -7,7 +7,7 @@ namespace gd {
 
 GD_KERNEL_CT k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
                                   uint32_t n, uint4 *__restrict__ workspace) {
-    point_scalarmul_body<true>(out, base, scalar, n, workspace);
+    point_scalarmul_ladder_body(out, base, scalar, n, workspace);
 }
 
 GD_KERNEL_CT k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,

@@ -1,0 +1,118 @@
+// montgomery.hpp -- variable-base multiplication WITHOUT a table: the index-independent default of
+//   goldilocks_448_point_scalarmul                 src/goldilocks.c:405-465
+// The reference reads its 16-entry window table through constant_time_lookup (src/include/constant_time.h:134-183:
+// every entry for every digit).  One operation per lane, a lane's table lives in HBM and such a scan is what
+// the kernel then waits for (200 GB per 2^20 operations).  This path needs no table at
+// all: the Montgomery ladder (the shape of the reference's own goldilocks_x448, src/goldilocks.c:1006-1076)
+// on the Montgomery model of the curve the reference computes on,
+//     E: -x^2 + y^2 = 1 + d' x^2 y^2, d' = -39082      <->      M: B v^2 = u^3 + A u^2 + u,
+//     u = (y + 1)/(y - 1),  v = -u/x,   A = 2(d' - 1)/(d' + 1) = 78166/39081,   (A - 2)/4 = 1/39081,
+// followed by Okeya-Sakurai recovery of v and the map back to extended coordinates.  Every step is
+// 5M + 4S + one multiplication by 39081 whatever the scalar; the only data-dependent instructions are selects.
+//
+// What the ladder computes is (s mod q) * P exactly.  The reference computes (s + m q) * P for an integer
+// m that depends on its recoding (src/goldilocks.c:420-438); on the points its API produces -- the
+// subgroup 2E, where q * P is the identity or the 2-torsion point (0, -1) -- the two agree up to that
+// 2-torsion point, which is the equivalence goldilocks_448_point_eq and the encodings are defined on
+// (src/goldilocks.c:644-653).
+//
+// Exceptional cases, all handled by selects on masks (no branch on the scalar):
+//   * P in {identity, (0,-1)} (X = 0): u is infinite or zero; the result is the identity;
+//   * s*P in {identity, (0,-1)}: the ladder's (X1 : Z1) has a zero; the result is the identity;
+//   * (s+1)*P in {identity, (0,-1)} (s = q - 1): (X2 : Z2) has a zero and the recovery formula
+//     degenerates; the result is -P.
+#pragma once
+#include "point.hpp"
+#include "sc14.hpp"
+
+namespace gd {
+
+constexpr uint32_t ML_C = 39081;            // 1 - d' ... the ladder's small constant: ((A - 2)/4)^-1
+constexpr uint32_t ML_2AC = 156332;         // 2 A * 39081
+constexpr int ML_BITS = 446;                // bits of q
+
+// What the ladder needs of the base point besides 1/(Y - Z): computed twice (once to learn the denominator
+// that goes into the lane's shared inversion, once when the ladder runs) rather than parked in memory.
+GD_FN fe ml_denominator(const pt &b) { return fe_weak(fe_sub<2>(b.y, b.z)); }   // Y - Z: zero iff P is the identity
+
+// One ladder step on (x2 : z2) = k P, (x3 : z3) = (k+1) P (already swapped so that the pair to double is 2).
+GD_FN void ml_step(fe &x2, fe &z2, fe &x3, fe &z3, const fe &x1) {
+    fe t1 = fe_add(x2, z2);                         // A = x2 + z2            mag 2
+    fe t2 = fe_weak(fe_sub<2>(x2, z2));             // B = x2 - z2            mag 1
+    fe d = fe_sub<2>(x3, z3);                       // D = x3 - z3            mag 3 (times mag 2 only)
+    fe da = fe_mul(t1, d);                          // DA
+    fe c = fe_add(z3, x3);                          // C = x3 + z3            mag 2
+    fe cb = fe_mul(c, t2);                          // CB
+    fe dm = fe_weak(fe_sub<2>(da, cb));             // DA - CB                mag 1
+    z3 = fe_mul(x1, fe_sqr(dm));                    // z3 = x1 (DA - CB)^2
+    x3 = fe_sqr(fe_add(da, cb));                    // x3 = (DA + CB)^2       (input mag 2)
+    fe aa = fe_sqr(t1);                             // AA                     (input mag 2)
+    fe bb = fe_sqr(t2);                             // BB
+    fe caa = fe_mulw(aa, ML_C);                     // 39081 AA
+    fe e = fe_weak(fe_sub<2>(aa, bb));              // E = AA - BB            mag 1
+    x2 = fe_mul(caa, bb);                           // x2 = 39081 AA BB
+    z2 = fe_mul(fe_add(caa, e), e);                 // z2 = E (39081 AA + E)  (2 x 1)
+}
+
+// bits.word(k): k-th 32-bit word of the scalar, already reduced mod q (446 bits).
+// b: the base point; di = 1/(Y - Z) (anything if Y = Z).
+template <class BITS>
+GD_FN pt ml_scalarmul(const pt &b, const fe &di, const BITS &bits) {
+    const fe yz = fe_add(b.y, b.z);                 // Y + Z                  mag 2
+    const fe x1 = fe_mul(yz, di);                   // u(P) = (Y + Z)/(Y - Z)
+    fe x2 = fe_one(), z2 = fe_zero(), x3 = x1, z3 = fe_one();
+    bool swap = false;
+#pragma unroll 1
+    for (int t = ML_BITS - 1; t >= 0; t--) {
+        const bool k_t = ((bits.word(t >> 5) >> (t & 31)) & 1u) != 0;
+        const bool sw = swap != k_t;
+        swap = k_t;
+        fe a2 = fe_select(x2, x3, sw), a3 = fe_select(x3, x2, sw);
+        fe c2 = fe_select(z2, z3, sw), c3 = fe_select(z3, z2, sw);
+        ml_step(a2, c2, a3, c3, x1);
+        x2 = a2; z2 = c2; x3 = a3; z3 = c3;
+    }
+    // (X1 : Z1) = u(sP), (X2 : Z2) = u((s+1)P)
+    const fe X1 = fe_select(x2, x3, swap), Z1 = fe_select(z2, z3, swap);
+    const fe X2 = fe_select(x3, x2, swap), Z2 = fe_select(z3, z2, swap);
+    const bool q_trivial = fe_is_zero(X1) | fe_is_zero(Z1);     // '|', not '||': no branch on the scalar
+    const bool qp_trivial = fe_is_zero(X2) | fe_is_zero(Z2);
+    const bool base_trivial = fe_is_zero(b.x);
+
+    // Okeya-Sakurai: with x = u(P), y = v(P) = vn / vd,
+    //   39081 * Ynum = Z2 [(X1 x + Z1)(39081 (X1 + x Z1) + 156332 Z1) - 156332 Z1^2] - 39081 (X1 - x Z1)^2 X2
+    //   (U : V : W) = (-8 vn X1 Z1 Z2 : 39081 Ynum vd : -8 vn Z1^2 Z2),   vn = -(Y+Z) Z,  vd = (Y-Z) X
+    // and x_E = -U/V, y_E = (U + W)/(U - W).  Signs are arranged so that nothing is negated.
+    const fe xz1 = fe_mul(x1, Z1);
+    const fe t1 = fe_add(fe_mul(X1, x1), Z1);                                   // mag 2
+    const fe t2 = fe_add(fe_mulw(fe_add(X1, xz1), ML_C), fe_mulw(Z1, ML_2AC));  // mag 2
+    const fe t3 = fe_weak(fe_sub<2>(fe_mul(t1, t2), fe_mulw(fe_sqr(Z1), ML_2AC)));
+    const fe t4 = fe_weak(fe_sub<2>(X1, xz1));
+    const fe q4 = fe_mulw(fe_mul(fe_sqr(t4), X2), ML_C);
+    const fe vneg = fe_mul(fe_weak(fe_sub<2>(q4, fe_mul(Z2, t3))),              // -39081 Ynum ...
+                           fe_mul(ml_denominator(b), b.x));                      // ... times vd
+    const fe kp = fe_mulw(fe_mul(fe_mul(yz, b.z), fe_mul(Z1, Z2)), 8);          // 8 (Y+Z) Z Z1 Z2
+    const fe kx = fe_mul(kp, X1);
+    const fe m = fe_weak(fe_sub<2>(X1, Z1));
+    const fe pl = fe_add(X1, Z1);                                               // mag 2
+    pt r;
+    r.x = fe_mul(kx, m);
+    r.y = fe_mul(vneg, pl);
+    r.z = fe_mul(vneg, m);
+    r.t = fe_mul(kx, pl);
+    // (s+1) P trivial: s P = -P
+    const pt nb = pt_negate(b);
+    r.x = fe_select(r.x, nb.x, qp_trivial);
+    r.y = fe_select(r.y, nb.y, qp_trivial);
+    r.z = fe_select(r.z, nb.z, qp_trivial);
+    r.t = fe_select(r.t, nb.t, qp_trivial);
+    const bool ident = q_trivial | base_trivial;
+    const pt id = pt_identity();
+    r.x = fe_select(r.x, id.x, ident);
+    r.y = fe_select(r.y, id.y, ident);
+    r.z = fe_select(r.z, id.z, ident);
+    r.t = fe_select(r.t, id.t, ident);
+    return r;
+}
+
+}  // namespace gd

@@ -7,6 +7,8 @@
 // src/goldilocks.c:437-442, :500-520, :590-610).
 #pragma once
 #include "kernels.hpp"
+#include "fixed_bodies.hpp"
+#include "montgomery.hpp"
 
 #ifndef GD_LDS_PREFETCH
 #define GD_LDS_PREFETCH 0
@@ -107,6 +109,59 @@ __device__ __forceinline__ void point_scalarmul_body(uint64_t *out, const uint64
         wave_sync();
         for (int k = 0; k < STAGE_U4 / 64; k++) stage[k * 64 + l] = make_uint4(0, 0, 0, 0);
     }
+}
+
+// config 2, index-independent (the library default): scaled[i] = scalar[i] * base[i] by the table-free
+// Montgomery ladder of montgomery.hpp   (ref: goldilocks_448_point_scalarmul, constant time there:
+// src/goldilocks.c:437-442 through constant_time.h:134-183).
+// The ladder wants u(P) = (Y+Z)/(Y-Z) in affine form: the inversions of the operations a lane owns are
+// shared (InvChain, fixed_bodies.hpp: Montgomery's trick along the lane) -- a first pass over the lane's
+// base points parks Y-Z and the running product (ML_SLOT_U4 uint4 per operation), one inversion, then
+// the operations run in reverse order, re-reading their base point.  out may alias base: an operation's
+// base point is read (again) right before its result is written, and the first pass is over by then.
+template <class BODY>
+__device__ __forceinline__ void for_each_wave_round_reverse(uint32_t n, BODY body) {
+    const uint32_t l = threadIdx.x & 63u;
+    const uint32_t first = blockIdx.x * BLOCK + threadIdx.x - l, stride = gridDim.x * BLOCK;
+    if (first >= n) return;
+    for (uint32_t i0 = first + (n - 1 - first) / stride * stride;; i0 -= stride) {
+        body(i0);
+        if (i0 < stride) break;
+    }
+}
+__device__ __forceinline__ void point_scalarmul_ladder_body(uint64_t *out, const uint64_t *base,
+                                                            const uint64_t *__restrict__ scalar, uint32_t n,
+                                                            uint4 *__restrict__ workspace) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint4 s_stage[(BLOCK / 64) * WAVE_STAGE_U4];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    const uint32_t l = threadIdx.x & 63u;
+    uint4 *stage = s_stage + (threadIdx.x >> 6) * WAVE_STAGE_U4;
+    InvChain ch;
+    ch.begin();
+    for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {   // wave-uniform: 64 consecutive operations per round
+        const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
+        const pt b = wave_load_points(stage, base, i0, m, l);
+        ch.push(workspace + (size_t)ML_SLOT_U4 * (i0 + l), ml_denominator(b), l < m);
+    }
+    ch.invert();
+    for_each_wave_round_reverse(n, [&](uint32_t i0) {
+        const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
+        const pt b = wave_load_points(stage, base, i0, m, l);
+        const sc k = wave_load_scalars(stage, scalar, i0, m, l);
+        pt r = b;
+        if (l < m) {
+            const fe di = ch.pop(workspace + (size_t)ML_SLOT_U4 * (i0 + l));
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(k));
+            r = ml_scalarmul(b, di, bits);
+        }
+        wave_store_points(stage, out, i0, m, l, r);
+    });
+    // the scalar was secret: neither its words nor its staged copy stay in LDS
+    lds_wipe_lane(s_bits + threadIdx.x, 15);
+    wave_sync();
+    for (int k = 0; k < WAVE_STAGE_U4 / 64; k++) stage[k * 64 + l] = make_uint4(0, 0, 0, 0);
 }
 
 // "next" row f2: wire-format scalarmul, 56 bytes in / 56 bytes out   (ref: goldilocks_448_direct_scalarmul)

@@ -10,6 +10,7 @@
 #include "../../libgoldilocks_amd/csrc/scalarmul.hpp"
 #include "../../libgoldilocks_amd/csrc/eddsa.hpp"
 #include "../../libgoldilocks_amd/csrc/x448.hpp"
+#include "../../libgoldilocks_amd/csrc/montgomery.hpp"
 
 #include <string.h>
 
@@ -123,10 +124,20 @@ void hs_point_scalarmul_w4(uint64_t *out, const uint64_t *base, const uint64_t *
     build_window_table_w<4>(tab, pt_from_abi(base));
     pt_to_abi(out, ladder_varbase_w<4>(bits, tab));
 }
+// the table-free ladder of the index-independent variable-base kernel (montgomery.hpp)
+void hs_point_scalarmul_ladder(uint64_t *out, const uint64_t *base, const uint64_t *scalar) {
+    const pt b = pt_from_abi(base);
+    const sc r = sc_reduce(sc_from_abi(scalar));
+    HostBits bits;
+    for (int i = 0; i < 14; i++) bits.w[i] = r.w[i];
+    bits.w[14] = 0;
+    pt_to_abi(out, ml_scalarmul(b, fe_invert(ml_denominator(b)), bits));
+}
 // Multiply-accumulates (v_mad_u64_u32 on the device) of one call of a building block; the counts
 // do not depend on the data.  what: 0 fe_mul, 1 fe_sqr, 2 fe_mulw, 3 pt_double, 4 pt_double + T,
 // 5 pt_add_niels + T, 6 niels_to_pt, 7 fe_isr, 8 pt_decode_eddsa, 9 pt_add (full), 10 pt_eq,
-// 11 variable base W = 5 (table + ladder), 12 variable base W = 4, 13 comb ladder, 14 the 4 x 7 x 16 comb ladder
+// 11 variable base W = 5 (table + ladder), 12 variable base W = 4, 13 comb ladder, 14 the 4 x 7 x 16 comb ladder,
+// 15 variable base by the Montgomery ladder (with its own inversion)
 void hs_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *scalar);
 void hs_precomputed_scalarmul(uint64_t *out, const uint64_t *table, const uint64_t *scalar);
 void hs_comb_big_scalarmul(uint64_t *out, const uint64_t *table, const uint64_t *scalar);
@@ -154,6 +165,7 @@ unsigned long long hs_mac_count_of(int what, const uint64_t *point, const uint64
     case 11: hs_point_scalarmul(out, point, scalar); break;
     case 12: hs_point_scalarmul_w4(out, point, scalar); break;
     case 13: hs_precomputed_scalarmul(out, comb_table, scalar); break;
+    case 15: hs_point_scalarmul_ladder(out, point, scalar); break;
     case 14: hs_comb_big_scalarmul(out, comb_table, scalar); c = 0; hs_comb_big_scalarmul(out, comb_table, scalar); break;   // the table is built by the first call
     default: return 0;
     }

@@ -385,3 +385,49 @@ def test_verification_with_half_size_scalars(H, O):
         assert got == c["verdict"], c["kind"]
         accepted += got == -1; rejected += got == 0
     assert accepted >= 4 and rejected >= 4
+
+
+def test_table_free_ladder_matches_oracle_and_golden_f1(H, O):
+    """montgomery.hpp: the index-independent variable-base multiplication (Montgomery ladder on the
+    Montgomery model of the reference's curve + Okeya-Sakurai recovery) against the oracle's windowed
+    multiplication (src/goldilocks.c:405-465): edge scalars (0, 1, q-1 -- the cases where the recovery
+    degenerates and a select takes over), the identity and the 2-torsion point as bases, rescaled
+    representatives, scalars >= q, and every 8th vector of the reference's fixture F1."""
+    def run(bases, scal):
+        out = np.empty((len(scal), 32), dtype=np.uint64)
+        for i in range(len(scal)):
+            H.hs_point_scalarmul_ladder(out[i].ctypes.data_as(C.c_void_p), bases[i].ctypes.data_as(C.c_void_p),
+                                        scal[i].ctypes.data_as(C.c_void_p))
+        return out
+    vals = [0, 1, 2, 3, Q - 1, Q - 2, Q - 3, (Q + 1) // 2, (Q - 1) // 2, 2**445, 2**445 - 1, 2**446 - 1 - Q, 7, 8]
+    bases = _gen.oracle_fixed(O, _gen.stream_scalars(len(vals), b"ml/base"))
+    scal = _gen.scalars_from_ints(vals)
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, bases, scal))
+    got = run(bases, scal)
+    assert (_gen.oracle_encode(got) == want).all()
+    for i in range(len(vals)):   # complete extended points: on the curve, X Y = Z T
+        assert H.hs_point_valid(got[i].ctypes.data_as(C.c_void_p)) == -1, hex(vals[i])
+    # the identity and (0, -1) as bases: the identity's class whatever the scalar
+    ident = np.frombuffer(bytes(Point.identity()), np.uint64).copy() if hasattr(Point, "identity") else None
+    if ident is None:
+        ident = np.zeros(32, np.uint64); ident[8] = 1; ident[16] = 1
+    t2 = ident.copy(); t2[8:16] = np.frombuffer(Gf.from_int(P - 1), np.uint64)
+    special = np.stack([ident, t2, ident, t2])
+    s4 = _gen.scalars_from_ints([0, 5, Q - 1, Q - 1])
+    enc = _gen.oracle_encode(run(special, s4))
+    assert (enc == 0).all()
+    # a scalar that is not reduced (q + 5, 2q + 1 as raw words): the reference reduces by its recoding
+    raw = np.empty((2, 7), np.uint64)
+    raw[0] = np.frombuffer((Q + 5).to_bytes(56, "little"), np.uint64)
+    raw[1] = np.frombuffer((2 * Q + 1).to_bytes(56, "little"), np.uint64)
+    b2 = bases[:2]
+    assert (_gen.oracle_encode(run(b2, raw)) == _gen.oracle_encode(_gen.oracle_varbase(O, b2, raw))).all()
+    # golden F1 (the reference's own outputs)
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f1_varbase.npz"))
+    idx = list(range(0, 1024, 8)) + list(range(1016, 1024))
+    fb = np.empty((len(idx), 32), np.uint64)
+    for j, i in enumerate(idx):
+        p = Point()
+        assert O.orc_point_decode(C.byref(p), buf(d["base"][i].tobytes()), 1) == -1
+        fb[j] = np.frombuffer(bytes(p), np.uint64)
+    assert (_gen.oracle_encode(run(fb, d["scalar"][idx])) == d["out"][idx]).all()
