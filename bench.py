@@ -24,13 +24,22 @@ Objects on the line besides the driver's contract:
                 "mac" carries the honest ceiling: 32x32->64 MAC/s against the measured
                 v_mad_u64_u32 peak (profiles/r01/ubench.txt).
   configs       (default N = 1 run only) the other BASELINE configs timed for a few steps each in
-                the same process: fixed-base comb in LDS (config 3), the base-point window table,
-                verify (config 4), and the index-independent variable-base mode.
-  cpu_baseline  the REAL reference (arch_x86_64 path, oracle/_ref, built for generic x86-64) -- or
-                the oracle port if that .so did not travel -- on the host cores: a single-thread
-                figure by the reference's own benchmark method (test/bench_goldilocks.cxx:73-143:
-                50 samples x 20 iterations, 2 + 2 trimmed, mean; its :190 "Point scalarmul" line)
-                and a short thread sweep over a bounded sample of the same batch.
+                the same process: fixed-base comb in LDS (config 3), the built-in base point, verify
+                (config 4), and the opt-in digit-addressed tables for public scalars (*_fast).
+  end_to_end    (default N = 1 run only) the host-array entry points (*_batch: pageable host arrays in,
+                host arrays out, H2D + kernels + D2H) for the three headline paths, library defaults
+                (SURVEY 8d "report both device-resident and end-to-end"; never `value`).
+  cpu_baseline  the REAL reference (arch_x86_64 path, oracle/_ref; two builds: generic x86-64 and
+                -march=x86-64-v3, the flags the reference's own Makefile.custom:63 -march=native gives on
+                a current host) -- or the oracle port if those did not travel -- on the host cores: a
+                single-thread figure by the reference's own benchmark method
+                (test/bench_goldilocks.cxx:73-143: 50 samples x 20 iterations, 2 + 2 trimmed, mean; its
+                :190 "Point scalarmul" line) and a short thread sweep over a bounded sample of the same
+                batch.  This leg is also where the oracle checks 256 lanes of every config's output.
+
+The table access of every timed call is passed PER CALL (the *_ex entry points, flags =
+GOLDILOCKS_AMD_CALL_TABLES_*); the process-wide default of the library is never touched.  The headline
+runs in the library's default mode, index-independent (the reference's constant-time contract).
 """
 import argparse
 import ctypes as C
@@ -52,9 +61,11 @@ VALU_MAC_PEAK = 36.0e12     # measured: 560-576 G v_mad_u64_u32 wave-instr/s x 6
 # accumulates per op, counted by the host checker build of the same lane code
 # (tests/test_hostsim.py::test_mac_counts_match_bench keeps these in step with the code).
 WORKLOADS = {
-    # 2175 M x 192 + 1785 S x 136 + 17 mulw x 16 with 5-bit windows; 4-bit windows (index-independent): +3 %
+    # fast (digit-addressed 5-bit window table): 2175 M x 192 + 1785 S x 136 + 17 mulw x 16.
+    # index-independent (the default; csrc/montgomery.hpp): 446 ladder steps of 5M + 4S + mulw, the y-recovery,
+    # the shared-inversion chain (3 M) and an eighth of an inversion (8 operations per lane at 2^20)
     "varbase": dict(metric="Ed448 variable-base scalarmuls/sec", unit="scalarmuls/s", bytes=568, macs=660_632,
-                    macs_index_independent=680_888,
+                    macs_index_independent=681_344 + 576 + 63_616 // 8, macs_ladder=681_344, macs_inversion=63_616,
                     desc="goldilocks_448_point_scalarmul, variable base, random scalars"),
     # a caller's precomputed_s: from 2^18 operations on the table is re-combed to 4 x 7 x 16 per call (k_import_comb +
     # k_recomb_big, 0.35 ms, inside the timed step) and multiplied by k_base_scalarmul_ct; below, the 5 x 5 x 18 comb
@@ -88,9 +99,11 @@ def parse(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip the extra BASELINE configs on the default run")
     ap.add_argument("--workload", default="varbase", choices=sorted(WORKLOADS))
-    ap.add_argument("--table-access", default="fast", choices=["fast", "index-independent"],
-                    help="goldilocks_amd_set_table_access: how tables are read for (possibly secret) scalars; "
-                         "the library's default is index-independent, the headline metric is quoted on fast")
+    ap.add_argument("--table-access", default="index-independent", choices=["fast", "index-independent"],
+                    help="GOLDILOCKS_AMD_CALL_TABLES_* of every timed call: how tables are read for (possibly secret) "
+                         "scalars; index-independent is the library's default and the reference's contract, fast the "
+                         "opt-in for public scalars")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-array (PCIe-inclusive) legs")
     ap.add_argument("--stub-step-ms", type=float, default=None,
                     help="launcher/timing self-test without a GPU: a step sleeps this long (tests only)")
     return ap.parse_args(argv)
@@ -101,8 +114,8 @@ def parse(argv=None):
 class Ctx(object):
     """What a workload needs: the binding, torch, the rank's batch size and launch stream."""
 
-    def __init__(self, ga, np, torch, n, rank, table_access):
-        self.ga, self.np, self.torch, self.n, self.rank, self.table_access = ga, np, torch, n, rank, table_access
+    def __init__(self, ga, np, torch, n, rank):
+        self.ga, self.np, self.torch, self.n, self.rank = ga, np, torch, n, rank
         self.stream = torch.cuda.current_stream().cuda_stream
         self._pairs = None
 
@@ -127,14 +140,21 @@ class Ctx(object):
         return self._pairs
 
 
-def make_workload(name, cx):
-    """-> dict(step, kernel, check() -> (ok, text), keep=[tensors])"""
+SAMPLE = 256   # lanes of every config the oracle re-computes in the cpu_baseline leg
+
+
+def make_workload(name, cx, access):
+    """-> dict(step, kernel, check() -> (ok, text, extra), sample() -> what the oracle needs to re-compute
+    the first SAMPLE lanes (host arrays only; the oracle itself is touched in cpu_baseline_leg alone)).
+    access: "index-independent" | "fast" -- passed to every timed call as its GOLDILOCKS_AMD_CALL_TABLES_* flags."""
     ga, np, torch, n, stream = cx.ga, cx.np, cx.torch, cx.n, cx.stream
-    ct = cx.table_access == "index-independent"
+    ct = access == "index-independent"
+    flags = ga.CALL_TABLES_INDEX_INDEPENDENT if ct else ga.CALL_TABLES_FAST
+    host = lambda t: t.cpu().numpy()
     if name == "varbase":
         bases, scalars = cx.pairs()
         out = torch.empty_like(bases)
-        step = lambda: ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, stream)
+        step = lambda: ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, stream, flags=flags)
 
         def check():
             stv = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -154,17 +174,23 @@ def make_workload(name, cx):
                 text += "; SHAKE256 digest of all outputs equals the reference's (golden F6)"
                 extra["full_batch_digest"] = {"shake256_32": digest, "matches_reference_fixture": match}
             return ok, text, extra
-        return dict(step=step, kernel="k_point_scalarmul_ct" if ct else "k_point_scalarmul", check=check, out=out)
+
+        def sample():
+            m = min(n, SAMPLE)
+            return dict(kind="varbase", bases=host(bases[:m]).view(np.uint64), scalars=host(scalars[:m]).view(np.uint64),
+                        got=ga.point_encode_batch(host(out[:m]).view(np.uint64)))
+        return dict(step=step, kernel="k_point_scalarmul_ct" if ct else "k_point_scalarmul", check=check, sample=sample)
     if name in ("fixed", "base"):
         _, scalars = cx.pairs()
         out = torch.empty((n, 32), dtype=torch.int64, device="cuda")
-        if name == "fixed":    # BASELINE config 3: a caller's precomputed_s -> a comb staged in LDS
+        if name == "fixed":    # BASELINE config 3: a caller's precomputed_s -> a comb staged in LDS (either mode)
             tab = torch.from_numpy(ga.precomputed_base().view(np.int64)).cuda()
-            step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), tab.data_ptr(), scalars.data_ptr(), n, stream)
+            step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), tab.data_ptr(), scalars.data_ptr(), n, stream,
+                                  flags=flags)
             kernel = "k_base_scalarmul_ct" if n >= WORKLOADS["fixed"]["recomb_min"] else "k_precomputed_scalarmul"
-        else:                  # the built-in base point: 16-bit window table (LDS comb when index-independent)
+        else:                  # the built-in base point: its LDS comb (index-independent) or its 16-bit window table (fast)
             tab = None
-            step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream)
+            step = lambda: ga.dev("precomputed_scalarmul", out.data_ptr(), None, scalars.data_ptr(), n, stream, flags=flags)
             kernel = "k_base_scalarmul_ct" if ct else "k_base_scalarmul"
 
         def check():
@@ -176,11 +202,16 @@ def make_workload(name, cx):
             zero = torch.zeros((m, 7), dtype=torch.int64, device="cuda")
             alt = torch.empty((m, 32), dtype=torch.int64, device="cuda")
             ga.dev("point_double_scalarmul", alt.data_ptr(), base_pt.data_ptr(), scalars.data_ptr(), base_pt.data_ptr(),
-                   zero.data_ptr(), m, None)
+                   zero.data_ptr(), m, None, flags=ga.CALL_TABLES_FAST)
             st = torch.empty(m, dtype=torch.int32, device="cuda")
             ga.dev("point_pred", st.data_ptr(), alt.data_ptr(), out.data_ptr(), 0, m, None)
             return int((st == -1).sum()) == m, "first %d results equal s*P + 0*P from the two-point window ladder, P = the generator as a caller's point" % m, {}
-        return dict(step=step, kernel=kernel, check=check, keep=[tab])
+
+        def sample():
+            m = min(n, SAMPLE)
+            return dict(kind="fixed", scalars=host(scalars[:m]).view(np.uint64),
+                        got=ga.point_encode_batch(host(out[:m]).view(np.uint64)))
+        return dict(step=step, kernel=kernel, check=check, sample=sample, keep=[tab])
     if name == "direct":       # wire format in and out: 56-byte encodings, decode + ladder + encode fused
         bases, scalars = cx.pairs()
         enc_in = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
@@ -188,11 +219,11 @@ def make_workload(name, cx):
         enc_out = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
         st_direct = torch.empty(n, dtype=torch.int32, device="cuda")
         step = lambda: ga.dev("direct_scalarmul", enc_out.data_ptr(), st_direct.data_ptr(), enc_in.data_ptr(),
-                              scalars.data_ptr(), 0, 0, n, stream)
+                              scalars.data_ptr(), 0, 0, n, stream, flags=flags)
 
         def check():
             ref = torch.empty_like(bases)
-            ga.dev("point_scalarmul", ref.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, None)
+            ga.dev("point_scalarmul", ref.data_ptr(), bases.data_ptr(), scalars.data_ptr(), n, None, flags=flags)
             ref_enc = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
             ga.dev("point_encode", ref_enc.data_ptr(), ref.data_ptr(), n, None)
             ok = bool((ref_enc == enc_out).all()) and int((st_direct == -1).sum()) == n
@@ -210,7 +241,7 @@ def make_workload(name, cx):
                                    .reshape(n, 32).copy()).cuda()
             sig_out = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
             step = lambda: ga.dev("ed448_sign", sig_out.data_ptr(), sk.data_ptr(), pk.data_ptr(), msg.data_ptr(), None,
-                                  32, 0, None, 0, n, stream)
+                                  32, 0, None, 0, n, stream, flags=flags)
 
             def check():
                 st = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -232,27 +263,92 @@ def make_workload(name, cx):
         return dict(step=step, kernel="k_x448", check=check)
     # verify: signatures over 32-byte messages from 1024 distinct keys, produced by the
     # library's own derive/sign kernels (bit-exact vs the reference: tests/test_gpu_parity.py); 1 % corrupted
-    nk, nsig = 1024, 4096
-    sk_k = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/sk" % cx.rank, 57 * nk), np.uint8).reshape(nk, 57)
-    pk_k = ga.ed448_derive_public_key_batch(sk_k)
-    key_of = np.arange(nsig) % nk
-    msg_h = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/msg" % cx.rank, 32 * nsig), np.uint8).reshape(nsig, 32)
-    sigs = ga.ed448_sign_batch(sk_k[key_of], pk_k[key_of], [m.tobytes() for m in msg_h])
-    pks = pk_k[key_of]
-    idx = np.random.default_rng(cx.rank).integers(0, nsig, n)
-    bad = np.random.default_rng(cx.rank + 99).random(n) < 0.01
-    sig_h = sigs[idx]
-    sig_h[bad, 5] ^= 0x20
-    d_sig, d_pk = torch.from_numpy(sig_h).cuda(), torch.from_numpy(pks[idx]).cuda()
-    d_msg = torch.from_numpy(msg_h[idx].copy()).cuda()
+    v = verify_inputs(cx)
+    d_sig, d_pk, d_msg = (torch.from_numpy(v[k]).cuda() for k in ("sig", "pk", "msg"))
     status = torch.empty(n, dtype=torch.int32, device="cuda")
     step = lambda: ga.dev("ed448_verify", status.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(),
                           None, 32, 0, None, 0, n, stream)
 
     def check():
         got = (status == -1).cpu().numpy()
-        return bool((got == ~bad).all()), "accepted lanes == uncorrupted lanes (signatures made by the sign kernel)", {}
-    return dict(step=step, kernel="k_ed448_verify", check=check)
+        return bool((got == ~v["bad"]).all()), "accepted lanes == uncorrupted lanes (signatures made by the sign kernel)", {}
+
+    def sample():
+        m = min(n, SAMPLE)
+        return dict(kind="verify", sigs=v["sig"][:m], pks=v["pk"][:m], msgs=[x.tobytes() for x in v["msg"][:m]],
+                    got=host(status[:m]))
+    return dict(step=step, kernel="k_ed448_verify", check=check, sample=sample)
+
+
+def verify_inputs(cx):
+    """BASELINE config 4's synthetic input (host arrays): n signatures over 32-byte messages from 1024 keys,
+    1 % corrupted (and lane 5 always, so that the oracle's sample of the first lanes holds a reject)."""
+    if getattr(cx, "_verify", None) is None:
+        import _gen
+        ga, np, n = cx.ga, cx.np, cx.n
+        nk, nsig = 1024, 4096
+        sk_k = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/sk" % cx.rank, 57 * nk), np.uint8).reshape(nk, 57)
+        pk_k = ga.ed448_derive_public_key_batch(sk_k)
+        key_of = np.arange(nsig) % nk
+        msg_h = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/msg" % cx.rank, 32 * nsig), np.uint8).reshape(nsig, 32)
+        sigs = ga.ed448_sign_batch(sk_k[key_of], pk_k[key_of], [m.tobytes() for m in msg_h])
+        pks = pk_k[key_of]
+        idx = np.random.default_rng(cx.rank).integers(0, nsig, n)
+        bad = np.random.default_rng(cx.rank + 99).random(n) < 0.01
+        if n > 5:
+            bad[5] = True
+        sig_h = sigs[idx]
+        sig_h[bad, 5] ^= 0x20
+        cx._verify = dict(sig=np.ascontiguousarray(sig_h), pk=np.ascontiguousarray(pks[idx]),
+                          msg=np.ascontiguousarray(msg_h[idx]), bad=bad)
+    return cx._verify
+
+
+# ---------------------------------------------------------------------------------------- end to end
+
+def end_to_end(cx, reps=3):
+    """The host-array entry points (goldilocks_448_point_scalarmul_batch, _precomputed_scalarmul_batch,
+    goldilocks_ed448_verify_batch): pageable host arrays in, host arrays out -- H2D, kernels and D2H inside
+    the timed call, library defaults (index-independent tables).  One untimed call first (it sizes the
+    library's staging pool), then the median of `reps`.  Output arrays are allocated and touched beforehand:
+    what is timed is the library, not the page faults of a fresh numpy array."""
+    ga, np, n = cx.ga, cx.np, cx.n
+    L = ga.lib()
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    bases, scalars = cx.pairs()
+    b_h, s_h = bases.cpu().numpy().view(np.uint64), scalars.cpu().numpy().view(np.uint64)
+    out = np.zeros((n, 32), dtype=np.uint64)
+    v = verify_inputs(cx)
+    msg = v["msg"]
+    mptr = (msg.ctypes.data + 32 * np.arange(n, dtype=np.uint64)).astype(np.uint64)   # const uint8_t *message[n]
+    mlen = np.full(n, 32, dtype=np.uint64)                                           # size_t message_len[n]
+    st = np.zeros(n, dtype=np.int32)
+    tab = C.c_void_p.in_dll(L, "goldilocks_448_precomputed_base")
+    calls = {
+        "varbase": (lambda: L.goldilocks_448_point_scalarmul_batch(ptr(out), ptr(b_h), ptr(s_h), n), 568,
+                    "goldilocks_448_point_scalarmul_batch"),
+        "fixed": (lambda: L.goldilocks_448_precomputed_scalarmul_batch(ptr(out), tab, ptr(s_h), n), 312,
+                  "goldilocks_448_precomputed_scalarmul_batch(goldilocks_448_precomputed_base)"),
+        "verify": (lambda: L.goldilocks_ed448_verify_batch(ptr(st), ptr(v["sig"]), ptr(v["pk"]), ptr(mptr), ptr(mlen), 0,
+                                                           None, 0, n), 207, "goldilocks_ed448_verify_batch"),
+    }
+    res = {}
+    for name, (call, nbytes, what) in calls.items():
+        if call():
+            raise RuntimeError(L.goldilocks_amd_last_error().decode())
+        times = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            rc = call()
+            times.append(time.perf_counter() - t0)
+            if rc:
+                raise RuntimeError(L.goldilocks_amd_last_error().decode())
+        t = sorted(times)[len(times) // 2]
+        res[name] = {"value": n / t, "unit": WORKLOADS[name]["unit"], "ms_per_call": t * 1e3, "entry_point": what,
+                     "pcie_bytes_per_op": nbytes, "host_memory": "pageable", "reps": reps}
+    ok = bool(((st == -1) == ~v["bad"]).all())
+    res["verify"]["check"] = "accepted lanes == uncorrupted lanes" if ok else "FAILED"
+    return res, ok
 
 
 # ---------------------------------------------------------------------------------------- CPU baseline
@@ -277,50 +373,63 @@ def host_cores():
     return usable, affinity, quota
 
 
-def cpu_model():
+def cpu_info():
+    model, flags = "unknown", set()
     try:
         for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            if line.startswith("flags") and not flags:
+                flags = set(line.split(":", 1)[1].split())
     except OSError:
         pass
-    return "unknown"
+    return model, flags
 
 
-def cpu_baseline(np, bases_h, scalars_h, budget_s=9.0):
-    """Time the reference's CPU path on the host cores.  The only place in this file that touches
-    oracle/ (test infrastructure).  Returns the object for the JSON line and the canonical encodings of
-    the first 256 reference results so that the caller can check the GPU's against them."""
-    from _libs import oracle, REF_X86_SO
+def cpu_baseline_leg(np, bases_h, scalars_h, samples, budget_s=9.0):
+    """Time the reference's CPU path on the host cores and let the oracle re-compute SAMPLE lanes of every
+    config.  The only place in this file that touches oracle/ (test infrastructure).
+    samples: {config name: workload sample()}.  -> (cpu_baseline object, {config name: (ok, text)})."""
+    from _libs import oracle, REF_X86_SO, REF_X86_V3_SO
     import _gen
     O = oracle()
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    kind, what, fn = "port", "oracle/gold_oracle.c (ref64-shaped restatement, gcc -O3)", None
-    if os.path.exists(REF_X86_SO):
-        try:
-            R = C.CDLL(REF_X86_SO)
-            fn = C.cast(R.goldilocks_448_point_scalarmul, C.c_void_p)
-            kind, what = "reference", "reference arch_x86_64 path (oracle/_ref, gcc -O2 generic x86-64)"
-        except OSError:
-            fn = None
+    model, cpuflags = cpu_info()
+    builds = []   # (label, what, function pointer or None)
+    for so, label, what, need in (
+            (REF_X86_SO, "x86_64_generic", "reference arch_x86_64 path, gcc -O2 -mtune=generic (oracle/Makefile)", set()),
+            (REF_X86_V3_SO, "x86_64_v3", "reference arch_x86_64 path, gcc -O2 -march=x86-64-v3: BMI2 mulx + AVX2, what "
+             "the reference's Makefile.custom:63 -march=native gives on a current host", {"avx2", "bmi2"})):
+        if os.path.exists(so) and need <= cpuflags:
+            try:
+                builds.append((label, what, C.cast(C.CDLL(so).goldilocks_448_point_scalarmul, C.c_void_p)))
+            except OSError:
+                pass
+    kind = "reference" if builds else "port"
+    if not builds:
+        builds.append(("oracle_port", "oracle/gold_oracle.c (ref64-shaped restatement, gcc -O3)", None))
     usable, affinity, quota = host_cores()
     n = len(scalars_h)
 
-    # (1) one thread, the reference's Benchmark method: 50 samples x 20 calls, drop 2 + 2, mean
+    # (1) one thread, the reference's Benchmark method: 50 samples x 20 calls, drop 2 + 2, mean -- every build
     nsamples, ntests, discard = 50, 20, 2
     m1 = min(n, nsamples * ntests)
     b1, s1 = np.ascontiguousarray(bases_h[:m1]), np.ascontiguousarray(scalars_h[:m1])
-    times = np.zeros(nsamples, dtype=np.float64)
-    O.orc_bench_extern_scalarmul(fn, p(b1), p(s1), m1, 3, ntests, p(times))          # warm tables and caches
-    O.orc_bench_extern_scalarmul(fn, p(b1), p(s1), m1, nsamples, ntests, p(times))
-    trimmed = np.sort(times)[discard:nsamples - discard]
-    us_per_op = float(trimmed.mean()) / ntests * 1e6
-    single = {"us_per_op": us_per_op, "value": 1e6 / us_per_op,
-              "method": "50 samples x 20 iterations, 2 low + 2 high dropped, mean (test/bench_goldilocks.cxx:73-143, :190)"}
+    singles = {}
+    for label, what, fn in builds:
+        times = np.zeros(nsamples, dtype=np.float64)
+        O.orc_bench_extern_scalarmul(fn, p(b1), p(s1), m1, 3, ntests, p(times))          # warm tables and caches
+        O.orc_bench_extern_scalarmul(fn, p(b1), p(s1), m1, nsamples, ntests, p(times))
+        us_per_op = float(np.sort(times)[discard:nsamples - discard].mean()) / ntests * 1e6
+        singles[label] = {"us_per_op": us_per_op, "value": 1e6 / us_per_op, "build": what}
+    best_label = max(singles, key=lambda k: singles[k]["value"])
+    label, what, fn = next(b for b in builds if b[0] == best_label)
+    single = dict(singles[best_label], method="50 samples x 20 iterations, 2 low + 2 high dropped, mean "
+                                              "(test/bench_goldilocks.cxx:73-143, :190)")
 
-    # (2) thread sweep over a bounded sample of the same batch; every point about budget/4 seconds
+    # (2) thread sweep of the faster build over a bounded sample of the same batch; every point about budget/4 seconds
     per_point = max(0.5, (budget_s - 1.0) / 3.0)
-    sweep, first = [], None
+    sweep = []
     for t in sorted({1, max(1, usable // 2), usable}):
         t = min(t, 256)                                    # the harness has 256 thread slots
         m = int(min(n, max(t * 64, per_point * t * single["value"])))
@@ -333,15 +442,34 @@ def cpu_baseline(np, bases_h, scalars_h, budget_s=9.0):
             O.orc_point_scalarmul_batch(p(out), p(b), p(s), m, t)
         dt = time.perf_counter() - t0
         sweep.append({"threads": t, "ops": m, "seconds": dt, "value": m / dt})
-        if first is None or len(out) > len(first):
-            first = out
     best = max(sweep, key=lambda r: r["value"])
+    try:
+        import subprocess
+        gcc = subprocess.run(["gcc", "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:   # noqa
+        gcc = "unknown"
     res = {"value": best["value"], "unit": "scalarmuls/s", "cores": best["threads"], "kind": kind,
            "sample": "best of a thread sweep %s over the first %d of this batch's (point, scalar) pairs; %s" %
                      ([r["threads"] for r in sweep], best["ops"], what),
-           "single_thread": single, "sweep": sweep, "cpu_model": cpu_model(), "affinity_cores": affinity,
+           "build": best_label, "single_thread": single, "single_thread_by_build": singles, "sweep": sweep,
+           "compiler": gcc + " (in the build container)", "cpu_model": model, "affinity_cores": affinity,
            "cgroup_quota_cores": quota, "usable_cores": usable}
-    return res, _gen.oracle_encode(first[:256])
+
+    # (3) the oracle re-computes the first lanes of every config
+    checks = {}
+    for cname, smp in samples.items():
+        if smp["kind"] == "varbase":
+            want = _gen.oracle_encode(_gen.oracle_varbase(O, smp["bases"], smp["scalars"]))
+            what_chk = "oracle's goldilocks_448_point_scalarmul (src/goldilocks.c:405-465)"
+        elif smp["kind"] == "fixed":
+            want = _gen.oracle_encode(_gen.oracle_fixed(O, smp["scalars"]))
+            what_chk = "oracle's goldilocks_448_precomputed_scalarmul (src/goldilocks.c:830-877)"
+        else:
+            want = _gen.oracle_verify(O, smp["sigs"], smp["pks"], smp["msgs"])
+            what_chk = "oracle's goldilocks_ed448_verify (src/eddsa.c:253-306), %d rejects among them" % int((want == 0).sum())
+        same = bool((np.asarray(smp["got"]) == want).all())
+        checks[cname] = (same, "first %d lanes equal the %s" % (len(want), what_chk))
+    return res, checks
 
 
 # ---------------------------------------------------------------------------------------- one rank
@@ -361,7 +489,7 @@ def pmc_traffic(kernel):
     return None
 
 
-def roofline(name, kernel, n, avg_ms, table_access="fast"):
+def roofline(name, kernel, n, avg_ms, table_access):
     spec = dict(WORKLOADS[name])
     if table_access == "index-independent" and spec.get("macs_index_independent"):
         spec["macs"] = spec["macs_index_independent"]
@@ -398,6 +526,14 @@ def run_stub(args, shard, rank, world):
         dist.destroy_process_group()
 
 
+# the other BASELINE configs on the default line: (key, workload, table access of its calls)
+CONFIGS = (("fixed", "fixed", "index-independent"),          # config 3: a caller's comb table, staged in LDS
+           ("base", "base", "index-independent"),            # ... the built-in base point, library default
+           ("verify", "verify", "index-independent"),        # config 4 (public data: the mode changes nothing)
+           ("varbase_fast", "varbase", "fast"),              # the opt-in for public scalars
+           ("base_fast", "base", "fast"))
+
+
 def run_rank(args):
     from libgoldilocks_amd import shard
     rank = int(os.environ.get("RANK", "0"))
@@ -413,7 +549,6 @@ def run_rank(args):
     torch.cuda.set_device(device)
     dist, backend = shard.init_group(world, rank, visible)
     ga.lib()
-    ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT if args.table_access == "index-independent" else ga.TABLES_FAST)
     info = ga.device_info()
 
     if args.global_log2_batch is not None:
@@ -423,12 +558,15 @@ def run_rank(args):
         n, scaling = 1 << args.log2_batch, "weak"
     name = args.workload
     spec = WORKLOADS[name]
-    cx = Ctx(ga, np, torch, n, rank, args.table_access)
-    w = make_workload(name, cx)
+    cx = Ctx(ga, np, torch, n, rank)
+    w = make_workload(name, cx, args.table_access)
     mine, worst, kernel_ms = time_workload(torch, shard, w, args.steps, args.warmup, dist, backend)
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     rows = shard.gather_over_ranks([rank, device, n * args.steps / mine, avg_ms, n], dist, backend)
     ok, check, extra = w["check"]() if rank == 0 else (True, "n/a", {})
+    default_line = rank == 0 and world == 1 and name == "varbase" and args.table_access == "index-independent" \
+        and args.global_log2_batch is None
+    samples = {}
 
     line = None
     if rank == 0:
@@ -439,6 +577,7 @@ def run_rank(args):
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": worst / args.steps * 1e3,
             "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "config": {"workload": spec["desc"], "batch_per_gpu": n, "table_access": args.table_access,
+                       "table_access_is_library_default": args.table_access == "index-independent",
                        "sharding": ("contiguous slices of one global batch of 2^%d" % args.global_log2_batch
                                     if args.global_log2_batch is not None else "independent batch per GPU")
                                    + ", no data-path collective", "control_plane": backend or "single process",
@@ -449,38 +588,44 @@ def run_rank(args):
             "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access),
         }
         line.update(extra)
+        if "sample" in w and world == 1:
+            samples["headline"] = w["sample"]()
 
     # the other BASELINE configs, a few steps each (default single-GPU run of the headline only)
-    if rank == 0 and world == 1 and name == "varbase" and args.table_access == "fast" and not args.no_configs \
-            and args.global_log2_batch is None:
+    if default_line and not args.no_configs:
         configs = {}
-        for cname, access in (("fixed", "fast"), ("base", "fast"), ("verify", "fast"), ("varbase", "index-independent")):
-            ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT if access == "index-independent" else ga.TABLES_FAST)
-            cx.table_access = access
-            cw = make_workload(cname, cx)
+        for key, cname, access in CONFIGS:
+            cw = make_workload(cname, cx, access)
             _, cworst, cms = time_workload(torch, shard, cw, 5, 1, None, None)
             cok, ctext, _ = cw["check"]()
             cavg = sum(cms) / len(cms)
             r = roofline(cname, cw["kernel"], n, cavg, access)
-            key = cname if access == "fast" else cname + "_index_independent"
             configs[key] = {"value": n * 5 / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
                             "table_access": access, "steps": 5, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
                             "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit")},
                             "mac_frac": r["mac"]["frac"] if "mac" in r else None, "check": ctext,
                             "parity_spot_check": "ok" if cok else "FAILED"}
             ok = ok and cok
+            samples[key] = cw["sample"]()
             del cw
-        ga.set_table_access(ga.TABLES_FAST)
-        cx.table_access = "fast"
         line["configs"] = configs
+
+    if default_line and not args.no_end_to_end:
+        line["end_to_end"], e2e_ok = end_to_end(cx)
+        ok = ok and e2e_ok
 
     if rank == 0 and world == 1 and name == "varbase" and not args.no_cpu_baseline:   # rank 0 at N = 1 only
         bases, scalars = cx.pairs()
         b_h, s_h = bases.cpu().numpy().view(np.uint64), scalars.cpu().numpy().view(np.uint64)
-        line["cpu_baseline"], ref_enc = cpu_baseline(np, b_h, s_h)
-        same = bool((ga.point_encode_batch(w["out"][:256].cpu().numpy().view(np.uint64)) == ref_enc).all())
-        ok = ok and same
-        line["config"]["check"] += "; first 256 results bit-exact vs the CPU baseline's outputs"
+        line["cpu_baseline"], checks = cpu_baseline_leg(np, b_h, s_h, samples)
+        for key, (same, text) in checks.items():
+            ok = ok and same
+            if key == "headline":
+                line["config"]["check"] += "; " + text
+            else:
+                line["configs"][key]["check"] = text + "; " + line["configs"][key]["check"]
+                if not same:
+                    line["configs"][key]["parity_spot_check"] = "FAILED"
         line["config"]["parity_spot_check"] = "ok" if ok else "FAILED"
 
     if rank == 0:

@@ -224,6 +224,16 @@ GOLDILOCKS_AMD_API int goldilocks_448_point_scalarmul_batch(goldilocks_448_point
         const goldilocks_448_point_s *base, const goldilocks_448_scalar_s *scalar, size_t n);
 GOLDILOCKS_AMD_API int goldilocks_448_precomputed_scalarmul_batch(goldilocks_448_point_s *scaled,
         const goldilocks_448_precomputed_s *table, const goldilocks_448_scalar_s *scalar, size_t n);
+/* The same with the table access (GOLDILOCKS_AMD_CALL_TABLES_*, below) and the devices of THIS call: the batch
+ * is cut into contiguous slices over devices[0..device_count) as goldilocks_amd_use_devices describes;
+ * device_count = 0: the process-wide list (by default the calling thread's current device), devices == NULL
+ * with device_count > 0: devices 0..device_count-1. */
+GOLDILOCKS_AMD_API int goldilocks_448_point_scalarmul_batch_ex(goldilocks_448_point_s *scaled,
+        const goldilocks_448_point_s *base, const goldilocks_448_scalar_s *scalar, size_t n, uint32_t flags,
+        const int *devices, int device_count);
+GOLDILOCKS_AMD_API int goldilocks_448_precomputed_scalarmul_batch_ex(goldilocks_448_point_s *scaled,
+        const goldilocks_448_precomputed_s *table, const goldilocks_448_scalar_s *scalar, size_t n, uint32_t flags,
+        const int *devices, int device_count);
 GOLDILOCKS_AMD_API int goldilocks_448_point_double_scalarmul_batch(goldilocks_448_point_s *combo,
         const goldilocks_448_point_s *base1, const goldilocks_448_scalar_s *scalar1,
         const goldilocks_448_point_s *base2, const goldilocks_448_scalar_s *scalar2, size_t n);
@@ -240,6 +250,12 @@ GOLDILOCKS_AMD_API int goldilocks_ed448_verify_batch(goldilocks_error_t *status,
         const uint8_t *sig /* n*114 */, const uint8_t *pk /* n*57 */,
         const uint8_t *const *message, const size_t *message_len, uint8_t prehashed,
         const uint8_t *context, uint8_t context_len, size_t n);
+
+/* ... over the devices of this call (verification is public data: no table-access choice) */
+GOLDILOCKS_AMD_API int goldilocks_ed448_verify_batch_ex(goldilocks_error_t *status,
+        const uint8_t *sig /* n*114 */, const uint8_t *pk /* n*57 */,
+        const uint8_t *const *message, const size_t *message_len, uint8_t prehashed,
+        const uint8_t *context, uint8_t context_len, size_t n, const int *devices, int device_count);
 
 GOLDILOCKS_AMD_API int goldilocks_ed448_derive_public_key_batch(uint8_t *pubkey /* n*57 */,
         const uint8_t *privkey /* n*57 */, size_t n);
@@ -294,9 +310,11 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  *       built-in table): a signed comb of the base point staged in LDS (4 combs x 7 teeth x spacing 16,
  *       the structure of the reference's 5x5x18 with fewer additions), every lookup a
  *       wavefront-shuffle gather whose addresses and timing do not depend on the digit;
- *     - variable-base multiplications (point_scalarmul, direct_scalarmul, double_scalarmul,
- *       dual_scalarmul): 4-bit signed windows, every lookup reads all 8 entries of the lane's table
- *       and keeps the wanted one with a select.
+ *     - goldilocks_448_point_scalarmul: NO table -- a Montgomery ladder on the Montgomery model of the
+ *       curve with selects only, then the other coordinate is recovered (csrc/montgomery.hpp);
+ *     - the other variable-base multiplications (direct_scalarmul, double_scalarmul, dual_scalarmul):
+ *       4-bit signed windows, every lookup reads all 8 entries of the lane's table and keeps the wanted
+ *       one with a select.
  *   GOLDILOCKS_AMD_TABLES_FAST (opt-in, for PUBLIC scalars only)
  *     - each lookup reads only the digit's entry (the address depends on the digit): the base point's
  *       16-bit window table in global memory, 5-bit windows for a variable base.
@@ -304,12 +322,24 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  * Not affected: verification and base_double_scalarmul_non_secret (public by contract: always the
  * fast tables), goldilocks_x448 with a peer's point (a Montgomery ladder with selects, no table),
  * caller-supplied precomputed_s tables (always an LDS comb with the same gather: the reference's 5x5x18,
- * re-combed to 4x7x16 per call for batches of 2^18 operations or more).  Process-wide; returns 0, or nonzero
- * for an unknown mode. */
+ * re-combed to 4x7x16 per call for batches of 2^18 operations or more).
+ *
+ * goldilocks_amd_set_table_access sets the PROCESS-WIDE DEFAULT only (returns 0, or nonzero for an unknown
+ * mode).  The reference has no mutable global state on these paths (every function is reentrant), so a
+ * caller with both public and secret scalars in one process should leave the default alone and say what it
+ * wants PER CALL: every entry point whose table access depends on the mode has an *_ex twin taking `flags`,
+ *     GOLDILOCKS_AMD_CALL_TABLES_DEFAULT             the process-wide default (what the plain name does)
+ *     GOLDILOCKS_AMD_CALL_TABLES_FAST                this call's scalars are public
+ *     GOLDILOCKS_AMD_CALL_TABLES_INDEX_INDEPENDENT   this call's scalars may be secret
+ * so that one thread's opt-in for public data can never downgrade another thread's signing. */
 #define GOLDILOCKS_AMD_TABLES_FAST 0
 #define GOLDILOCKS_AMD_TABLES_INDEX_INDEPENDENT 1
 GOLDILOCKS_AMD_API int goldilocks_amd_set_table_access(int mode);
-GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the mode in force */
+GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the process-wide default in force */
+#define GOLDILOCKS_AMD_CALL_TABLES_DEFAULT 0u
+#define GOLDILOCKS_AMD_CALL_TABLES_FAST 1u
+#define GOLDILOCKS_AMD_CALL_TABLES_INDEX_INDEPENDENT 2u
+#define GOLDILOCKS_AMD_CALL_TABLES_MASK 3u
 /* Small batches.  One lane's ladder takes 2.1-2.8 ms however few operations a call has, so batches of
  * up to `n` variable-base, double-base or dual multiplications -- 3n/4 fixed-base multiplications or X448
  * shared secrets, n/2 verifications, wire-format multiplications, key derivations, X448 key generations
@@ -384,6 +414,26 @@ GOLDILOCKS_AMD_API int goldilocks_amd_point_from_hash_dev(void *pt, const void *
 /* base == NULL: x448_derive_public_key for every lane (status all success); status: int32[n] or NULL */
 GOLDILOCKS_AMD_API int goldilocks_amd_x448_dev(void *shared /* n*56 */, void *status, const void *base,
         const void *scalar /* n*56 */, size_t n, void *stream);
+
+/* The device-array entry points whose table access depends on the mode, with the mode of THIS call
+ * (flags = GOLDILOCKS_AMD_CALL_TABLES_*; unknown bits are an error).  Everything else as the plain name. */
+GOLDILOCKS_AMD_API int goldilocks_amd_point_scalarmul_dev_ex(void *scaled, const void *base, const void *scalar,
+        size_t n, void *stream, uint32_t flags);
+GOLDILOCKS_AMD_API int goldilocks_amd_precomputed_scalarmul_dev_ex(void *scaled, const void *table,
+        const void *scalar, size_t n, void *stream, uint32_t flags);
+GOLDILOCKS_AMD_API int goldilocks_amd_point_double_scalarmul_dev_ex(void *combo, const void *base1,
+        const void *scalar1, const void *base2, const void *scalar2, size_t n, void *stream, uint32_t flags);
+GOLDILOCKS_AMD_API int goldilocks_amd_ed448_derive_public_key_dev_ex(void *pubkey, const void *privkey, size_t n,
+        void *stream, uint32_t flags);
+GOLDILOCKS_AMD_API int goldilocks_amd_ed448_sign_dev_ex(void *signature, const void *privkey, const void *pubkey,
+        const void *msgs, const void *msg_offsets, size_t msg_len, uint8_t prehashed, const void *ctx,
+        uint8_t ctx_len, size_t n, void *stream, uint32_t flags);
+GOLDILOCKS_AMD_API int goldilocks_amd_direct_scalarmul_dev_ex(void *scaled, void *status, const void *base,
+        const void *scalar, int allow_identity, int short_circuit, size_t n, void *stream, uint32_t flags);
+GOLDILOCKS_AMD_API int goldilocks_amd_point_dual_scalarmul_dev_ex(void *a1, void *a2, const void *base,
+        const void *scalar1, const void *scalar2, size_t n, void *stream, uint32_t flags);
+GOLDILOCKS_AMD_API int goldilocks_amd_x448_dev_ex(void *shared, void *status, const void *base, const void *scalar,
+        size_t n, void *stream, uint32_t flags);
 
 /* Field-level test hook (parity tests for SURVEY 8a rows a2-a7; ref: src/f_field.h:76-79,
  * src/arch_ref64/f_impl.h:10-38, src/f_generic.c:19-131).  a, b, out: gf_448_s[n] in the ABI limb form.

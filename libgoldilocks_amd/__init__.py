@@ -60,6 +60,9 @@ FUNCTIONS = {
     # (2) host-array batches
     "goldilocks_448_point_scalarmul_batch": (C.c_int, "pppz"),
     "goldilocks_448_precomputed_scalarmul_batch": (C.c_int, "pppz"),
+    "goldilocks_448_point_scalarmul_batch_ex": (C.c_int, "pppzIpi"),
+    "goldilocks_448_precomputed_scalarmul_batch_ex": (C.c_int, "pppzIpi"),
+    "goldilocks_ed448_verify_batch_ex": (C.c_int, "pppppBpBzpi"),
     "goldilocks_448_point_double_scalarmul_batch": (C.c_int, "pppppz"),
     "goldilocks_448_point_encode_batch": (C.c_int, "ppz"),
     "goldilocks_448_point_decode_batch": (C.c_int, "pppQz"),
@@ -103,13 +106,22 @@ FUNCTIONS = {
     "goldilocks_amd_x448_dev": (C.c_int, "ppppzp"),
     "goldilocks_amd_point_dual_scalarmul_dev": (C.c_int, "pppppzp"),
     "goldilocks_amd_point_from_hash_dev": (C.c_int, "ppizp"),
+    # ... with the table access of the call (GOLDILOCKS_AMD_CALL_TABLES_*)
+    "goldilocks_amd_point_scalarmul_dev_ex": (C.c_int, "pppzpI"),
+    "goldilocks_amd_precomputed_scalarmul_dev_ex": (C.c_int, "pppzpI"),
+    "goldilocks_amd_point_double_scalarmul_dev_ex": (C.c_int, "pppppzpI"),
+    "goldilocks_amd_ed448_derive_public_key_dev_ex": (C.c_int, "ppzpI"),
+    "goldilocks_amd_ed448_sign_dev_ex": (C.c_int, "pppppzBpBzpI"),
+    "goldilocks_amd_direct_scalarmul_dev_ex": (C.c_int, "ppppiizpI"),
+    "goldilocks_amd_point_dual_scalarmul_dev_ex": (C.c_int, "pppppzpI"),
+    "goldilocks_amd_x448_dev_ex": (C.c_int, "ppppzpI"),
 }
 DATA_SYMBOLS = [
     "goldilocks_448_sizeof_precomputed_s", "goldilocks_448_alignof_precomputed_s",
     "goldilocks_448_scalar_one", "goldilocks_448_scalar_zero", "goldilocks_448_point_identity",
     "goldilocks_448_point_base", "goldilocks_448_precomputed_base", "goldilocks_x448_base_point",
 ]
-_CT = {"p": C.c_void_p, "z": C.c_size_t, "Q": C.c_uint64, "B": C.c_uint8, "i": C.c_int}
+_CT = {"p": C.c_void_p, "z": C.c_size_t, "Q": C.c_uint64, "B": C.c_uint8, "i": C.c_int, "I": C.c_uint32}
 
 _lib = None
 
@@ -187,16 +199,27 @@ def precomputed_base():
 # ----------------------------------------------------------------------------- host-array batches
 
 
-def point_scalarmul_batch(bases, scalars):
+CALL_TABLES_DEFAULT, CALL_TABLES_FAST, CALL_TABLES_INDEX_INDEPENDENT = 0, 1, 2   # the `flags` of the *_ex entry points
+
+
+def _devs(devices):
+    devices = list(devices or [])
+    arr = (C.c_int * max(1, len(devices)))(*devices)
+    return arr, (C.addressof(arr) if devices else None), len(devices)
+
+
+def point_scalarmul_batch(bases, scalars, flags=CALL_TABLES_DEFAULT, devices=None):
+    """flags / devices: the table access and the GPUs of THIS call (goldilocks_448_point_scalarmul_batch_ex)."""
     bases, scalars = _u64(bases, 32), _u64(scalars, 7)
     n = len(scalars)
     assert len(bases) == n
     out = np.empty((n, 32), dtype=np.uint64)
-    _check(lib().goldilocks_448_point_scalarmul_batch(_ptr(out), _ptr(bases), _ptr(scalars), n))
+    keep, dp, dn = _devs(devices)
+    _check(lib().goldilocks_448_point_scalarmul_batch_ex(_ptr(out), _ptr(bases), _ptr(scalars), n, flags, dp, dn))
     return out
 
 
-def precomputed_scalarmul_batch(scalars, table=None):
+def precomputed_scalarmul_batch(scalars, table=None, flags=CALL_TABLES_DEFAULT, devices=None):
     scalars = _u64(scalars, 7)
     n = len(scalars)
     out = np.empty((n, 32), dtype=np.uint64)
@@ -205,7 +228,8 @@ def precomputed_scalarmul_batch(scalars, table=None):
     else:
         table = np.ascontiguousarray(table, dtype=np.uint64).reshape(1920)
         tab = _ptr(table)
-    _check(lib().goldilocks_448_precomputed_scalarmul_batch(_ptr(out), tab, _ptr(scalars), n))
+    keep, dp, dn = _devs(devices)
+    _check(lib().goldilocks_448_precomputed_scalarmul_batch_ex(_ptr(out), tab, _ptr(scalars), n, flags, dp, dn))
     return out
 
 
@@ -254,8 +278,8 @@ def point_decode_like_eddsa_batch(enc):
     return pts, st
 
 
-def ed448_verify_batch(sigs, pks, messages, prehashed=False, context=b""):
-    """status[i] in {-1 (valid), 0 (invalid)} for each (sig, pk, message)."""
+def ed448_verify_batch(sigs, pks, messages, prehashed=False, context=b"", devices=None):
+    """status[i] in {-1 (valid), 0 (invalid)} for each (sig, pk, message); devices: the GPUs of this call."""
     sigs, pks = _u8(sigs, 114), _u8(pks, 57)
     n = len(sigs)
     assert len(pks) == n and len(messages) == n
@@ -264,9 +288,10 @@ def ed448_verify_batch(sigs, pks, messages, prehashed=False, context=b""):
     lens = (C.c_size_t * n)(*[len(m) for m in messages])
     ctx = C.create_string_buffer(bytes(context), max(len(context), 1))
     st = np.empty(n, dtype=np.int32)
-    _check(lib().goldilocks_ed448_verify_batch(_ptr(st), _ptr(sigs), _ptr(pks), C.addressof(ptrs),
-                                               C.addressof(lens), 1 if prehashed else 0, C.addressof(ctx),
-                                               len(context), n))
+    keep, dp, dn = _devs(devices)
+    _check(lib().goldilocks_ed448_verify_batch_ex(_ptr(st), _ptr(sigs), _ptr(pks), C.addressof(ptrs),
+                                                  C.addressof(lens), 1 if prehashed else 0, C.addressof(ctx),
+                                                  len(context), n, dp, dn))
     return st
 
 
@@ -379,9 +404,13 @@ class EDDSA448(object):
 # ----------------------------------------------------------------------------- device-array API (torch / raw pointers)
 
 
-def dev(name, *args):
-    """Call goldilocks_amd_<name>_dev with raw device pointers (ints) / sizes; raises on error."""
-    _check(getattr(lib(), "goldilocks_amd_%s_dev" % name)(*args))
+def dev(name, *args, flags=None):
+    """Call goldilocks_amd_<name>_dev with raw device pointers (ints) / sizes; raises on error.
+    flags (CALL_TABLES_*): the table access of this call, through goldilocks_amd_<name>_dev_ex."""
+    if flags is None:
+        _check(getattr(lib(), "goldilocks_amd_%s_dev" % name)(*args))
+    else:
+        _check(getattr(lib(), "goldilocks_amd_%s_dev_ex" % name)(*args, flags))
 
 
 def use_devices(devices=None):

@@ -13,8 +13,8 @@ bench.py uses everything in this file:
                    rank, BEFORE anything in this process has touched a GPU (this module imports
                    neither torch nor HIP at module level; a process that has initialised the GPU
                    must never re-exec, and this one never initialises it at all)
-  init_group()     the process group of a rank: RCCL ("nccl") when every rank has a GPU of its own,
-                   gloo when ranks have to share a device (2 ranks on a 1-GPU box) or run without one
+  init_group()     the process group of a rank: gloo always, plus RCCL ("nccl") on top when every rank has
+                   a GPU of its own AND the ranks agree (over gloo) that it came up on all of them
   timed_region()   W untimed steps, barrier + sync, K timed steps, barrier + sync
   max_over_ranks / sum_over_ranks / gather_over_ranks
 """
@@ -55,10 +55,16 @@ def rank_env(rank, world, port, base=None):
     return env
 
 
-def launch_ranks(argv, world, timeout=None):
+LAUNCH_TIMEOUT_S = 3600.0   # a whole bench run of one rank, generously; launch_ranks(timeout=None) waits forever
+
+
+def launch_ranks(argv, world, timeout=LAUNCH_TIMEOUT_S, poll_s=0.05):
     """Run `python argv...` once per rank (fresh processes, rendezvous on 127.0.0.1) and return the
     largest exit code.  Rank 0's stdout is this process's stdout (the one JSON line); the other
-    ranks' stdout goes to stderr.  Nothing here touches a GPU."""
+    ranks' stdout goes to stderr.  Nothing here touches a GPU.
+    All children are polled together: the first one that ends with a non-zero code ends the launch --
+    the others (probably waiting for it in a barrier) are killed at once instead of sitting out the
+    process group's timeout -- and so does the deadline (exit code 124)."""
     port = free_port()
     procs = []
     for rank in range(world):
@@ -67,12 +73,21 @@ def launch_ranks(argv, world, timeout=None):
     deadline = None if timeout is None else time.time() + timeout
     code = 0
     try:
-        for p in procs:
-            left = None if deadline is None else max(1.0, deadline - time.time())
-            rc = p.wait(timeout=left)
-            code = max(code, abs(rc))
-    except subprocess.TimeoutExpired:
-        code = 124
+        running = list(procs)
+        while running:
+            for p in list(running):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                running.remove(p)
+                code = max(code, abs(rc))
+            if code:                      # a rank failed: do not wait for the ones it left hanging
+                break
+            if deadline is not None and time.time() > deadline:
+                code = 124
+                break
+            if running:
+                time.sleep(poll_s)
     finally:
         for p in procs:           # exactly the children started here, by pid
             if p.poll() is None:
@@ -81,11 +96,42 @@ def launch_ranks(argv, world, timeout=None):
     return code
 
 
-def init_group(world, rank, visible_devices, use_gpu=True):
-    """torch.distributed process group for this rank, or None when world == 1.  Returns (dist, backend).
-    RCCL ("nccl") when every rank has a GPU of its own, gloo otherwise; GOLDILOCKS_BENCH_BACKEND=gloo
-    forces gloo, and a failing RCCL bring-up falls back to it (the group only carries the barrier, the MAX
-    of the elapsed time and the per-rank rows -- nothing of the data path)."""
+class Group(object):
+    """The control-plane process group of a rank: torch.distributed bound to ONE group, so that callers
+    (bench.py, the helpers below) write dist.barrier() / dist.all_reduce(t) whichever backend carries it."""
+
+    def __init__(self, dist, group):
+        self._dist, self.group = dist, group
+        self.ReduceOp = dist.ReduceOp
+
+    def is_initialized(self):
+        return self._dist.is_initialized()
+
+    def get_world_size(self):
+        return self._dist.get_world_size(group=self.group)
+
+    def barrier(self):
+        self._dist.barrier(group=self.group)
+
+    def all_reduce(self, t, op=None):
+        self._dist.all_reduce(t, op=op if op is not None else self._dist.ReduceOp.SUM, group=self.group)
+
+    def all_gather(self, out, t):
+        self._dist.all_gather(out, t, group=self.group)
+
+    def destroy_process_group(self):
+        self._dist.destroy_process_group()
+
+
+def init_group(world, rank, visible_devices, use_gpu=True, rccl_timeout_s=120):
+    """The process group of this rank, or (None, None) when world == 1.  Returns (Group, backend).
+
+    The DEFAULT group is always gloo (it comes up wherever TCP on 127.0.0.1 does).  When every rank has a
+    GPU of its own an RCCL ("nccl") group is brought up on top of it, and the ranks AGREE over gloo whether
+    that worked for all of them: RCCL carries the barrier / MAX / all-gather only if every rank's bring-up
+    succeeded, otherwise every rank uses gloo -- no rank decides on its own, so a partial RCCL failure can
+    neither hang the others in a barrier nor split the job over two backends.  GOLDILOCKS_BENCH_BACKEND=gloo
+    skips RCCL.  The group only carries the control plane; nothing of the data path."""
     if world <= 1 and not os.environ.get("GOLDILOCKS_BENCH_FORCE_DIST"):   # the knob lets a 1-GPU box exercise RCCL
         return None, None
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -95,34 +141,33 @@ def init_group(world, rank, visible_devices, use_gpu=True):
     import torch
     import torch.distributed as dist
     own_device = use_gpu and visible_devices >= world
-    backend = os.environ.get("GOLDILOCKS_BENCH_BACKEND") or ("nccl" if own_device else "gloo")
+    want = os.environ.get("GOLDILOCKS_BENCH_BACKEND") or ("nccl" if own_device else "gloo")
     os.environ.setdefault("NCCL_DEBUG", "WARN")          # keep RCCL's banner off stdout: one JSON line only
-
-    def bring_up(which):
-        kw = {}
-        if which == "nccl":
-            kw["device_id"] = torch.device("cuda", device_for_rank(rank, visible_devices))
-        dist.init_process_group(which, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600), **kw)
-        dist.barrier()                                   # connections are made (and announced) lazily
 
     # gloo and RCCL print banners on the C-level stdout; rank 0's stdout carries ONE JSON line only
     sys.stdout.flush()
     saved = os.dup(1)
     os.dup2(2, 1)
     try:
-        try:
-            bring_up(backend)
-        except Exception as e:   # noqa: BLE001 -- whatever RCCL raises on this node
-            if backend != "nccl":
-                raise
-            print("shard.init_group: RCCL bring-up failed (%s); control plane falls back to gloo" % e, file=sys.stderr)
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600))
+        dist.barrier()
+        group, backend = None, "gloo"
+        if want == "nccl":
+            mine, rccl = 1, None
             try:
-                dist.destroy_process_group()
-            except Exception:   # noqa: BLE001
-                pass
-            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
-            backend = "gloo"
-            bring_up(backend)
+                rccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=rccl_timeout_s))
+                dist.barrier(group=rccl)                 # connections are made (and announced) lazily
+                torch.cuda.synchronize()
+            except Exception as e:   # noqa: BLE001 -- whatever RCCL raises on this node
+                mine = 0
+                print("shard.init_group: rank %d: RCCL bring-up failed (%s)" % (rank, e), file=sys.stderr)
+            agreed = torch.tensor([mine], dtype=torch.int32)
+            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)    # over gloo: every rank learns the same answer
+            if int(agreed.item()) == 1:
+                group, backend = rccl, "nccl"
+            elif rank == 0:
+                print("shard.init_group: RCCL did not come up on every rank; the control plane stays on gloo",
+                      file=sys.stderr)
     finally:
         try:   # what the C libraries wrote sits in stdio's buffer: push it out while fd 1 still is stderr
             import ctypes
@@ -131,7 +176,7 @@ def init_group(world, rank, visible_devices, use_gpu=True):
             pass
         os.dup2(saved, 1)
         os.close(saved)
-    return dist, backend
+    return Group(dist, group), backend
 
 
 def _reduce(value, op_name, dist, backend, dtype_name):

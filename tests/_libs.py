@@ -11,6 +11,7 @@ ORACLE_DIR = os.path.join(ROOT, "oracle")
 ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 REF_SO = os.path.join(ORACLE_DIR, "_ref", "libgoldilocks_ref64.so")
 REF_X86_SO = os.path.join(ORACLE_DIR, "_ref", "libgoldilocks_x86_64.so")
+REF_X86_V3_SO = os.path.join(ORACLE_DIR, "_ref", "libgoldilocks_x86_64_v3.so")   # -march=x86-64-v3: needs AVX2 + BMI2
 
 P = 2**448 - 2**224 - 1
 Q = 2**446 - 0x8335DC163BB124B65129C96FDE933D8D723A70AADC873D6D54A7BB0D

@@ -119,7 +119,7 @@ def test_bench_touches_the_oracle_only_in_its_cpu_baseline_leg():
     src = open(os.path.join(ROOT, "bench.py")).read()
     tree = ast.parse(src)
     for node in tree.body:
-        if isinstance(node, ast.FunctionDef) and node.name != "cpu_baseline":
+        if isinstance(node, ast.FunctionDef) and node.name != "cpu_baseline_leg":
             seg = ast.get_source_segment(src, node)
             code_lines = [l.split("#")[0] for l in seg.splitlines()]
             code = "\n".join(l for l in code_lines if not l.strip().startswith(('"', "'")))

@@ -76,3 +76,26 @@ def test_rank_to_device_mapping_and_strong_slices():
         device_for_rank(0, 0)
     # BASELINE config 5: 2^24 verifications over 8 GPUs = 2^21 each
     assert [shard_range(1 << 24, r, 8)[1] - shard_range(1 << 24, r, 8)[0] for r in range(8)] == [1 << 21] * 8
+
+
+def test_a_dead_rank_ends_the_launch_promptly():
+    """Rank 1 exits with code 3 while rank 0 would sit in a barrier (here: sleeps a minute): the launcher polls all
+    children, returns the failure within seconds and leaves no child behind (a 600-second
+    process-group timeout is not how a dead rank should show up on the first 8-GPU run)."""
+    import time
+    from libgoldilocks_amd import shard
+    t0 = time.time()
+    code = shard.launch_ranks(["-c", "import os, sys, time\n"
+                               "if os.environ['RANK'] == '1': sys.exit(3)\n"
+                               "time.sleep(60)"], 2)
+    assert code == 3 and time.time() - t0 < 5.0
+
+
+def test_the_launch_deadline_is_a_default():
+    import inspect
+    import time
+    from libgoldilocks_amd import shard
+    assert inspect.signature(shard.launch_ranks).parameters["timeout"].default == shard.LAUNCH_TIMEOUT_S
+    t0 = time.time()
+    assert shard.launch_ranks(["-c", "import time; time.sleep(60)"], 2, timeout=1.0) == 124
+    assert time.time() - t0 < 5.0

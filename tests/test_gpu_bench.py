@@ -29,8 +29,9 @@ def test_two_ranks_self_launched_variable_base():
     assert line["n_gpus"] == 2 and line["steps"] == 2 and line["scaling"] == "weak"
     assert line["config"]["parity_spot_check"] == "ok"
     assert [g["rank"] for g in line["per_gpu"]] == [0, 1] and all(g["value"] > 0 for g in line["per_gpu"])
-    assert line["value"] > 0 and line["roofline"]["kernel"] == "k_point_scalarmul"
-    assert "configs" not in line and "cpu_baseline" not in line          # N = 1 only
+    assert line["value"] > 0 and line["roofline"]["kernel"] == "k_point_scalarmul_ct"   # the library's default mode
+    assert line["config"]["table_access"] == "index-independent" and line["config"]["table_access_is_library_default"]
+    assert "configs" not in line and "cpu_baseline" not in line and "end_to_end" not in line   # N = 1 only
     launcher = [json.loads(l) for l in err.splitlines() if l.startswith('{"launcher"')]
     assert launcher and launcher[0]["launcher"]["torch_imported_by_launcher"] is False
 
@@ -43,16 +44,27 @@ def test_config5_invocation_strong_slices_verify():
     assert line["config"]["parity_spot_check"] == "ok"
 
 
-def test_default_line_carries_configs_and_cpu_baseline():
-    """The driver's N = 1 invocation at a reduced batch: headline + configs 3, 3', 4 and the
-    index-independent variable-base mode + the CPU baseline with its single-thread figure."""
+def test_default_line_carries_configs_end_to_end_and_cpu_baseline():
+    """The driver's N = 1 invocation at a reduced batch: the headline in the library's default
+    (index-independent) mode + configs 3, 3', 4 and the opt-in fast tables, every config's first lanes
+    re-computed by the oracle + the host-array (PCIe-inclusive) rates + the CPU baseline of both reference builds."""
     line, _ = _run(["--steps", "2", "--warmup", "1", "--log2-batch", "15"])
     assert line["n_gpus"] == 1 and line["config"]["parity_spot_check"] == "ok"
-    assert set(line["configs"]) == {"fixed", "base", "verify", "varbase_index_independent"}
+    assert line["roofline"]["kernel"] == "k_point_scalarmul_ct" and line["config"]["table_access"] == "index-independent"
+    assert "oracle's goldilocks_448_point_scalarmul" in line["config"]["check"]
+    assert set(line["configs"]) == {"fixed", "base", "verify", "varbase_fast", "base_fast"}
     for c in line["configs"].values():
         assert c["parity_spot_check"] == "ok" and c["value"] > 0 and c["kernel_ms_avg"] > 0
-    assert line["configs"]["varbase_index_independent"]["kernel"] == "k_point_scalarmul_ct"
+        assert "equal the oracle's" in c["check"]                        # not a self-comparison
+    assert "rejects among them" in line["configs"]["verify"]["check"]
+    assert line["configs"]["varbase_fast"]["kernel"] == "k_point_scalarmul"
+    assert line["configs"]["base"]["kernel"] == "k_base_scalarmul_ct" and line["configs"]["base_fast"]["kernel"] == "k_base_scalarmul"
+    assert set(line["end_to_end"]) == {"varbase", "fixed", "verify"}
+    for e in line["end_to_end"].values():
+        assert e["value"] > 0 and e["host_memory"] == "pageable"
+    assert line["end_to_end"]["varbase"]["value"] < line["value"]        # PCIe-inclusive: never the headline
     cb = line["cpu_baseline"]
+    assert set(cb["single_thread_by_build"]) <= {"x86_64_generic", "x86_64_v3", "oracle_port"} and cb["build"] in cb["single_thread_by_build"]
     assert cb["cores"] >= 1 and cb["single_thread"]["us_per_op"] > 0
     # the stated core count is consistent with the speed-up over one thread (within 2x)
     ratio = cb["value"] / cb["single_thread"]["value"]
@@ -62,7 +74,7 @@ def test_default_line_carries_configs_and_cpu_baseline():
 def test_control_plane_over_rccl_on_one_gpu():
     """The barrier / MAX / all-gather path over RCCL ("nccl"), as the ranks of a real multi-GPU run use it:
     a one-rank group on this box's GPU."""
-    line, _ = _run(["--steps", "2", "--warmup", "1", "--log2-batch", "14", "--no-cpu-baseline", "--no-configs"],
-                   GOLDILOCKS_BENCH_FORCE_DIST="1")
+    line, _ = _run(["--steps", "2", "--warmup", "1", "--log2-batch", "14", "--no-cpu-baseline", "--no-configs",
+                    "--no-end-to-end"], GOLDILOCKS_BENCH_FORCE_DIST="1")
     assert line["config"]["control_plane"] == "nccl" and line["n_gpus"] == 1
     assert line["config"]["parity_spot_check"] == "ok"

@@ -382,3 +382,41 @@ def test_batch_output_may_alias_the_base_array(ga, O):
     small = bases[:100].copy()                                     # 100 operations: the one-operation-per-wave path
     assert ga.lib().goldilocks_448_point_scalarmul_batch(small.ctypes.data, small.ctypes.data, s.ctypes.data, 100) == 0
     assert (enc(small) == enc(want[:100])).all()
+
+
+@pytest.mark.parametrize("log2n", [20, 21])
+def test_config5_share_of_one_gpu_in_one_launch(ga, O, log2n):
+    """BASELINE config 5 at its real per-GPU size: 2^21 verifications (2^24 over 8 GPUs) in ONE
+    goldilocks_amd_ed448_verify_dev launch, a tenth of them corrupted -- and 2^20, the launch bench.py times
+    (config 4).  The accept / reject set must be exact in every lane (reference: src/eddsa.c:253-306, early
+    returns and all), and 256 lanes spread over the batch, rejects among them, are re-verified by the oracle."""
+    import torch
+    n, nk = 1 << log2n, 1024
+    sk = np.frombuffer(_gen.stream(b"c5/sk", 57 * nk), np.uint8).reshape(nk, 57)
+    sk_d = torch.from_numpy(np.ascontiguousarray(sk[np.arange(n) % nk])).cuda()
+    msg = torch.from_numpy(np.frombuffer(_gen.stream(b"c5/msg", 32 * 4096), np.uint8).reshape(4096, 32)[np.arange(n) % 4096].copy()).cuda()
+    idx = torch.arange(n, device="cuda")
+    for b in range(3):                                     # every message distinct
+        msg[:, b] = ((idx >> (8 * b)) & 0xff).to(torch.uint8)
+    pk = torch.empty((n, 57), dtype=torch.uint8, device="cuda")
+    sig = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
+    st = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    ga.dev("ed448_derive_public_key", pk.data_ptr(), sk_d.data_ptr(), n, None)
+    ga.dev("ed448_sign", sig.data_ptr(), sk_d.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0, None, 0, n, None)
+    bad = (idx % 10) == 3
+    # corrupt S, R, the key or the message, by turns
+    kind = (idx // 10) % 4
+    sig[bad & (kind == 0), 60] ^= 1
+    sig[bad & (kind == 1), 5] ^= 0x20
+    pk[bad & (kind == 2), 9] ^= 4
+    msg[bad & (kind == 3), 31] ^= 0x80
+    ga.dev("ed448_verify", st.data_ptr(), sig.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0, None, 0, n, None)
+    torch.cuda.synchronize()
+    assert bool(((st == -1) | (st == 0)).all())
+    assert bool(((st == -1) == ~bad).all())
+    rng = np.random.default_rng(log2n)
+    pick = np.unique(np.concatenate([rng.integers(0, n, 200), 10 * rng.integers(0, n // 10, 56) + 3]))   # 56 corrupted lanes for sure
+    pick_d = torch.from_numpy(pick).cuda()
+    want = _gen.oracle_verify(O, sig[pick_d].cpu().numpy(), pk[pick_d].cpu().numpy(),
+                              [m.tobytes() for m in msg[pick_d].cpu().numpy()])
+    assert (st[pick_d].cpu().numpy() == want).all() and (want == 0).sum() >= 50

@@ -17,7 +17,7 @@ for name, lib in libs.items():
     if names and name not in names:
         continue
     env = dict(os.environ, GOLDILOCKS_AMD_LIB=lib)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-configs"] + args,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--no-configs", "--no-end-to-end"] + args,
                        env=env, capture_output=True, text=True)
     try:
         line = json.loads(r.stdout.strip().splitlines()[-1])
