@@ -258,194 +258,6 @@ GD_FN void load_bytes_as_words(uint32_t *w, const uint8_t *p, int nbytes, int nw
     }
 }
 
-// FB: fixed-base multiplier for the base point (FixedComb / FixedBwt).  AT: this lane's window
-// table, filled here.  STAGE: sponge block; `mkbits(sc, slot)` turns a recoded scalar into a BITS
-// reader (LDS-backed on the device).  The two halves S*B and (-h)*A are computed separately --
-// signed-window ladder for one, fixed-base table for the other, accumulated onto the ladder's result:
-// fewer field multiplications than interleaving them on one doubling chain, and no lane divergence.
-//
-// The phases are ordered so that their live state does not overlap (one lane has 256 registers):
-//   decode A -> A's window table (A itself is dead afterwards)
-//   decode R -> its X and Y wait in the table's build slot, free once the table is built
-//   challenge hash (the Keccak state is the only large live object)
-//   ladder -h*A, then the base-point additions onto the same accumulator
-//   compare with R read back.
-template <class FB, class AT, class STAGE, class MKBITS>
-GD_FN bool ed448_verify_core(const Ed448Msg &m, const FB &fb, AT &a_tab, STAGE &stage, MKBITS &mkbits) {
-    constexpr int PARK = window_plan<5>::ENTRIES;
-    uint32_t w[29];
-    bool ok;
-    {
-        pt A;
-        load_bytes_as_words(w, m.b, 57, 15);          // public key
-        ok = pt_decode_eddsa_words(A, w);
-        build_window_table(a_tab, A);
-    }
-    {
-        pt R;
-        load_bytes_as_words(w, m.a, 57, 15);          // R = sig[0:57]
-        ok = pt_decode_eddsa_words(R, w) && ok;       // (both decoded: lanes stay uniform)
-        pniels park;
-        park.a = R.x;
-        park.b = R.y;
-        park.cn = fe_zero();
-        park.z = fe_zero();
-        a_tab.store(PARK, park);
-    }
-    shake256_114(w, m, m.total(), stage);
-    sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));   // -h mod q
-    load_bytes_as_words(w, m.a + 57, 57, 15);     // S = sig[57:114]
-    sc response = sc_decode_long_words<57>(w);                        // S mod q, no range check
-
-    auto bits_c = mkbits(sc_recode_signed(challenge), 1);
-    pt P = ladder_varbase(bits_c, a_tab);                             // -h*A, T included
-    fb.add_to(P, response, mkbits);                                   // + S*B
-    const pniels r = a_tab.load(PARK);
-    return ok && fe_eq(fe_mul(P.y, r.a), fe_mul(r.b, P.x));          // P == R up to 2-torsion (src/goldilocks.c:644-653)
-}
-
-// ------------------------------------------------------------------ verification, one exponentiation per signature
-// ed448_verify_core above spends two 446-squaring exponentiations per signature: the inverse square
-// roots that decode A and R.  R does not have to be decoded.  With u = 1 - y^2, v = 1 - d y^2 (so that
-// x_R^2 = u / v) and P = S*B - h*A = (X_P : Y_P : ..), the reference's test "P == isogeny(R) up to
-// 2-torsion", X_P Y' == Y_P X' (src/goldilocks.c:644-653 after :949-1004), multiplied through by v^2 reads
-//       L == K * x_R,     L = X_P (y^2 v - u)(u + y^2 v),     K = 2 Y_P (2 v - u - y^2 v) v y.
-// So (K != 0, u v != 0):  L^2 v == K^2 u  says that L / K is a square root of u / v (if u / v has none the
-// reference rejects R, and the equation cannot hold); and then x_R == L / K iff the low bit of L / K is
-// R's sign bit, because the decoder picks the root with that low bit.  The one division left, 1 / K,
-// is shared with the NEXT signature the lane handles: its key decoding needs isr(n_A), and
-//       t = isr(n_A K^2):   1/sqrt(n_A) = +- t K,    1 / K = legendre(n_A) * t^2 n_A K
-// (for a non-square m, isr(m)^2 m = -1).  A lane therefore carries one pending quotient from each
-// verification into the next one's first exponentiation, and pays one plain inversion for the last
-// signature it handles.  u v == 0 is the reference's isr(0) failure; K == 0 (y = 0, Y_P = 0 or
-// 2 - x^2 - y^2 = 0) and n_A == 0 take the two-exponentiation path of ed448_verify_core.
-struct VerifyPending {
-    fe K, L;          // R's x-coordinate is L / K
-    bool live;        // a sign test is waiting for 1 / K
-    bool sign;        // R's sign bit
-    bool ok;          // everything else about that signature held
-    uint32_t index;   // where its verdict goes
-};
-GD_FN void verify_pending_clear(VerifyPending &p) {
-    p.K = fe_one();
-    p.L = fe_zero();
-    p.live = false;
-    p.sign = false;
-    p.ok = false;
-    p.index = 0;
-}
-// the pending signature's verdict, given 1 / K
-GD_FN bool verify_pending_verdict(const VerifyPending &p, const fe &inv_k) {
-    return p.ok && (fe_lobit(fe_mul(p.L, inv_k)) == p.sign);
-}
-// Verify signature `index` (message string m); *done_index / *done_ok report the verdict that became
-// final during this call: the previous pending one (merged exponentiation) or this one (slow path), if any.
-// Returns how many verdicts were produced (0, 1 or 2: at most the previous one and, on the slow path, this one).
-template <class FB, class AT, class STAGE, class MKBITS>
-GD_FN int ed448_verify_chained(const Ed448Msg &m, uint32_t index, VerifyPending &pend, const FB &fb, AT &a_tab,
-                               STAGE &stage, MKBITS &mkbits, uint32_t done_index[2], bool done_ok[2]) {
-    constexpr int PARK = window_plan<5>::ENTRIES;
-    int ndone = 0;
-    uint32_t w[29];
-    bool ok;
-    {   // ---- the key: decoding shares its exponentiation with the pending quotient
-        load_bytes_as_words(w, m.b, 57, 15);
-        const uint32_t last = w[14] & 0xff;
-        const bool low = (last & 0x80) != 0;
-        ok = (last & 0x7f) == 0;
-        fe y;
-        ok = fe_deserialize_words(y, w) && ok;
-        const fe y2 = fe_sqr(y);
-        const fe num = fe_weak(fe_sub<2>(fe_one(), y2));                           // 1 - y^2
-        const fe den = fe_weak(fe_add(fe_one(), fe_mulw(y2, NEG_EDWARDS_D)));      // 1 - d y^2
-        const fe n_a = fe_mul(num, den);
-        const bool zero_a = fe_is_zero(n_a);
-        const fe n_ap = fe_select(n_a, fe_one(), zero_a);
-        const fe kp = fe_select(fe_one(), pend.K, pend.live);
-        bool sq;
-        const fe t = fe_isr(fe_mul(n_ap, fe_sqr(kp)), &sq);                        // the ONE exponentiation
-        ok = ok && sq && !zero_a;
-        if (pend.live) {
-            fe inv_k = fe_mul(fe_mul(fe_sqr(t), n_ap), kp);                        // +- 1 / K
-            inv_k = fe_weak(fe_cond_neg(inv_k, !sq));                              // legendre(n_A) = -1: the other sign
-            done_index[ndone] = pend.index;
-            done_ok[ndone] = verify_pending_verdict(pend, inv_k);
-            ndone++;
-            pend.live = false;
-        }
-        fe x = fe_mul(fe_mul(t, kp), num);
-        x = fe_weak(fe_cond_neg(x, fe_lobit(x) != low));
-        // isogeny: like doubling with Z = 1 but E = 2 - D
-        pt A;
-        const fe c = fe_sqr(x);
-        const fe d = fe_add(c, y2);
-        const fe b = fe_weak(fe_sub<4>(fe_sqr(fe_add(x, y)), d));
-        const fe tt = fe_weak(fe_sub<2>(y2, c));
-        const fe e = fe_weak(fe_sub<4>(fe_small(2), d));
-        A.x = fe_mul(e, b);
-        A.z = fe_mul(tt, e);
-        A.y = fe_mul(d, tt);
-        A.t = fe_mul(d, b);
-        build_window_table(a_tab, A);
-    }
-    bool sign_r;
-    {   // ---- R: only what the equation needs; y, u, v wait in the table's build slot
-        load_bytes_as_words(w, m.a, 57, 15);
-        const uint32_t last = w[14] & 0xff;
-        sign_r = (last & 0x80) != 0;
-        ok = ok && (last & 0x7f) == 0;
-        fe y;
-        ok = fe_deserialize_words(y, w) && ok;
-        const fe y2 = fe_sqr(y);
-        pniels park;
-        park.a = y;
-        park.b = fe_weak(fe_sub<2>(fe_one(), y2));                                 // u
-        park.cn = fe_weak(fe_add(fe_one(), fe_mulw(y2, NEG_EDWARDS_D)));           // v
-        park.z = y2;
-        ok = ok && !fe_is_zero(park.b) && !fe_is_zero(park.cn);                    // the reference's isr(0) failure
-        a_tab.store(PARK, park);
-    }
-    shake256_114(w, m, m.total(), stage);
-    const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));          // -h mod q
-    load_bytes_as_words(w, m.a + 57, 57, 15);
-    const sc response = sc_decode_long_words<57>(w);                               // S mod q, no range check
-    auto bits_c = mkbits(sc_recode_signed(challenge), 1);
-    pt P = ladder_varbase(bits_c, a_tab);                                          // -h*A, T included
-    fb.add_to(P, response, mkbits);                                                // + S*B
-    const pniels r = a_tab.load(PARK);                                             // (y, u, v, y^2)
-    const fe w1 = fe_mul(r.z, r.cn);                                               // y^2 v
-    const fe lf = fe_mul(fe_weak(fe_sub<2>(w1, r.b)), fe_add(r.b, w1));            // (y^2 v - u)(u + y^2 v)
-    const fe L = fe_mul(P.x, lf);
-    const fe ef = fe_weak(fe_sub<4>(fe_add(r.cn, r.cn), fe_add(r.b, w1)));         // 2 v - u - y^2 v
-    fe K = fe_mul(P.y, fe_mul(fe_mul(ef, r.cn), r.a));
-    K = fe_weak(fe_add(K, K));
-    const bool poly = fe_eq(fe_mul(fe_sqr(L), r.cn), fe_mul(fe_sqr(K), r.b));     // L^2 v == K^2 u
-    if (fe_is_zero(K)) {
-        // rare (y = 0, Y_P = 0, 2 - x^2 - y^2 = 0): decode R after all and compare points, as ed448_verify_core does
-        pt R;
-        load_bytes_as_words(w, m.a, 57, 15);
-        const bool okr = pt_decode_eddsa_words(R, w);
-        done_index[ndone] = index;
-        done_ok[ndone] = ok && okr && pt_eq(P, R);
-        ndone++;
-    } else {
-        pend.K = K;
-        pend.L = L;
-        pend.live = true;
-        pend.sign = sign_r;
-        pend.ok = ok && poly;
-        pend.index = index;
-    }
-    return ndone;
-}
-// the last signature of a lane: a plain inversion
-GD_FN bool ed448_verify_chain_flush(VerifyPending &pend, uint32_t &done_index) {
-    done_index = pend.index;
-    const bool v = verify_pending_verdict(pend, fe_invert(pend.K));
-    pend.live = false;
-    return v;
-}
-
 // ------------------------------------------------------------------ verification with half-size scalars
 // (lattice.hpp)  Accept iff  V = (|tau| S)*B + rho*PA + |tau|*PR  is the identity (V.x == 0: all of this
 // happens in the subgroup of prime order q), with (rho, tau) the short pair of the challenge,
@@ -469,14 +281,7 @@ GD_FN LatticePair ed448_verify_lattice_pair(const Ed448Msg &m, STAGE &stage) {
     const sc response = sc_decode_long_words<57>(w);                          // S mod q, no range check
     wide15 rho;
     int8w tau;
-#if defined(GD_LATTICE_FAKE)   // timing experiment only: a pair of the right size without the reduction (wrong verdicts)
-#pragma unroll
-    for (int i = 0; i < 15; i++) rho.w[i] = i < 6 ? h.w[i] : 0u;
-#pragma unroll
-    for (int i = 0; i < 8; i++) tau.w[i] = i < 6 ? h.w[i + 7] | 1u : 0u;
-#else
     half_size_pair(rho, tau, h);
-#endif
     pr.tau_pos = !is_negative(tau);
     const sc tau_mag = magnitude_as_scalar(tau);
     pr.ts = sc_mul(tau_mag, response);
@@ -670,14 +475,6 @@ struct HostMkBits {
         return b;
     }
 };
-template <class FB, class AT>
-static inline bool ed448_verify_lane(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen,
-                                     uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const FB &bt, AT &at) {
-    Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
-    HostStage stage;
-    HostMkBits mk;
-    return ed448_verify_core(m, bt, at, stage, mk);
-}
 #endif
 
 }  // namespace gd

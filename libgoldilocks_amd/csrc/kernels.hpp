@@ -25,13 +25,6 @@
 
 namespace gd {
 
-#ifndef GD_SCAN_UNROLL
-#define GD_SCAN_UNROLL 1            // entries of an index-independent scan in flight together (ScanTable)
-#endif
-constexpr int SCAN_UNROLL = GD_SCAN_UNROLL;
-#ifndef GD_SCAN_PIPELINED
-#define GD_SCAN_PIPELINED 0
-#endif
 constexpr int BLOCK = 256;          // 4 waves: one per SIMD
 #ifndef GD_WAVES_PER_SIMD
 #define GD_WAVES_PER_SIMD 2
@@ -196,71 +189,12 @@ __device__ __forceinline__ pniels pniels_load(const uint4 *q) {
     e.z = fe_load(q + 12);
     return e;
 }
-#ifndef GD_FAST_PACKED
-#define GD_FAST_PACKED 0   // experiment: 224-byte bit-packed entries in the digit-addressed table (profiles/r02/experiments.md)
-#endif
 struct LaneTable {  // this lane's window table in the HBM workspace, lane-contiguous; the digit picks the address
     static constexpr bool direct = true;   // lookup = one entry's loads (a two-table ladder may issue both entries' at once)
     uint4 *p;
-#if GD_FAST_PACKED
-    __device__ __forceinline__ void store(int k, const pniels &e) const {
-        uint32_t w[56];
-        fe_serialize_words(w, e.a);
-        fe_serialize_words(w + 14, e.b);
-        fe_serialize_words(w + 28, e.cn);
-        fe_serialize_words(w + 42, e.z);
-        uint4 *q = p + 14 * k;
-#pragma unroll
-        for (int r = 0; r < 14; r++) q[r] = make_uint4(w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]);
-    }
-    __device__ __forceinline__ pniels load(uint32_t k) const {
-        const uint4 *q = p + 14 * k;
-        uint32_t w[56];
-#pragma unroll
-        for (int r = 0; r < 14; r++) {
-            const uint4 v = q[r];
-            w[4 * r] = v.x; w[4 * r + 1] = v.y; w[4 * r + 2] = v.z; w[4 * r + 3] = v.w;
-        }
-        pniels e;
-        e.a = fe_unpack_words(w);
-        e.b = fe_unpack_words(w + 14);
-        e.cn = fe_unpack_words(w + 28);
-        e.z = fe_unpack_words(w + 42);
-        return e;
-    }
-#else
-    __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
-    __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
-#endif
-    __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
-    __device__ __forceinline__ void prefetch(uint32_t) const {}
-    __device__ __forceinline__ pniels fetch(uint32_t idx) const { return load(idx); }
-};
-// Experiment (GD_LDS_PREFETCH, profiles/r02/experiments.md): the digit's entry is DMA'd into LDS
-// (global_load_lds_dwordx4, no registers held) before the window's doublings and read back with
-// ds_read_b128 for the addition, so its HBM latency hides behind the doublings.
-struct LaneTableLdsPrefetch {
-    static constexpr bool direct = true;
-    uint4 *p;     // this lane's table
-    uint4 *lds;   // the WAVE's 16-KiB staging region (16 rows x 64 lanes x 16 B)
     __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
-    __device__ __forceinline__ void prefetch(uint32_t idx) const {
-        const uint4 *src = p + 16 * idx;
-#pragma unroll
-        for (int r = 0; r < 16; r++) __builtin_amdgcn_global_load_lds(src + r, lds + r * 64, 16, 0, 0);
-    }
-    __device__ __forceinline__ pniels fetch(uint32_t) const {
-        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the DMA has landed
-        const uint4 *q = lds + (threadIdx.x & 63u);
-        pniels e;
-        e.a = fe_from_u4(q[0 * 64], q[1 * 64], q[2 * 64], q[3 * 64]);
-        e.b = fe_from_u4(q[4 * 64], q[5 * 64], q[6 * 64], q[7 * 64]);
-        e.cn = fe_from_u4(q[8 * 64], q[9 * 64], q[10 * 64], q[11 * 64]);
-        e.z = fe_from_u4(q[12 * 64], q[13 * 64], q[14 * 64], q[15 * 64]);
-        return e;
-    }
 };
 // The index-independent window table: the counterpart of the reference's constant_time_lookup
 // (src/include/constant_time.h:134-183, used at src/goldilocks.c:440): every lookup reads EVERY entry
@@ -323,37 +257,15 @@ struct ScanTable {
     }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const {
         uint4 r[SCAN_ROWS];
-#if GD_SCAN_PIPELINED
-        // two candidates in flight: the loads of entry k+1 are issued before entry k is looked at, and
-        // the scheduler may not move anything across the stage boundaries (it would hoist every load to
-        // the top and spill); the compiler's own counted vmcnt waits then do the rest
-        uint4 a[SCAN_ROWS], b[SCAN_ROWS];
         load_raw(r, 0);
-        load_raw(a, 1);
-#pragma unroll
-        for (int k = 1; k < ENTRIES; k += 2) {
-            if (k + 1 < ENTRIES) load_raw(b, k + 1);
-            __builtin_amdgcn_sched_barrier(0);
-            keep(r, a, idx == (uint32_t)k);
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 2 < ENTRIES) load_raw(a, k + 2);
-            __builtin_amdgcn_sched_barrier(0);
-            if (k + 1 < ENTRIES) keep(r, b, idx == (uint32_t)(k + 1));
-            __builtin_amdgcn_sched_barrier(0);
-        }
-#else
-        load_raw(r, 0);
-#pragma unroll SCAN_UNROLL
-        for (int k = 1; k < ENTRIES; k++) {
+#pragma unroll 1
+        for (int k = 1; k < ENTRIES; k++) {   // one candidate in flight: two at a time spill (profiles/r02/experiments.md B)
             uint4 w[SCAN_ROWS];
             load_raw(w, k);
             keep(r, w, idx == (uint32_t)k);
         }
-#endif
         return from_raw(r);
     }
-    __device__ __forceinline__ void prefetch(uint32_t) const {}
-    __device__ __forceinline__ pniels fetch(uint32_t idx) const { return lookup(idx); }
 };
 // uint4 per WAVE of a scan table: (ENTRIES + 1 build slot) x SCAN_ROWS uint4 x 64 lanes
 template <int ENTRIES>

@@ -6,7 +6,7 @@ namespace gd {
 
 GD_KERNEL k_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar, uint32_t n,
                             uint4 *__restrict__ workspace) {
-    point_scalarmul_body<false>(out, base, scalar, n, workspace);
+    point_scalarmul_body(out, base, scalar, n, workspace);
 }
 
 GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,

@@ -1,13 +1,6 @@
 // kernels_verify.hip -- kernel definitions (see kernels.hpp for the memory plan and policies).
 #include "varbase_bodies.hpp"
 
-// 1: half-size scalars, A and R in one ladder of 45 windows (ed448_verify_lattice; the default).
-// 0: the full-length ladder with one exponentiation per signature (ed448_verify_chained): 13 % slower,
-//    kept as the measured alternative (profiles/r02/experiments.md).
-#ifndef GD_VERIFY_LATTICE
-#define GD_VERIFY_LATTICE 1
-#endif
-
 namespace gd {
 
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i]; b1 == nullptr: b1 is the base point (its 16-bit window table)
@@ -46,7 +39,6 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
     FixedBwt<GlobalBwt> b_tab{bwt_tab};
     LdsStage stage{s_stage + threadIdx.x};
     LdsMkBits mk{s_bits + threadIdx.x};
-#if GD_VERIFY_LATTICE
     // Half-size scalars (lattice.hpp): A and R share one ladder of 45 windows; two tables per lane.
     LaneTable a_tab = VarTable<false>::at(workspace, 0, 2), r_tab = VarTable<false>::at(workspace, 1, 2);
     for (uint32_t i = lane; i < n; i += stride) {
@@ -58,31 +50,6 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
         const bool ok = ed448_verify_lattice(m, b_tab, a_tab, r_tab, stage, mk);
         status[i] = ok && fits ? -1 : 0;
     }
-#else
-    LaneTable a_tab{workspace + (size_t)lane * TABLE_U4};
-    // One exponentiation per signature: each verification hands a pending quotient to the next one this
-    // lane handles (ed448_verify_chained, eddsa.hpp).
-    VerifyPending pend;
-    verify_pending_clear(pend);
-    for (uint32_t i = lane; i < n; i += stride) {
-        const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
-        const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
-        const bool fits = len64 < MAX_MESSAGE_BYTES;   // longer than the 32-bit byte counters hold: the lane fails
-        const uint32_t mlen = fits ? (uint32_t)len64 : 0u;
-        Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg, mlen, prehashed, ctx,
-                                            ctx_len);
-        uint32_t done_index[2];
-        bool done_ok[2];
-        const int nd = ed448_verify_chained(m, i, pend, b_tab, a_tab, stage, mk, done_index, done_ok);
-        if (!fits) pend.ok = false;
-        for (int k = 0; k < nd; k++) status[done_index[k]] = done_ok[k] && (done_index[k] != i || fits) ? -1 : 0;
-    }
-    if (pend.live) {
-        uint32_t idx;
-        const bool v = ed448_verify_chain_flush(pend, idx);
-        status[idx] = v ? -1 : 0;
-    }
-#endif
 }
 
 }  // namespace gd

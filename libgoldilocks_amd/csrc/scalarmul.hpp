@@ -88,12 +88,11 @@ GD_FN pt ladder_varbase_w(const BITS &bits, const TABLE &table) {
 #pragma unroll 1
     for (int pos = window_plan<W>::TOP - W; pos >= 0; pos -= W) {
         signed_digit_w<W>(window_w<W>(bits, pos), idx, neg);
-        table.prefetch(idx);   // a policy may start fetching the entry now (the digit is known); most do nothing
 #pragma unroll 1
         for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
         // all of the entry's loads are issued together, behind the doublings (read field by field, each
         // right before its product, the same kernel measures 0.8 % slower: profiles/r02/experiments.md)
-        pniels e = table.fetch(idx);
+        pniels e = table.lookup(idx);
         // T is only needed by a following addition, i.e. never after the last window's
         // add -- except that the caller wants a complete extended point at pos == 0.
         pt_add_pniels(acc, e, neg, pos == 0);
@@ -285,9 +284,6 @@ template <class BITS, class TABLE1, class TABLE2>
 GD_FN pt ladder_double(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2) {
     return ladder_double_w<5>(bits1, t1, bits2, t2);
 }
-#ifndef GD_LATTICE_PREFETCH
-#define GD_LATTICE_PREFETCH 1
-#endif
 // The same with `nw` 5-bit windows instead of 90 (nw must be the same in every lane of a wave): for the
 // half-size scalars of verification (lattice.hpp).  bits: words of (s + 2^(5 nw) - 1) / 2 for odd INTEGER s.
 template <class BITS, class TABLE1, class TABLE2>
@@ -302,7 +298,7 @@ GD_FN pt ladder_double_var(const BITS &bits1, const TABLE1 &t1, const BITS &bits
     for (int pos = 5 * (nw - 2); pos >= 0; pos -= 5) {
 #pragma unroll 1
         for (int j = 0; j < 5; j++) pt_double(acc, j == 4);
-#if GD_LATTICE_PREFETCH   // both entries' loads are issued before the first addition (1 % faster than one at a time)
+        // both entries' loads are issued before the first addition (1 % faster than one at a time)
         uint32_t idx2;
         bool neg2;
         signed_digit(window5(bits1, pos), idx, neg);
@@ -311,12 +307,6 @@ GD_FN pt ladder_double_var(const BITS &bits1, const TABLE1 &t1, const BITS &bits
         const pniels e2 = t2.lookup(idx2);
         pt_add_pniels(acc, e1, neg, true);
         pt_add_pniels(acc, e2, neg2, true);
-#else
-        signed_digit(window5(bits1, pos), idx, neg);
-        pt_add_pniels(acc, t1.lookup(idx), neg, true);
-        signed_digit(window5(bits2, pos), idx, neg);
-        pt_add_pniels(acc, t2.lookup(idx), neg, true);
-#endif
     }
     return acc;
 }

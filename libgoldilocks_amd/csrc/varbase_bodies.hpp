@@ -10,25 +10,6 @@
 #include "fixed_bodies.hpp"
 #include "montgomery.hpp"
 
-#ifndef GD_LDS_PREFETCH
-#define GD_LDS_PREFETCH 0
-#endif
-// The two waves that share a SIMD run the same program and would reach their table scans -- the
-// phases in which a wave waits on memory -- together, leaving the SIMD idle; the wave in the odd
-// hardware slot therefore starts GD_CT_STAGGER x 8128 cycles late, about half a window, so that one
-// wave scans while the other computes (MI355X_MICROARCH.md, "Two waves per SIMD", item 9).
-#ifndef GD_CT_STAGGER
-#define GD_CT_STAGGER 0
-#endif
-namespace gd {
-__device__ __forceinline__ void stagger_odd_wave_slot(int units) {
-    // HW_REG_HW_ID (4), bits [3:0]: the wave's slot on its SIMD
-    const uint32_t slot = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
-    if (slot & 1u)
-        for (int i = 0; i < units; i++) __builtin_amdgcn_s_sleep(127);
-}
-}  // namespace gd
-
 namespace gd {
 
 template <bool CT>
@@ -60,37 +41,22 @@ struct VarTable<true> {
 template <bool CT>
 constexpr int var_table_lane_u4() { return CT ? scan_table_wave_u4<VarTable<true>::ENTRIES>() / 64 : TABLE_U4; }
 
-template <bool CT>
-__device__ __forceinline__ auto headline_table(uint4 *workspace, uint4 *stage) {
-    if constexpr (!CT && GD_LDS_PREFETCH) {
-        return LaneTableLdsPrefetch{VarTable<false>::at(workspace, 0, 1).p, stage};
-    } else {
-        (void)stage;
-        return VarTable<CT>::at(workspace, 0, 1);
-    }
-}
-
-// config 2: scaled[i] = scalar[i] * base[i]   (ref: goldilocks_448_point_scalarmul)
-// out may alias base (the host-array path multiplies in place): no __restrict__ on that pair.
-template <bool CT>
+// config 2 with digit-addressed tables (public scalars): scaled[i] = scalar[i] * base[i]
+// (ref: goldilocks_448_point_scalarmul).  out may alias base (the host-array path multiplies in place): no
+// __restrict__ on that pair.
 __device__ __forceinline__ void point_scalarmul_body(uint64_t *out, const uint64_t *base,
                                                      const uint64_t *__restrict__ scalar, uint32_t n,
                                                      uint4 *__restrict__ workspace) {
+    constexpr bool CT = false;
     constexpr int W = VarTable<CT>::W;
     __shared__ uint32_t s_bits[15 * BLOCK];
-#if GD_LDS_PREFETCH
-    // the I/O staging buffer doubles as the entry-prefetch buffer (16 KiB per wave; never in use together)
-    constexpr int STAGE_U4 = CT ? WAVE_STAGE_U4 : 16 * 64;
-#else
     constexpr int STAGE_U4 = WAVE_STAGE_U4;
-#endif
     __shared__ uint4 s_stage[(BLOCK / 64) * STAGE_U4];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
     const uint32_t l = threadIdx.x & 63u;
     uint4 *stage = s_stage + (threadIdx.x >> 6) * STAGE_U4;
-    auto tab = headline_table<CT>(workspace, stage);
-    if (CT && GD_CT_STAGGER) stagger_odd_wave_slot(GD_CT_STAGGER);
+    auto tab = VarTable<CT>::at(workspace, 0, 1);
     // wave-uniform loop: the 64 lanes of a wave own 64 consecutive operations per round
     for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {
         const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
@@ -103,11 +69,6 @@ __device__ __forceinline__ void point_scalarmul_body(uint64_t *out, const uint64
             r = ladder_varbase_w<W>(bits, tab);
         }
         wave_store_points(stage, out, i0, m, l, r);
-    }
-    if (CT) {   // the scalar was secret: neither its recoding nor its staged copy stays in LDS
-        lds_wipe_lane(s_bits + threadIdx.x, 15);
-        wave_sync();
-        for (int k = 0; k < STAGE_U4 / 64; k++) stage[k * 64 + l] = make_uint4(0, 0, 0, 0);
     }
 }
 

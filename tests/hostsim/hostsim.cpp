@@ -34,8 +34,6 @@ struct HostTable {
     void store(int k, const pniels &p) { e[k] = p; }
     pniels load(uint32_t k) const { return e[k]; }
     pniels lookup(uint32_t k) const { return e[k]; }
-    void prefetch(uint32_t) const {}
-    pniels fetch(uint32_t k) const { return e[k]; }
 };
 struct HostComb {
     using plan = comb_ref;
@@ -58,6 +56,65 @@ void bytes_to_words(uint32_t *w, const uint8_t *in, int nbytes, int nwords) {
     for (int i = 0; i < nwords; i++) w[i] = 0;
     for (int i = 0; i < nbytes; i++) w[i / 4] |= (uint32_t)in[i] << (8 * (i % 4));
 }
+// ---- the plain verification, shaped like the reference's (src/eddsa.c:253-306): decode A, decode R, the
+// full-length ladder -h*A, + S*B, compare with R.  CHECKER ONLY: the device verifies with half-size scalars
+// (eddsa.hpp ed448_verify_lattice); this is what that is compared with on the host, besides the oracle.
+// FB: fixed-base multiplier for the base point (FixedComb / FixedBwt).  AT: this lane's window
+// table, filled here.  STAGE: sponge block; `mkbits(sc, slot)` turns a recoded scalar into a BITS
+// reader (LDS-backed on the device).  The two halves S*B and (-h)*A are computed separately --
+// signed-window ladder for one, fixed-base table for the other, accumulated onto the ladder's result:
+// fewer field multiplications than interleaving them on one doubling chain, and no lane divergence.
+//
+// The phases are ordered so that their live state does not overlap (one lane has 256 registers):
+//   decode A -> A's window table (A itself is dead afterwards)
+//   decode R -> its X and Y wait in the table's build slot, free once the table is built
+//   challenge hash (the Keccak state is the only large live object)
+//   ladder -h*A, then the base-point additions onto the same accumulator
+//   compare with R read back.
+template <class FB, class AT, class STAGE, class MKBITS>
+static inline bool ed448_verify_core(const Ed448Msg &m, const FB &fb, AT &a_tab, STAGE &stage, MKBITS &mkbits) {
+    constexpr int PARK = window_plan<5>::ENTRIES;
+    uint32_t w[29];
+    bool ok;
+    {
+        pt A;
+        load_bytes_as_words(w, m.b, 57, 15);          // public key
+        ok = pt_decode_eddsa_words(A, w);
+        build_window_table(a_tab, A);
+    }
+    {
+        pt R;
+        load_bytes_as_words(w, m.a, 57, 15);          // R = sig[0:57]
+        ok = pt_decode_eddsa_words(R, w) && ok;       // (both decoded: lanes stay uniform)
+        pniels park;
+        park.a = R.x;
+        park.b = R.y;
+        park.cn = fe_zero();
+        park.z = fe_zero();
+        a_tab.store(PARK, park);
+    }
+    shake256_114(w, m, m.total(), stage);
+    sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));   // -h mod q
+    load_bytes_as_words(w, m.a + 57, 57, 15);     // S = sig[57:114]
+    sc response = sc_decode_long_words<57>(w);                        // S mod q, no range check
+
+    auto bits_c = mkbits(sc_recode_signed(challenge), 1);
+    pt P = ladder_varbase(bits_c, a_tab);                             // -h*A, T included
+    fb.add_to(P, response, mkbits);                                   // + S*B
+    const pniels r = a_tab.load(PARK);
+    return ok && fe_eq(fe_mul(P.y, r.a), fe_mul(r.b, P.x));          // P == R up to 2-torsion (src/goldilocks.c:644-653)
+}
+
+
+template <class FB, class AT>
+static inline bool ed448_verify_lane(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen,
+                                     uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const FB &bt, AT &at) {
+    Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
+    HostStage stage;
+    HostMkBits mk;
+    return ed448_verify_core(m, bt, at, stage, mk);
+}
+
 }  // namespace
 
 extern "C" {
@@ -278,33 +335,6 @@ int hs_ed448_verify(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, s
     FixedComb<HostComb> fb{comb};
     HostTable ta;
     return ed448_verify_lane(sig, pk, msg, msglen, prehashed, ctx, ctxlen, fb, ta) ? -1 : 0;
-}
-
-// n signatures through the chained verification of one lane (one exponentiation per signature; the
-// last one flushed with a plain inversion): status[i] = -1 / 0.  Message i = msgs[msg_off[i] .. msg_off[i+1]).
-void hs_ed448_verify_chain(int32_t *status, const uint8_t *sig, const uint8_t *pk, const uint8_t *msgs, const uint64_t *msg_off,
-                           uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, size_t n, const uint64_t *comb_table) {
-    static HostComb comb;
-    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
-    FixedComb<HostComb> fb{comb};
-    HostTable ta;
-    HostStage stage;
-    HostMkBits mk;
-    VerifyPending pend;
-    verify_pending_clear(pend);
-    for (size_t i = 0; i < n; i++) {
-        Ed448Msg m = ed448_challenge_string(sig + 114 * i, pk + 57 * i, msgs + msg_off[i], (uint32_t)(msg_off[i + 1] - msg_off[i]),
-                                            prehashed, ctx, ctxlen);
-        uint32_t done_index[2];
-        bool done_ok[2];
-        const int nd = ed448_verify_chained(m, (uint32_t)i, pend, fb, ta, stage, mk, done_index, done_ok);
-        for (int k = 0; k < nd; k++) status[done_index[k]] = done_ok[k] ? -1 : 0;
-    }
-    if (pend.live) {
-        uint32_t idx;
-        const bool v = ed448_verify_chain_flush(pend, idx);
-        status[idx] = v ? -1 : 0;
-    }
 }
 
 // one verification with half-size scalars (lattice.hpp)

@@ -182,13 +182,18 @@ def test_mac_counts_match_bench(H, O):
     s = _gen.stream_scalars(1, b"mac-count")[0].copy()
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     names = ["fe_mul", "fe_sqr", "fe_mulw", "dbl", "dbl_t", "add_niels_t", "niels_to_pt", "isr", "decode_eddsa",
-             "pt_add", "pt_eq", "varbase5", "varbase4", "comb", "comb_big"]
+             "pt_add", "pt_eq", "varbase5", "varbase4", "comb", "comb_big", "ladder"]
     c = {name: H.hs_mac_count_of(i, p(base), p(s), p(comb)) for i, name in enumerate(names)}
     assert (c["fe_mul"], c["fe_sqr"], c["fe_mulw"]) == (192, 136, 16)
     assert c["dbl"] == 4 * 136 + 3 * 192 and c["dbl_t"] == c["dbl"] + 192
     W = bench.WORKLOADS
     assert W["varbase"]["macs"] == c["varbase5"] == 2175 * 192 + 1785 * 136 + 17 * 16
-    assert W["varbase"]["macs_index_independent"] == c["varbase4"]
+    # the library's default: the table-free Montgomery ladder (montgomery.hpp) -- count 15 holds its own inversion,
+    # the device shares one between the 8 operations a lane owns at batch 2^20 (chain: 3 more multiplications)
+    inv = c["isr"] + 2 * c["fe_sqr"] + c["fe_mul"]
+    assert (W["varbase"]["macs_ladder"], W["varbase"]["macs_inversion"]) == (c["ladder"] - inv, inv)
+    assert W["varbase"]["macs_index_independent"] == c["ladder"] - inv + 3 * c["fe_mul"] + inv // 8
+    assert c["ladder"] - inv == 446 * (5 * 192 + 4 * 136 + 16) + (16 * 192 + 2 * 136 + 5 * 16)   # steps + u(P), recovery and the map back
     assert W["fixed"]["macs_reference_comb"] == c["comb"] == c["niels_to_pt"] + 89 * c["add_niels_t"] - 17 * 192 + 17 * c["dbl_t"]
     assert W["fixed"]["macs"] == c["comb_big"]          # large batches: the caller's table re-combed to 4 x 7 x 16
     # the built-in base point with index-independent access: the library's 4 x 7 x 16 comb
@@ -209,22 +214,7 @@ def test_mac_counts_match_bench(H, O):
         per.append(H.hs_mac_counter_get())
     assert len(set(per)) == 1                                                                  # the same work for every signature
     assert W["verify"]["macs"] == per[0] - (c["comb"] + c["pt_add"]) + 28 * c["add_niels_t"]
-    assert W["verify"]["macs"] < 0.80 * 766_184                                               # the full-length ladder's figure
-    # the alternative, one exponentiation per signature (ed448_verify_chained): the steady-state cost of a lane's chain
-    sigs, pks, msgs = _gen.signatures(O, 9, msglen=32, seed=b"mac-count-sig", nkeys=3)
-    blob = np.frombuffer(b"".join(msgs), np.uint8).copy()
-    off = (np.arange(10) * 32).astype(np.uint64)
-    counts = {}
-    for n in (1, 9):
-        st = np.zeros(n, np.int32)
-        H.hs_mac_counter_reset()
-        H.hs_ed448_verify_chain(p(st), p(sigs), p(pks), p(blob), p(off), C.c_uint8(0), None, C.c_uint8(0), C.c_size_t(n), p(comb))
-        counts[n] = H.hs_mac_counter_get()
-        assert (st == -1).all()
-    steady = (counts[9] - counts[1]) // 8
-    assert (counts[9] - counts[1]) % 8 == 0
-    assert 766_184 == steady - (c["comb"] + c["pt_add"]) + 28 * c["add_niels_t"]
-    assert steady < 2 * c["decode_eddsa"] + c["varbase5"] + c["comb"] + c["pt_add"] + c["pt_eq"] - 55_000   # one isr gone
+    assert W["verify"]["macs"] < 0.80 * 766_184        # the full-length ladder with one exponentiation (round 2's alternative)
 
 
 def test_big_comb_of_the_base_point_matches_oracle(H, O):
@@ -261,63 +251,6 @@ def test_four_bit_window_ladder_matches_oracle(H, O):
         H.hs_point_scalarmul_w4(o2[i].ctypes.data_as(C.c_void_p), b2[i].ctypes.data_as(C.c_void_p),
                                 s2[i].ctypes.data_as(C.c_void_p))
     assert (_gen.oracle_encode(o2) == _gen.oracle_encode(_gen.oracle_varbase(O, b2, s2))).all()
-
-
-def test_chained_verification_one_exponentiation_per_signature(H, O):
-    """ed448_verify_chained (eddsa.hpp): R is never decoded -- L == K * x_R is tested as L^2 v == K^2 u plus a
-    sign test whose division 1/K rides on the NEXT signature's key decoding.  A lane's worth of signatures in
-    every order of valid / corrupted / degenerate cases (y_R = 0 and other K = 0 inputs take the slow path,
-    y = +-1 is the reference's isr(0) failure, n_A = 0 keys, encodings >= p, sign-bit flips, torsion-shifted
-    R from fixture F7) must get exactly the oracle's verdicts, which are the reference's."""
-    import json
-    tab = O.orc_precomputed_base()
-    rnd = random.Random(11)
-    n = 40
-    sigs, pks, msgs = _gen.signatures(O, n, msglen=32, seed=b"chain", nkeys=5)
-    msgs = np.frombuffer(b"".join(msgs), np.uint8).reshape(n, 32).copy()
-    P_ = 2**448 - 2**224 - 1
-    enc = lambda y, s=0: np.frombuffer(int(y).to_bytes(56, "little") + bytes([0x80 * s]), np.uint8)
-    special_r = [enc(0), enc(0, 1), enc(1), enc(P_ - 1), enc(P_), enc(2**448 - 1), enc(1, 1), enc(5), enc(5, 1)]
-    for i, r in enumerate(special_r):
-        sigs[2 + 3 * i, :57] = r                                     # degenerate / invalid R between valid neighbours
-    sigs[30, 56] ^= 0x80                                             # sign bit of R flipped: the deferred test must catch it
-    sigs[31, 56] |= 0x01                                             # garbage in byte 56
-    sigs[32, 60] ^= 1                                                # S corrupted
-    pks[33] = enc(1)                                                 # n_A = 0
-    pks[34] = enc(P_ - 1)                                            # n_A = 0
-    pks[35] = enc(0)                                                 # a key of order 4
-    pks[36, 56] ^= 0x80                                              # -A
-    msgs[37, 3] ^= 1
-    # torsion-malleable signatures and small-order points of fixture F7 (the real reference's verdicts), spliced in
-    f7 = [c for c in json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden",
-                                                 "f7_verify_torsion.json")))["cases"] if c["ctx"] == ""]
-    assert len(f7) >= 12
-    mlist = [m.tobytes() for m in msgs]
-    spliced = []
-    for j, c in enumerate(f7):
-        at = (3 + 7 * j) % n
-        if any(at == a_ for a_, _ in spliced) or at in (30, 31, 32, 33, 34, 35, 36, 37):
-            continue
-        sigs[at] = np.frombuffer(bytes.fromhex(c["sig"]), np.uint8)
-        pks[at] = np.frombuffer(bytes.fromhex(c["pk"]), np.uint8)
-        mlist[at] = bytes.fromhex(c["msg"])
-        spliced.append((at, c["verdict"]))
-    assert len(spliced) >= 10
-    want = _gen.oracle_verify(O, sigs, pks, mlist)
-    for at, verdict in spliced:
-        assert want[at] == verdict                                   # the oracle agrees with the reference's own verdicts
-    for order in (list(range(n)), list(range(n - 1, -1, -1)), rnd.sample(range(n), n)):
-        s_, p_ = (np.ascontiguousarray(a[order]) for a in (sigs, pks))
-        ml = [mlist[i] for i in order]
-        off = np.zeros(n + 1, dtype=np.uint64)
-        off[1:] = np.cumsum([len(x) for x in ml])
-        blob = np.frombuffer(b"".join(ml) + b"\0", np.uint8).copy()
-        got = np.full(n, 7, dtype=np.int32)
-        H.hs_ed448_verify_chain(got.ctypes.data_as(C.c_void_p), s_.ctypes.data_as(C.c_void_p), p_.ctypes.data_as(C.c_void_p),
-                                blob.ctypes.data_as(C.c_void_p), off.ctypes.data_as(C.c_void_p), C.c_uint8(0), None, C.c_uint8(0),
-                                C.c_size_t(n), tab)
-        assert (got == want[order]).all(), [(order[i], int(got[i]), int(want[order[i]])) for i in range(n) if got[i] != want[order[i]]]
-    assert (want == -1).sum() >= 10 and (want == 0).sum() >= 10
 
 
 def test_half_size_pair_of_a_challenge(H):
@@ -408,9 +341,7 @@ def test_table_free_ladder_matches_oracle_and_golden_f1(H, O):
     for i in range(len(vals)):   # complete extended points: on the curve, X Y = Z T
         assert H.hs_point_valid(got[i].ctypes.data_as(C.c_void_p)) == -1, hex(vals[i])
     # the identity and (0, -1) as bases: the identity's class whatever the scalar
-    ident = np.frombuffer(bytes(Point.identity()), np.uint64).copy() if hasattr(Point, "identity") else None
-    if ident is None:
-        ident = np.zeros(32, np.uint64); ident[8] = 1; ident[16] = 1
+    ident = np.zeros(32, np.uint64); ident[8] = 1; ident[16] = 1
     t2 = ident.copy(); t2[8:16] = np.frombuffer(Gf.from_int(P - 1), np.uint64)
     special = np.stack([ident, t2, ident, t2])
     s4 = _gen.scalars_from_ints([0, 5, Q - 1, Q - 1])
