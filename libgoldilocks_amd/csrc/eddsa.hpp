@@ -151,11 +151,14 @@ struct shake256 {
 
 // ------------------------------------------------------------------ challenge hash
 // The hashed string is  "SigEd448" | ph | ctxlen | ctx | R(57) | A(57) | msg.
-// MSG policy: src.byte(j) returns byte j of that virtual string (j < total).
-// STAGE policy: a per-lane 136-byte scratch: stage.put(i, byte), stage.get64(k).
-// Returns the first 114 output bytes as 29 words (top 2 bytes of word 28 zero).
+// MSG policy: src.word(j) returns bytes j .. j+3 of that virtual string as a little-endian word, zero beyond
+// its end (j a multiple of 4).  A 136-byte block is absorbed as 34 such words with compile-time indices, so
+// the Keccak state stays in registers and the 34 reads of a block are in flight together (read byte by byte,
+// each read waiting for the one before, the two blocks of a verification cost 4 % of the kernel:
+// tools/verifyphases).  Returns the first 114 output bytes as 29 words (top 2 bytes of word 28 zero).
 template <class MSG, class STAGE>
 GD_FN void shake256_114(uint32_t out[29], const MSG &src, uint32_t total, STAGE &stage) {
+    (void)stage;
     uint64_t st[25];
 #pragma unroll
     for (int i = 0; i < 25; i++) st[i] = 0;
@@ -163,15 +166,17 @@ GD_FN void shake256_114(uint32_t out[29], const MSG &src, uint32_t total, STAGE 
 #pragma unroll 1
     for (uint32_t blk = 0; blk < nblocks; blk++) {
         const uint32_t base = blk * SHAKE256_RATE;
-#pragma unroll 1
-        for (uint32_t i = 0; i < SHAKE256_RATE; i++) {
-            const uint32_t j = base + i;
-            uint32_t b = j < total ? src.byte(j) : (j == total ? 0x1fu : 0u);
-            if (i == SHAKE256_RATE - 1 && blk == nblocks - 1) b ^= 0x80u;
-            stage.put(i, b);
-        }
+        uint32_t w[SHAKE256_RATE / 4];
 #pragma unroll
-        for (int k = 0; k < SHAKE256_RATE / 8; k++) st[k] ^= stage.get64(k);
+        for (int i = 0; i < SHAKE256_RATE / 4; i++) {
+            const uint32_t j = base + 4 * i;
+            uint32_t v = src.word(j);
+            if (total >= j && total < j + 4) v |= 0x1fu << (8 * (total - j));   // SHAKE's domain byte right behind the string
+            w[i] = v;
+        }
+        if (blk == nblocks - 1) w[SHAKE256_RATE / 4 - 1] ^= 0x80000000u;        // the last byte of the last block
+#pragma unroll
+        for (int k = 0; k < SHAKE256_RATE / 8; k++) st[k] ^= (uint64_t)w[2 * k] | (uint64_t)w[2 * k + 1] << 32;
         keccak_f1600(st);
     }
 #pragma unroll
@@ -239,6 +244,25 @@ struct Ed448Msg {
         j -= alen;
         if (j < blen) return b[j];
         return msg[j - blen];
+    }
+    // bytes j .. j+3 as a little-endian word, zero beyond the end of the string.  Four bytes inside one of
+    // the caller's buffers are ONE read (global memory takes unaligned 32-bit reads); only the words that
+    // straddle two pieces -- at most four per string -- are put together byte by byte.
+    static GD_MFN uint32_t load32(const uint8_t *p) {
+        uint32_t v;
+        __builtin_memcpy(&v, p, 4);
+        return v;
+    }
+    GD_MFN uint32_t word(uint32_t j) const {
+        const uint32_t off_a = dom ? 10 + ctxlen : 0, off_b = off_a + alen, off_m = off_b + blen, end = off_m + msglen;
+        if (j >= off_m && j + 4 <= end) return load32(msg + (j - off_m));
+        if (j >= off_b && j + 4 <= off_m) return load32(b + (j - off_b));
+        if (j >= off_a && j + 4 <= off_b) return load32(a + (j - off_a));
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++)
+            if (j + k < end) v |= byte(j + k) << (8 * k);
+        return v;
     }
 };
 GD_FN Ed448Msg ed448_challenge_string(const uint8_t *r57, const uint8_t *pk57, const uint8_t *msg, uint32_t msglen,

@@ -196,6 +196,50 @@ struct LaneTable {  // this lane's window table in the HBM workspace, lane-conti
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
 };
+// The same lane-contiguous table with WAVE-COOPERATIVE stores (every lane of the wave must call, k uniform).
+// A lane that stores its own 256-byte entry issues 16-byte pieces 4 KiB apart from its neighbours': every store
+// instruction touches 64 cache lines and the L1 -> L2 write path sees 1088 partial-line requests per entry and
+// wave -- the table builds of verification ran at 1.8 x their arithmetic time for it (tools/verifyphases: 3.8 ms
+// of 34.9 per 2^20 signatures vanish when the stores are left out; staggering the blocks changes nothing, so it
+// is the request count, not a burst).  Here the wave transposes through LDS, half an entry (= one 128-byte line
+// per lane) at a time: in store instruction j lanes 8g .. 8g+7 write the eight pieces of ONE line, the one of
+// owner lane 8j + g, so an instruction is 8 whole lines and an entry 128 requests.  The slot of piece p of
+// owner L in the wave's buffer is 8 L + (p ^ (L & 7)): conflict-free for the owners' writes and the readers' reads.
+constexpr int XPOSE_U4 = 64 * 8;   // uint4 of LDS per wave: 8 KiB
+struct CoopLaneTable {
+    static constexpr bool direct = true;
+    uint4 *p;          // this lane's table
+    uint4 *wave0;      // the table (same `which`) of lane 0 of this wave
+    uint32_t stride;   // uint4 between the tables of consecutive lanes
+    uint4 *lds;        // the wave's transposition buffer (XPOSE_U4)
+    __device__ __forceinline__ void store_half(int k, int h, const fe &f0, const fe &f1) const {
+        const uint32_t l = threadIdx.x & 63u, sw = l & 7u;
+        wave_sync();   // the buffer's previous readers are done
+        uint4 *mine = lds + 8 * l;
+        mine[0 ^ sw] = make_uint4(f0.v[0], f0.v[1], f0.v[2], f0.v[3]);
+        mine[1 ^ sw] = make_uint4(f0.v[4], f0.v[5], f0.v[6], f0.v[7]);
+        mine[2 ^ sw] = make_uint4(f0.v[8], f0.v[9], f0.v[10], f0.v[11]);
+        mine[3 ^ sw] = make_uint4(f0.v[12], f0.v[13], f0.v[14], f0.v[15]);
+        mine[4 ^ sw] = make_uint4(f1.v[0], f1.v[1], f1.v[2], f1.v[3]);
+        mine[5 ^ sw] = make_uint4(f1.v[4], f1.v[5], f1.v[6], f1.v[7]);
+        mine[6 ^ sw] = make_uint4(f1.v[8], f1.v[9], f1.v[10], f1.v[11]);
+        mine[7 ^ sw] = make_uint4(f1.v[12], f1.v[13], f1.v[14], f1.v[15]);
+        wave_sync();
+        const uint32_t g = l >> 3, piece = l & 7u;
+        uint4 *dst = wave0 + (size_t)g * stride + 16 * k + 8 * h + piece;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t owner = 8 * j + g;
+            dst[(size_t)(8 * j) * stride] = lds[8 * owner + (piece ^ (owner & 7u))];
+        }
+    }
+    __device__ __forceinline__ void store(int k, const pniels &e) const {
+        store_half(k, 0, e.a, e.b);
+        store_half(k, 1, e.cn, e.z);
+    }
+    __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
+    __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
+};
 // The index-independent window table: the counterpart of the reference's constant_time_lookup
 // (src/include/constant_time.h:134-183, used at src/goldilocks.c:440): every lookup reads EVERY entry
 // and keeps the wanted one with v_cndmask, so neither the addresses issued nor the number of

@@ -33,22 +33,29 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
                          uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt) {
     __shared__ uint32_t s_bits[30 * BLOCK];
     __shared__ uint32_t s_stage[34 * BLOCK];
+    __shared__ uint4 s_xpose[(BLOCK / 64) * XPOSE_U4];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> b_tab{bwt_tab};
     LdsStage stage{s_stage + threadIdx.x};
     LdsMkBits mk{s_bits + threadIdx.x};
-    // Half-size scalars (lattice.hpp): A and R share one ladder of 45 windows; two tables per lane.
-    LaneTable a_tab = VarTable<false>::at(workspace, 0, 2), r_tab = VarTable<false>::at(workspace, 1, 2);
-    for (uint32_t i = lane; i < n; i += stride) {
+    // Half-size scalars (lattice.hpp): A and R share one ladder of 45 windows; two tables per lane, stored
+    // wave-cooperatively (CoopLaneTable) -- so the loop is wave-uniform: a lane without a signature of its own in
+    // the last round verifies the batch's last one once more and stores nothing.
+    CoopLaneTable a_tab = coop_table_at(workspace, 0, 2, s_xpose), r_tab = coop_table_at(workspace, 1, 2, s_xpose);
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {
+        const uint32_t slot = lane + r * stride;
+        const bool live = slot < n;
+        const uint32_t i = live ? slot : n - 1;
         const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
         const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
         const bool fits = len64 < MAX_MESSAGE_BYTES;   // longer than the 32-bit byte counters hold: the lane fails
         const Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg,
                                                   fits ? (uint32_t)len64 : 0u, prehashed, ctx, ctx_len);
         const bool ok = ed448_verify_lattice(m, b_tab, a_tab, r_tab, stage, mk);
-        status[i] = ok && fits ? -1 : 0;
+        if (live) status[i] = ok && fits ? -1 : 0;
     }
 }
 

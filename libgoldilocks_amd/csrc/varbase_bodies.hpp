@@ -24,6 +24,13 @@ struct VarTable<false> {
         return type{ws + ((size_t)lane * ntab + which) * TABLE_U4};
     }
 };
+// the same tables with wave-cooperative stores (CoopLaneTable): for kernels whose table code runs wave-uniformly
+__device__ __forceinline__ CoopLaneTable coop_table_at(uint4 *ws, int which, int ntab, uint4 *xpose) {
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x, l = threadIdx.x & 63u;
+    uint4 *mine = ws + ((size_t)lane * ntab + which) * TABLE_U4;
+    return CoopLaneTable{mine, mine - (size_t)l * ntab * TABLE_U4, (uint32_t)(ntab * TABLE_U4),
+                         xpose + (threadIdx.x >> 6) * XPOSE_U4};
+}
 #ifndef GD_CT_WINDOW
 #define GD_CT_WINDOW 4
 #endif
