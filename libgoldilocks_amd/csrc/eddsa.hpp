@@ -273,11 +273,18 @@ GD_FN Ed448Msg ed448_challenge_string(const uint8_t *r57, const uint8_t *pk57, c
     return m;
 }
 
+// nbytes bytes at p (any alignment) as little-endian words; the unused high bytes of the last word are zero.
+// Whole words are ONE read each (global memory takes unaligned 32-bit reads): byte by byte, 57 reads each
+// waiting for the one before, a decoding spent a tenth of its time fetching its input (tools/verifyphases).
 GD_FN void load_bytes_as_words(uint32_t *w, const uint8_t *p, int nbytes, int nwords) {
     for (int i = 0; i < nwords; i++) {
         uint32_t x = 0;
-        for (int b = 0; b < 4; b++)
-            if (4 * i + b < nbytes) x |= (uint32_t)p[4 * i + b] << (8 * b);
+        if (4 * i + 4 <= nbytes) {
+            __builtin_memcpy(&x, p + 4 * i, 4);
+        } else {
+            for (int b = 0; b < 4; b++)
+                if (4 * i + b < nbytes) x |= (uint32_t)p[4 * i + b] << (8 * b);
+        }
         w[i] = x;
     }
 }
@@ -337,18 +344,26 @@ GD_FN void lattice_subtract_once(pt &V, const AT &tab, bool doit) {
 template <class FB, class AT, class BITS, class MKBITS>
 GD_FN bool ed448_verify_lattice_walk(const Ed448Msg &m, const LatticePair &pr, const BITS &bits1, const BITS &bits2,
                                      const FB &fb, AT &a_tab, AT &r_tab, MKBITS &mkbits) {
-    uint32_t w[15];
     bool ok;
     {
-        pt A;
-        load_bytes_as_words(w, m.b, 57, 15);                                  // public key
-        ok = pt_decode_eddsa_words(A, w);
+        // both points are decoded in ONE instruction stream (their exponentiations interleaved); R waits in its
+        // table's memory (slot 0, as a plain four-field record) while the key's table is built
+        uint32_t wa[15], wr[15];
+        load_bytes_as_words(wa, m.b, 57, 15);                                 // public key
+        load_bytes_as_words(wr, m.a, 57, 15);                                 // R = sig[0:57]
+        pt A, R;
+        bool oka, okr;
+        pt_decode_eddsa_words2(A, R, oka, okr, wa, wr);
+        ok = oka && okr;
+        pniels park;
+        park.a = R.x; park.b = R.y; park.cn = R.z; park.z = R.t;
+        r_tab.store(0, park);
         build_window_table(a_tab, pr.tau_pos ? pt_negate(A) : A);             // PA
     }
     {
+        const pniels park = r_tab.load(0);
         pt R;
-        load_bytes_as_words(w, m.a, 57, 15);                                  // R = sig[0:57]
-        ok = pt_decode_eddsa_words(R, w) && ok;
+        R.x = park.a; R.y = park.b; R.z = park.cn; R.t = park.z;
         build_window_table(r_tab, pt_negate(R));                              // PR
     }
     pt V = ladder_double_var(bits1, a_tab, bits2, r_tab, LATTICE_WINDOWS);

@@ -195,6 +195,49 @@ struct LaneTable {  // this lane's window table in the HBM workspace, lane-conti
     __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
+    __device__ __forceinline__ void put_step(const pniels &e) const { store(16, e); }   // slot 16: the build slot
+    __device__ __forceinline__ pniels step() const { return load(16); }
+};
+// The same table with the build's step in LDS instead of slot 16.  Memory operations complete in order, so a
+// read issued behind the 16 stores of an entry waits until those have been acknowledged: with the step in the
+// table's own memory every iteration of the build pays that (tools/verifyphases: the table builds of
+// verification ran at 14-18 clocks per multiply-accumulate against the ladder's 10, and at the ladder's rate
+// with the stores left out).  From LDS the step comes back at once and the stores drain behind the next addition.
+// Piece-major ([piece][lane], 16 bytes each): conflict-free.
+constexpr int STEP_LDS_U4 = 16 * 256;   // uint4 per 256-lane block
+struct LdsStepTable {
+    static constexpr bool direct = true;
+    uint4 *p;        // this lane's table in the workspace
+    uint4 *lds;      // the block's step region + threadIdx.x
+    __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
+    __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
+    __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
+    __device__ __forceinline__ void put_piece(int i, const fe &f) const {
+        lds[(4 * i + 0) * 256] = make_uint4(f.v[0], f.v[1], f.v[2], f.v[3]);
+        lds[(4 * i + 1) * 256] = make_uint4(f.v[4], f.v[5], f.v[6], f.v[7]);
+        lds[(4 * i + 2) * 256] = make_uint4(f.v[8], f.v[9], f.v[10], f.v[11]);
+        lds[(4 * i + 3) * 256] = make_uint4(f.v[12], f.v[13], f.v[14], f.v[15]);
+    }
+    __device__ __forceinline__ fe get_piece(int i) const {
+        return fe_from_u4(lds[(4 * i + 0) * 256], lds[(4 * i + 1) * 256], lds[(4 * i + 2) * 256], lds[(4 * i + 3) * 256]);
+    }
+    __device__ __forceinline__ void put_step(const pniels &e) const {
+        put_piece(0, e.a);
+        put_piece(1, e.b);
+        put_piece(2, e.cn);
+        put_piece(3, e.z);
+    }
+    __device__ __forceinline__ pniels step() const {
+        // read anew in every iteration of the build: hoisted out of the loop (nothing there writes LDS) the step
+        // would sit in 64 registers next to the accumulator, which is exactly what spills
+        asm volatile("" ::: "memory");
+        pniels e;
+        e.a = get_piece(0);
+        e.b = get_piece(1);
+        e.cn = get_piece(2);
+        e.z = get_piece(3);
+        return e;
+    }
 };
 // The same lane-contiguous table with WAVE-COOPERATIVE stores (every lane of the wave must call, k uniform).
 // A lane that stores its own 256-byte entry issues 16-byte pieces 4 KiB apart from its neighbours': every store
@@ -239,6 +282,8 @@ struct CoopLaneTable {
     }
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
+    __device__ __forceinline__ void put_step(const pniels &e) const { store(16, e); }
+    __device__ __forceinline__ pniels step() const { return load(16); }
 };
 // The index-independent window table: the counterpart of the reference's constant_time_lookup
 // (src/include/constant_time.h:134-183, used at src/goldilocks.c:440): every lookup reads EVERY entry
@@ -289,6 +334,8 @@ struct ScanTable {
         load_raw(w, (int)k);
         return from_raw(w);
     }
+    __device__ __forceinline__ void put_step(const pniels &e) const { store(ENTRIES, e); }   // the build slot
+    __device__ __forceinline__ pniels step() const { return load(ENTRIES); }
     // the entry a SECRET digit asks for: all ENTRIES candidates are read, one is kept
     __device__ __forceinline__ static void keep(uint4 (&r)[SCAN_ROWS], const uint4 (&w)[SCAN_ROWS], bool take) {
 #pragma unroll
@@ -421,6 +468,25 @@ struct LdsMkBits {
         return LdsBits{slot};
     }
 };
+
+// Verification's three scalars in 16 words of LDS per lane: the two half-size ones of the joint ladder are 225
+// bits each (words 0..7 and 8..15), and the base point's full-size one is only made when they are dead (words 0..13;
+// its 16-bit digits never straddle a word, so no padding word is read).
+struct LdsMkBitsVerify {
+    uint32_t *slot0;
+    __device__ __forceinline__ LdsBits operator()(const sc &s, int) const {
+#pragma unroll
+        for (int k = 0; k < 14; k++) slot0[k * BLOCK] = s.w[k];
+        return LdsBits{slot0};
+    }
+    __device__ __forceinline__ LdsBits words(const uint32_t (&w)[15], int which) const {
+        uint32_t *slot = slot0 + which * 8 * BLOCK;
+#pragma unroll
+        for (int k = 0; k < 8; k++) slot[k * BLOCK] = w[k];
+        return LdsBits{slot};
+    }
+};
+static_assert(BWT_BITS == 16 || BWT_BITS == 8, "LdsMkBitsVerify: the base point's digits must not straddle words");
 
 #define GD_KERNEL extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 // the index-independent variable-base kernels: resident blocks per CU chosen separately, because what

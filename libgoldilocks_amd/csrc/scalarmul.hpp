@@ -11,8 +11,8 @@
 // (a) instantiated by the HIP kernels with HBM/LDS-backed storage and (b) run on
 // the host by tests/hostsim with plain arrays (checker only, never shipped):
 //   BITS  : bits.word(k) -> k-th 32-bit word of s' (k < 15, word 14 is zero)
-//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table (ENTRIES + 1 slots:
-//           the entries + one scratch slot used while the table is built; k is public there);
+//   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table, table.put_step(pniels) /
+//           table.step() for the one value the build re-reads (k is public there);
 //           table.lookup(idx) is the read of a digit's entry -- direct, or index-independent (a scan
 //           of every entry, kernels.hpp ScanTable)
 #pragma once
@@ -57,19 +57,20 @@ template <int W>
 GD_FN sc sc_recode_window(const sc &s) { return W == 5 ? sc_recode_signed(s) : sc_recode_signed8(s); }
 
 // multiples[k] = (2k+1)*B, k < 2^(W-1), as projective niels (src/goldilocks.c:382-403).
-// The step 2B is parked in the lane's table memory (slot ENTRIES) and re-read every iteration, as the
-// ladder re-reads its entries: holding it in registers next to the accumulator spills.
+// The step 2B does not stay in registers next to the accumulator (that spills): the policy parks it
+// (table.put_step) and hands it back every iteration (table.step()) -- in the table's own memory, slot
+// ENTRIES, or wherever a kernel has room that is not behind its stores (kernels.hpp LdsStepTable).
 template <int W, class TABLE>
 GD_FN void build_window_table_w(TABLE &table, const pt &b) {
     constexpr int E = window_plan<W>::ENTRIES;
     pt twice = b;
     pt_double(twice, true);
-    table.store(E, pt_to_pniels(twice));
+    table.put_step(pt_to_pniels(twice));
     table.store(0, pt_to_pniels(b));
     pt acc = b;
 #pragma unroll 1
     for (int k = 1; k < E; k++) {
-        pt_add_pniels(acc, table.load(E), false, true);
+        pt_add_pniels(acc, table.step(), false, true);
         table.store(k, pt_to_pniels(acc));
     }
 }
@@ -196,15 +197,25 @@ GD_FN void signed_digit_bwt(uint32_t w, uint32_t &idx, bool &neg) {
     neg = w < (uint32_t)BWT_PER_WINDOW;
     idx = (neg ? ~w : w) & (uint32_t)(BWT_PER_WINDOW - 1);
 }
-// acc += s*B through the same table: one mixed addition per digit onto a caller's accumulator (acc.t valid)
+// acc += s*B through the same table: one mixed addition per digit onto a caller's accumulator (acc.t valid).
+// The entry of the NEXT digit is requested before the current addition: a gather from a 168-MiB table is a
+// miss almost every time, and 28 of them in a row, each waited for, cost as much as 8 of the 28 additions
+// (tools/verifyphases: 12.6 clocks per multiply-accumulate against the ladder's 9.7).
 template <class BITS, class BWT>
 GD_FN void ladder_bwt_onto(pt &acc, const BITS &bits, const BWT &bwt) {
     uint32_t idx;
     bool neg;
+    signed_digit_bwt(window_bwt(bits, BWT_WINDOWS - 1), idx, neg);
+    niels next = bwt.load(BWT_WINDOWS - 1, idx);
 #pragma unroll 1
     for (int i = BWT_WINDOWS - 1; i >= 0; i--) {
-        signed_digit_bwt(window_bwt(bits, i), idx, neg);
-        pt_add_niels(acc, bwt.load(i, idx), neg, true);
+        const niels e = next;
+        const bool neg_e = neg;
+        if (i > 0) {
+            signed_digit_bwt(window_bwt(bits, i - 1), idx, neg);
+            next = bwt.load(i - 1, idx);
+        }
+        pt_add_niels(acc, e, neg_e, true);
     }
 }
 template <class BITS, class BWT>

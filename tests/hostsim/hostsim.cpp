@@ -34,6 +34,8 @@ struct HostTable {
     void store(int k, const pniels &p) { e[k] = p; }
     pniels load(uint32_t k) const { return e[k]; }
     pniels lookup(uint32_t k) const { return e[k]; }
+    void put_step(const pniels &p) { e[16] = p; }
+    pniels step() const { return e[16]; }
 };
 struct HostComb {
     using plan = comb_ref;

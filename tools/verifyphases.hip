@@ -30,11 +30,11 @@ using namespace gd;
     } while (0)
 
 constexpr int NPH = 10;
-static const char *PHASE[NPH] = {"hash + scalar decoding", "short pair (lattice) + tau*S", "decode A", "table A",
-                                 "decode R",              "table R",                      "joint ladder (45 windows)",
+static const char *PHASE[NPH] = {"hash + scalar decoding", "short pair (lattice) + tau*S", "decode A and R together", "table A",
+                                 "(reload R)",            "table R",                      "joint ladder (45 windows)",
                                  "two correcting adds",   "28 base-point adds",           "test + store"};
 // multiply-accumulates per phase (tests/hostsim counters): decode 64.6 K each, table 26.1 K each, ...
-static const double MACS[NPH] = {0, 0, 64572, 26080, 64572, 26080, 225 * 1120.0 + 45 * 192 + 90 * 1728, 2 * 1728, 28 * 1344, 0};
+static const double MACS[NPH] = {0, 0, 2 * 64572, 26080, 0, 26080, 225 * 1120.0 + 45 * 192 + 90 * 1728, 2 * 1728, 28 * 1344, 0};
 
 __device__ __forceinline__ uint64_t now() { return __builtin_readcyclecounter(); }
 
@@ -42,16 +42,17 @@ extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ pk,
          const uint8_t *__restrict__ msgs, uint32_t msg_len, uint32_t n, uint4 *__restrict__ workspace,
          const uint4 *__restrict__ bwt, unsigned long long *__restrict__ totals, int stagger_units, int stagger_mod) {
-    __shared__ uint32_t s_bits[30 * BLOCK];
+    __shared__ uint32_t s_bits[16 * BLOCK];
     __shared__ uint32_t s_stage[34 * BLOCK];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> fb{bwt_tab};
     LdsStage stage{s_stage + threadIdx.x};
-    LdsMkBits mkbits{s_bits + threadIdx.x};
-    __shared__ uint4 s_xpose[(BLOCK / 64) * XPOSE_U4];
-    CoopLaneTable a_tab = coop_table_at(workspace, 0, 2, s_xpose), r_tab = coop_table_at(workspace, 1, 2, s_xpose);   // n is a multiple of the grid: wave-uniform
+    LdsMkBitsVerify mkbits{s_bits + threadIdx.x};
+    __shared__ uint4 s_step[STEP_LDS_U4];
+    LdsStepTable a_tab{VarTable<false>::at(workspace, 0, 2).p, s_step + threadIdx.x},
+                 r_tab{VarTable<false>::at(workspace, 1, 2).p, s_step + threadIdx.x};
     uint64_t acc[NPH];
     for (int k = 0; k < NPH; k++) acc[k] = 0;
     // experiment: blocks start at different times so that their table-building phases (bursts of stores) do not coincide
@@ -92,17 +93,24 @@ k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const ui
         MARK(1);
         bool ok;
         {
-            pt A;
-            load_bytes_as_words(w, m.b, 57, 15);
-            ok = pt_decode_eddsa_words(A, w);
+            uint32_t wa[15], wr[15];
+            load_bytes_as_words(wa, m.b, 57, 15);
+            load_bytes_as_words(wr, m.a, 57, 15);
+            pt A, R;
+            bool oka, okr;
+            pt_decode_eddsa_words2(A, R, oka, okr, wa, wr);
+            ok = oka && okr;
+            pniels park;
+            park.a = R.x; park.b = R.y; park.cn = R.z; park.z = R.t;
+            r_tab.store(0, park);
             MARK(2);
             build_window_table(a_tab, pr.tau_pos ? pt_negate(A) : A);
             MARK(3);
         }
         {
+            const pniels park = r_tab.load(0);
             pt R;
-            load_bytes_as_words(w, m.a, 57, 15);
-            ok = pt_decode_eddsa_words(R, w) && ok;
+            R.x = park.a; R.y = park.b; R.z = park.cn; R.t = park.z;
             MARK(4);
             build_window_table(r_tab, pt_negate(R));
             MARK(5);
