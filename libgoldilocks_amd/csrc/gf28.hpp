@@ -40,6 +40,15 @@
 
 namespace gd {
 
+// Nothing is scheduled across this point (device build; nothing on the host): used where a memory read has to be
+// ISSUED early -- ahead of a block of arithmetic it does not depend on -- and the compiler's scheduler, minding
+// register pressure, would move it down to its first use.
+GD_FN void gd_keep_order() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 constexpr uint32_t M28 = (1u << 28) - 1;
 
 struct fe {

@@ -297,6 +297,9 @@ GD_FN pt ladder_double(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, c
 }
 // The same with `nw` 5-bit windows instead of 90 (nw must be the same in every lane of a wave): for the
 // half-size scalars of verification (lattice.hpp).  bits: words of (s + 2^(5 nw) - 1) / 2 for odd INTEGER s.
+// Public data (TABLE::direct): the first entry of a window is requested BEFORE the window's last doubling and
+// the second one before the first addition, so each read has a field operation's worth of arithmetic to hide
+// behind (with both requested after the doublings the first addition waited for memory 44 times per signature).
 template <class BITS, class TABLE1, class TABLE2>
 GD_FN pt ladder_double_var(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2, int nw) {
     uint32_t idx;
@@ -308,14 +311,16 @@ GD_FN pt ladder_double_var(const BITS &bits1, const TABLE1 &t1, const BITS &bits
 #pragma unroll 1
     for (int pos = 5 * (nw - 2); pos >= 0; pos -= 5) {
 #pragma unroll 1
-        for (int j = 0; j < 5; j++) pt_double(acc, j == 4);
-        // both entries' loads are issued before the first addition (1 % faster than one at a time)
+        for (int j = 0; j < 4; j++) pt_double(acc, false);
         uint32_t idx2;
         bool neg2;
         signed_digit(window5(bits1, pos), idx, neg);
         signed_digit(window5(bits2, pos), idx2, neg2);
         const pniels e1 = t1.lookup(idx);
+        gd_keep_order();        // (the scheduler would otherwise sink the reads to right before their first use)
+        pt_double(acc, true);
         const pniels e2 = t2.lookup(idx2);
+        gd_keep_order();
         pt_add_pniels(acc, e1, neg, true);
         pt_add_pniels(acc, e2, neg2, true);
     }
