@@ -239,128 +239,6 @@ struct LdsStepTable {
         return e;
     }
 };
-// The same lane-contiguous table with WAVE-COOPERATIVE stores (every lane of the wave must call, k uniform).
-// A lane that stores its own 256-byte entry issues 16-byte pieces 4 KiB apart from its neighbours': every store
-// instruction touches 64 cache lines and the L1 -> L2 write path sees 1088 partial-line requests per entry and
-// wave -- the table builds of verification ran at 1.8 x their arithmetic time for it (tools/verifyphases: 3.8 ms
-// of 34.9 per 2^20 signatures vanish when the stores are left out; staggering the blocks changes nothing, so it
-// is the request count, not a burst).  Here the wave transposes through LDS, half an entry (= one 128-byte line
-// per lane) at a time: in store instruction j lanes 8g .. 8g+7 write the eight pieces of ONE line, the one of
-// owner lane 8j + g, so an instruction is 8 whole lines and an entry 128 requests.  The slot of piece p of
-// owner L in the wave's buffer is 8 L + (p ^ (L & 7)): conflict-free for the owners' writes and the readers' reads.
-constexpr int XPOSE_U4 = 64 * 8;   // uint4 of LDS per wave: 8 KiB
-struct CoopLaneTable {
-    static constexpr bool direct = true;
-    uint4 *p;          // this lane's table
-    uint4 *wave0;      // the table (same `which`) of lane 0 of this wave
-    uint32_t stride;   // uint4 between the tables of consecutive lanes
-    uint4 *lds;        // the wave's transposition buffer (XPOSE_U4)
-    __device__ __forceinline__ void store_half(int k, int h, const fe &f0, const fe &f1) const {
-        const uint32_t l = threadIdx.x & 63u, sw = l & 7u;
-        wave_sync();   // the buffer's previous readers are done
-        uint4 *mine = lds + 8 * l;
-        mine[0 ^ sw] = make_uint4(f0.v[0], f0.v[1], f0.v[2], f0.v[3]);
-        mine[1 ^ sw] = make_uint4(f0.v[4], f0.v[5], f0.v[6], f0.v[7]);
-        mine[2 ^ sw] = make_uint4(f0.v[8], f0.v[9], f0.v[10], f0.v[11]);
-        mine[3 ^ sw] = make_uint4(f0.v[12], f0.v[13], f0.v[14], f0.v[15]);
-        mine[4 ^ sw] = make_uint4(f1.v[0], f1.v[1], f1.v[2], f1.v[3]);
-        mine[5 ^ sw] = make_uint4(f1.v[4], f1.v[5], f1.v[6], f1.v[7]);
-        mine[6 ^ sw] = make_uint4(f1.v[8], f1.v[9], f1.v[10], f1.v[11]);
-        mine[7 ^ sw] = make_uint4(f1.v[12], f1.v[13], f1.v[14], f1.v[15]);
-        wave_sync();
-        const uint32_t g = l >> 3, piece = l & 7u;
-        uint4 *dst = wave0 + (size_t)g * stride + 16 * k + 8 * h + piece;
-#pragma unroll
-        for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t owner = 8 * j + g;
-            dst[(size_t)(8 * j) * stride] = lds[8 * owner + (piece ^ (owner & 7u))];
-        }
-    }
-    __device__ __forceinline__ void store(int k, const pniels &e) const {
-        store_half(k, 0, e.a, e.b);
-        store_half(k, 1, e.cn, e.z);
-    }
-    __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
-    __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
-    __device__ __forceinline__ void put_step(const pniels &e) const { store(16, e); }
-    __device__ __forceinline__ pniels step() const { return load(16); }
-};
-// The index-independent window table: the counterpart of the reference's constant_time_lookup
-// (src/include/constant_time.h:134-183, used at src/goldilocks.c:440): every lookup reads EVERY entry
-// and keeps the wanted one with v_cndmask, so neither the addresses issued nor the number of
-// transactions depend on the (secret) digit.  The table is private to a lane, so there is nothing for
-// a wavefront shuffle to share; instead
-//   * the wave's 64 tables are interleaved [entry][row][lane], so each load of a scan is one fully
-//     coalesced 1-KiB row (a lane-contiguous table would touch 64 lines per instruction);
-//   * entries are stored canonical and bit-packed, 4 field elements x 448 bits = 14 uint4 = 224 B
-//     instead of 256: a scan moves ENTRIES x 224 B per digit, which is what bounds this kernel
-//     (HBM / Infinity-Cache bandwidth), and with 4-bit windows the tables of all
-//     resident lanes (131 072 x 8 x 224 B = 224 MiB) fit the 256-MiB Infinity Cache.
-constexpr int SCAN_ROWS = 14;   // uint4 per packed entry
-template <int ENTRIES>
-struct ScanTable {
-    static constexpr bool direct = false;   // lookup = a scan of the whole table
-    uint4 *p;   // the wave's region + lane: row r of entry k of this lane at p[(SCAN_ROWS * k + r) * 64]
-    __device__ __forceinline__ void store(int k, const pniels &e) const {
-        uint32_t w[56];
-        fe_serialize_words(w, e.a);          // canonical limbs < 2^28, packed
-        fe_serialize_words(w + 14, e.b);
-        fe_serialize_words(w + 28, e.cn);
-        fe_serialize_words(w + 42, e.z);     // 2Z mod p
-        uint4 *q = p + (size_t)(SCAN_ROWS * k) * 64;
-#pragma unroll
-        for (int r = 0; r < SCAN_ROWS; r++) q[r * 64] = make_uint4(w[4 * r], w[4 * r + 1], w[4 * r + 2], w[4 * r + 3]);
-    }
-    __device__ __forceinline__ void load_raw(uint4 (&w)[SCAN_ROWS], int k) const {
-        const uint4 *q = p + (size_t)(SCAN_ROWS * k) * 64;
-#pragma unroll
-        for (int i = 0; i < SCAN_ROWS; i++) w[i] = q[i * 64];
-    }
-    __device__ __forceinline__ static pniels from_raw(const uint4 (&r)[SCAN_ROWS]) {
-        uint32_t w[56];
-#pragma unroll
-        for (int i = 0; i < SCAN_ROWS; i++) {
-            w[4 * i] = r[i].x; w[4 * i + 1] = r[i].y; w[4 * i + 2] = r[i].z; w[4 * i + 3] = r[i].w;
-        }
-        pniels e;
-        e.a = fe_unpack_words(w);
-        e.b = fe_unpack_words(w + 14);
-        e.cn = fe_unpack_words(w + 28);
-        e.z = fe_unpack_words(w + 42);
-        return e;
-    }
-    __device__ __forceinline__ pniels load(uint32_t k) const {   // table building only (k is public)
-        uint4 w[SCAN_ROWS];
-        load_raw(w, (int)k);
-        return from_raw(w);
-    }
-    __device__ __forceinline__ void put_step(const pniels &e) const { store(ENTRIES, e); }   // the build slot
-    __device__ __forceinline__ pniels step() const { return load(ENTRIES); }
-    // the entry a SECRET digit asks for: all ENTRIES candidates are read, one is kept
-    __device__ __forceinline__ static void keep(uint4 (&r)[SCAN_ROWS], const uint4 (&w)[SCAN_ROWS], bool take) {
-#pragma unroll
-        for (int i = 0; i < SCAN_ROWS; i++) {
-            r[i].x = take ? w[i].x : r[i].x;
-            r[i].y = take ? w[i].y : r[i].y;
-            r[i].z = take ? w[i].z : r[i].z;
-            r[i].w = take ? w[i].w : r[i].w;
-        }
-    }
-    __device__ __forceinline__ pniels lookup(uint32_t idx) const {
-        uint4 r[SCAN_ROWS];
-        load_raw(r, 0);
-#pragma unroll 1
-        for (int k = 1; k < ENTRIES; k++) {   // one candidate in flight: two at a time spill (profiles/r02/experiments.md B)
-            uint4 w[SCAN_ROWS];
-            load_raw(w, k);
-            keep(r, w, idx == (uint32_t)k);
-        }
-        return from_raw(r);
-    }
-};
-// uint4 per WAVE of a scan table: (ENTRIES + 1 build slot) x SCAN_ROWS uint4 x 64 lanes
-template <int ENTRIES>
-constexpr int scan_table_wave_u4() { return (ENTRIES + 1) * SCAN_ROWS * 64; }
 // The comb staged in LDS and gathered with wavefront shuffles.  Entry e occupies words
 // [49e, 49e+48) (stride 49 keeps the fill reads below conflict-free).  For comb j every lane
 // first reads 12 words with a LANE-dependent, index-INDEPENDENT address: lane l takes words
@@ -489,13 +367,6 @@ struct LdsMkBitsVerify {
 static_assert(BWT_BITS == 16 || BWT_BITS == 8, "LdsMkBitsVerify: the base point's digits must not straddle words");
 
 #define GD_KERNEL extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
-// the index-independent variable-base kernels: resident blocks per CU chosen separately, because what
-// bounds them is how much table the resident lanes keep in the Infinity Cache
-#ifndef GD_CT_WAVES_PER_SIMD
-#define GD_CT_WAVES_PER_SIMD 2
-#endif
-constexpr int CT_WAVES_PER_SIMD = GD_CT_WAVES_PER_SIMD;
-#define GD_KERNEL_CT extern "C" __global__ void __launch_bounds__(BLOCK, CT_WAVES_PER_SIMD)
 
 // ---------------------------------------------------------------- kernel prototypes
 // Definitions live in kernels_{varbase,verify,fixed,misc}.hip (separate translation units so the
@@ -503,7 +374,7 @@ constexpr int CT_WAVES_PER_SIMD = GD_CT_WAVES_PER_SIMD;
 // (no __restrict__ on an output the host runtime aliases with an input: out/base, out/b2, out1/base, out/a)
 GD_KERNEL k_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar, uint32_t n,
                             uint4 *__restrict__ workspace);
-GD_KERNEL_CT k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
+GD_KERNEL k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
                                   uint32_t n, uint4 *__restrict__ workspace);
 // one operation per WAVE (wave_coop.hpp): the small-batch / single-call path
 extern "C" __global__ void k_point_scalarmul_wave(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
@@ -548,7 +419,7 @@ GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__
 GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                              const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                              uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt);
-GD_KERNEL_CT k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                    uint4 *__restrict__ workspace);
 GD_KERNEL k_point_encode_eddsa_shared(uint8_t *__restrict__ enc, const uint64_t *__restrict__ pts, uint32_t n,
@@ -584,14 +455,13 @@ GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__
                              const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
                              int allow_identity, int short_circuit, uint4 *__restrict__ workspace,
                              const uint64_t *__restrict__ point_base_abi);
-GD_KERNEL_CT k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
-                                   const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
-                                   int allow_identity, int short_circuit, uint4 *__restrict__ workspace,
-                                   const uint64_t *__restrict__ point_base_abi);
+GD_KERNEL k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                                const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
+                                int allow_identity, int short_circuit, const uint64_t *__restrict__ point_base_abi);
 GD_KERNEL k_point_dual_scalarmul(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
                                  const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                  uint4 *__restrict__ workspace);
-GD_KERNEL_CT k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
+GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
                                        const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                        uint4 *__restrict__ workspace);
 GD_KERNEL k_point_from_hash(uint64_t *__restrict__ out, const uint8_t *__restrict__ hash, uint32_t n, int uniform);

@@ -1,33 +1,31 @@
-// kernels_varbase_ct.hip -- the index-independent variants of the variable-base kernels (every table
-// lookup scans the whole table: ScanTable in kernels.hpp); the library's default for every entry point
-// whose scalar may be secret.  Bodies in varbase_bodies.hpp.
+// kernels_varbase_ct.hip -- the index-independent variants of the variable-base kernels: no table at all, a
+// Montgomery ladder of selects (montgomery.hpp); the library's default for every entry point whose scalar may be
+// secret.  Bodies in varbase_bodies.hpp.
 #include "varbase_bodies.hpp"
 
 namespace gd {
 
-GD_KERNEL_CT k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
-                                  uint32_t n, uint4 *__restrict__ workspace) {
+GD_KERNEL k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
+                               uint32_t n, uint4 *__restrict__ workspace) {
     point_scalarmul_ladder_body(out, base, scalar, n, workspace);
 }
 
-GD_KERNEL_CT k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
-                                   const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
-                                   int allow_identity, int short_circuit, uint4 *__restrict__ workspace,
-                                   const uint64_t *__restrict__ point_base_abi) {
-    direct_scalarmul_body<true>(scaled, status, base, scalar, n, allow_identity, short_circuit, workspace,
-                                point_base_abi);
+GD_KERNEL k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                                const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
+                                int allow_identity, int short_circuit, const uint64_t *__restrict__ point_base_abi) {
+    direct_scalarmul_ladder_body(scaled, status, base, scalar, n, allow_identity, short_circuit, point_base_abi);
 }
 
-GD_KERNEL_CT k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
-                                       const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
-                                       uint4 *__restrict__ workspace) {
-    point_dual_scalarmul_body<true>(out1, out2, base, s1, s2, n, workspace);
+GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
+                                    const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
+                                    uint4 *__restrict__ workspace) {
+    point_dual_scalarmul_ladder_body(out1, out2, base, s1, s2, n, workspace);
 }
 
-GD_KERNEL_CT k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
-                                   const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
-                                   uint4 *__restrict__ workspace) {
-    double_scalarmul_body<true>(out, b1, s1, b2, s2, n, workspace, nullptr);
+GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+                                const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
+                                uint4 *__restrict__ workspace) {
+    double_scalarmul_ladder_body(out, b1, s1, b2, s2, n, workspace);
 }
 
 }  // namespace gd

@@ -1,17 +1,13 @@
 // kernels_verify.hip -- kernel definitions (see kernels.hpp for the memory plan and policies).
 #include "varbase_bodies.hpp"
 
-#ifndef GD_VERIFY_TABLES
-#define GD_VERIFY_TABLES 1
-#endif
-
 namespace gd {
 
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i]; b1 == nullptr: b1 is the base point (its 16-bit window table)
 GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                              const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                              uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt) {
-    double_scalarmul_body<false>(out, b1, s1, b2, s2, n, workspace, bwt);
+    double_scalarmul_body(out, b1, s1, b2, s2, n, workspace, bwt);
 }
 
 // test hook: the short pair (rho, tau) of verification's half-size scalars for challenge h[i] (lattice.hpp)
@@ -46,16 +42,9 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
     // Half-size scalars (lattice.hpp): A and R share one ladder of 45 windows; two tables per lane.  The loop is
     // wave-uniform: a lane without a signature of its own in the last round verifies the batch's last one once more
     // and stores nothing.
-#if GD_VERIFY_TABLES == 2   // wave-cooperative stores
-    __shared__ uint4 s_xpose[(BLOCK / 64) * XPOSE_U4];
-    CoopLaneTable a_tab = coop_table_at(workspace, 0, 2, s_xpose), r_tab = coop_table_at(workspace, 1, 2, s_xpose);
-#elif GD_VERIFY_TABLES == 1   // the build's step in LDS
-    __shared__ uint4 s_step[STEP_LDS_U4];
-    LdsStepTable a_tab{VarTable<false>::at(workspace, 0, 2).p, s_step + threadIdx.x},
-                 r_tab{VarTable<false>::at(workspace, 1, 2).p, s_step + threadIdx.x};
-#else
-    LaneTable a_tab = VarTable<false>::at(workspace, 0, 2), r_tab = VarTable<false>::at(workspace, 1, 2);
-#endif
+    __shared__ uint4 s_step[STEP_LDS_U4];   // the table builds' step (LdsStepTable)
+    LdsStepTable a_tab{lane_table_at(workspace, 0, 2).p, s_step + threadIdx.x},
+                 r_tab{lane_table_at(workspace, 1, 2).p, s_step + threadIdx.x};
     const uint32_t rounds = (n + stride - 1) / stride;
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t slot = lane + r * stride;

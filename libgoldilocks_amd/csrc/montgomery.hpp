@@ -55,11 +55,10 @@ GD_FN void ml_step(fe &x2, fe &z2, fe &x3, fe &z3, const fe &x1) {
 }
 
 // bits.word(k): k-th 32-bit word of the scalar, already reduced mod q (446 bits).
-// b: the base point; di = 1/(Y - Z) (anything if Y = Z).
+// b: the base point; x1 = u(P) = (Y + Z)/(Y - Z) in affine form (anything if P is the identity or (0,-1)).
 template <class BITS>
-GD_FN pt ml_scalarmul(const pt &b, const fe &di, const BITS &bits) {
+GD_FN pt ml_scalarmul_u(const pt &b, const fe &x1, const BITS &bits) {
     const fe yz = fe_add(b.y, b.z);                 // Y + Z                  mag 2
-    const fe x1 = fe_mul(yz, di);                   // u(P) = (Y + Z)/(Y - Z)
     fe x2 = fe_one(), z2 = fe_zero(), x3 = x1, z3 = fe_one();
     bool swap = false;
 #pragma unroll 1
@@ -113,6 +112,11 @@ GD_FN pt ml_scalarmul(const pt &b, const fe &di, const BITS &bits) {
     r.z = fe_select(r.z, id.z, ident);
     r.t = fe_select(r.t, id.t, ident);
     return r;
+}
+// ... given di = 1/(Y - Z) (anything if Y = Z): what a kernel that shares its inversions has at hand
+template <class BITS>
+GD_FN pt ml_scalarmul(const pt &b, const fe &di, const BITS &bits) {
+    return ml_scalarmul_u(b, fe_mul(fe_add(b.y, b.z), di), bits);
 }
 
 }  // namespace gd

@@ -207,6 +207,49 @@ GD_FN bool pt_decode_words(pt &p, const uint32_t in[14], bool allow_identity) {
     return ok;
 }
 
+// -1/156324 mod p = -1/(4 d' + 4) ... the constant of u(P) below
+GD_CONST uint32_t NEG_INV_156324[16] = {0x157aa51u, 0xf0cf349u, 0x1278ef6u, 0xd9a3e9cu, 0x0594bdfu, 0xdfb66ccu,
+                                        0x618ccd8u, 0x2fb57b4u, 0xfd93896u, 0x56bc321u, 0xe7aa36fu, 0x174cd4au,
+                                        0x1cf5b23u, 0x39836c3u, 0x8e03c94u, 0xca1d2d0u};
+// Decaf decoding that also hands out u(P) = (y + 1)/(y - 1), the affine Montgomery coordinate the table-free
+// ladder starts from (montgomery.hpp), WITHOUT a second exponentiation.  With m = num den^2 the decoder's root
+// is isr(m); here j = isr(m s^4) = isr(m)/s^2 exactly (the exponentiation is multiplicative and s^(p-3) = s^-2),
+// so isr(m) = j s^2 -- the reference's value, bit for bit -- and 1/s^2 = j isr(m) m comes with it.  Then
+//     y = ynum/sqrt(num), sqrt(num) = num tmp:   u = (ynum + num tmp)^2 / (ynum^2 - num),   ynum^2 - num = -156324 s^2.
+// s = 0 (the identity, if allowed): u = 0, and the ladder's own test on X = 0 takes over.
+GD_FN bool pt_decode_words_u(pt &p, fe &u, const uint32_t in[14], bool allow_identity) {
+    fe s;
+    bool ok = fe_deserialize_words(s, in);
+    ok = ok && (allow_identity || !fe_is_zero(s));
+    ok = ok && !fe_lobit(s);
+    fe s2 = fe_sqr(s);
+    fe den = fe_weak(fe_sub<2>(fe_one(), s2));          // 1 - s^2
+    fe ynum = fe_add(fe_one(), s2);                     // 1 + s^2   mag 2
+    fe den2 = fe_sqr(den);
+    fe num = fe_weak(fe_add(den2, fe_mulw(s2, FOUR_EFF_D)));  // den^2 - 4 d' s^2
+    const fe m = fe_mul(num, den2);
+    bool sq;
+    const fe j = fe_isr(fe_mul(m, fe_sqr(s2)), &sq);
+    sq = sq || fe_is_zero(s);                           // s = 0: m = 1 is a square, m s^4 = 0 says nothing
+    const fe isr = fe_select(fe_mul(j, s2), fe_one(), fe_is_zero(s));   // isr(1) = 1
+    ok = ok && sq;
+    const fe inv_s2 = fe_mul(fe_mul(j, isr), m);        // 1/s^2  (0 for s = 0)
+    fe tmp = fe_mul(isr, den);
+    p.y = fe_mul(tmp, ynum);
+    fe w = fe_mul(tmp, s);
+    w = fe_add(w, w);                                   // 2 s isr den   mag 2
+    p.x = fe_mul(fe_mul(w, isr), num);
+    p.x = fe_weak(fe_cond_neg(p.x, fe_lobit(fe_mul(w, fe_factor()))));
+    p.z = fe_one();
+    p.t = fe_mul(p.x, p.y);
+    const fe top = fe_sqr(fe_weak(fe_add(ynum, fe_mul(num, tmp))));    // (ynum + sqrt(num))^2
+    fe k;
+#pragma unroll
+    for (int i = 0; i < 16; i++) k.v[i] = NEG_INV_156324[i];
+    u = fe_mul(fe_mul(top, inv_s2), k);
+    return ok;
+}
+
 // RFC 8032 decoding followed by the 4-isogeny onto the twisted curve
 // (src/goldilocks.c:949-1004).  in: 57 bytes as 15 words (top 3 bytes of word 14 unused).  In three parts so
 // that two decodings can share one instruction stream through their exponentiation (pt_decode_eddsa_words2).

@@ -13,8 +13,8 @@
 //   BITS  : bits.word(k) -> k-th 32-bit word of s' (k < 15, word 14 is zero)
 //   TABLE : table.store(k, pniels) / table.load(k) for the per-lane window table, table.put_step(pniels) /
 //           table.step() for the one value the build re-reads (k is public there);
-//           table.lookup(idx) is the read of a digit's entry -- direct, or index-independent (a scan
-//           of every entry, kernels.hpp ScanTable)
+//           table.lookup(idx) is the read of a digit's entry (public digits only: scalars that may be secret
+//           are multiplied without a table, montgomery.hpp)
 #pragma once
 #include "point.hpp"
 #include "sc14.hpp"
@@ -41,20 +41,16 @@ GD_FN void signed_digit_w(uint32_t w, uint32_t &idx, bool &neg) {
 }
 GD_FN void signed_digit(uint32_t w, uint32_t &idx, bool &neg) { signed_digit_w<5>(w, idx, neg); }
 
-// The variable-base ladder comes in two widths.  W = 5 is the reference's (90 windows, 16 table
-// entries, src/goldilocks.c:405-465).  W = 4 (112 windows, 8 entries) costs 22 more additions and
-// saves 8 table entries -- about 4 % more field multiplications -- but halves the table, which is
-// what the index-independent lookup (every entry read for every digit, constant_time.h:134-183)
-// pays for: see ScanTable in kernels.hpp.  Both walk s' = (s + 2^(W*NW) - 1)/2 mod q.
+// The reference's window plan: signed 5-bit windows, 90 of them, 16 table entries (src/goldilocks.c:405-465).
 template <int W>
 struct window_plan {
-    static_assert(W == 4 || W == 5, "recoding constants exist for 4- and 5-bit windows");
+    static_assert(W == 5, "the recoding constant exists for 5-bit windows");
     static constexpr int ENTRIES = 1 << (W - 1);
-    static constexpr int WINDOWS = (446 + W - 1) / W;            // 112 or 90
-    static constexpr int TOP = W * (WINDOWS - 1);                 // 444 or 445
+    static constexpr int WINDOWS = (446 + W - 1) / W;             // 90
+    static constexpr int TOP = W * (WINDOWS - 1);                 // 445
 };
 template <int W>
-GD_FN sc sc_recode_window(const sc &s) { return W == 5 ? sc_recode_signed(s) : sc_recode_signed8(s); }
+GD_FN sc sc_recode_window(const sc &s) { return sc_recode_signed(s); }
 
 // multiples[k] = (2k+1)*B, k < 2^(W-1), as projective niels (src/goldilocks.c:382-403).
 // The step 2B does not stay in registers next to the accumulator (that spills): the policy parks it

@@ -1,10 +1,12 @@
-// varbase_bodies.hpp -- bodies of the kernels that multiply a caller's point by a scalar, as
-// templates on the table-access policy; instantiated by kernels_varbase.hip / kernels_verify.hip
-// (CT = false: the digit picks the address of its entry in the lane's table, 5-bit windows) and
-// kernels_varbase_ct.hip (CT = true: every lookup scans the whole table, 4-bit windows; the
-// counterpart of the reference's constant_time_lookup, src/include/constant_time.h:134-183, which
-// goldilocks_448_point_scalarmul / _double_scalarmul / _dual_scalarmul / direct_scalarmul all use,
-// src/goldilocks.c:437-442, :500-520, :590-610).
+// varbase_bodies.hpp -- bodies of the kernels that multiply a caller's point by a scalar, in two families:
+//   * digit-addressed window tables (5-bit signed windows, the digit picks the address of its entry in the
+//     lane's table): public scalars -- verification, base_double_scalarmul_non_secret, or a caller who asked for
+//     GOLDILOCKS_AMD_TABLES_FAST.  Instantiated by kernels_varbase.hip / kernels_verify.hip.
+//   * NO table at all (montgomery.hpp: a Montgomery ladder of selects): the library's default for every entry
+//     point whose scalar may be secret -- the counterpart of the reference's constant_time_lookup
+//     (src/include/constant_time.h:134-183), which goldilocks_448_point_scalarmul / _double_scalarmul /
+//     _dual_scalarmul / direct_scalarmul all use (src/goldilocks.c:437-442, :500-520, :590-610).
+//     Instantiated by kernels_varbase_ct.hip.
 #pragma once
 #include "kernels.hpp"
 #include "fixed_bodies.hpp"
@@ -12,58 +14,26 @@
 
 namespace gd {
 
-template <bool CT>
-struct VarTable;
-template <>
-struct VarTable<false> {
-    static constexpr int W = 5;
-    using type = LaneTable;
-    // table `which` of `ntab` tables of this lane
-    static __device__ __forceinline__ type at(uint4 *ws, int which, int ntab) {
-        const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-        return type{ws + ((size_t)lane * ntab + which) * TABLE_U4};
-    }
-};
-// the same tables with wave-cooperative stores (CoopLaneTable): for kernels whose table code runs wave-uniformly
-__device__ __forceinline__ CoopLaneTable coop_table_at(uint4 *ws, int which, int ntab, uint4 *xpose) {
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x, l = threadIdx.x & 63u;
-    uint4 *mine = ws + ((size_t)lane * ntab + which) * TABLE_U4;
-    return CoopLaneTable{mine, mine - (size_t)l * ntab * TABLE_U4, (uint32_t)(ntab * TABLE_U4),
-                         xpose + (threadIdx.x >> 6) * XPOSE_U4};
+// table `which` of the `ntab` digit-addressed tables of this lane
+__device__ __forceinline__ LaneTable lane_table_at(uint4 *ws, int which, int ntab) {
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    return LaneTable{ws + ((size_t)lane * ntab + which) * TABLE_U4};
 }
-#ifndef GD_CT_WINDOW
-#define GD_CT_WINDOW 4
-#endif
-template <>
-struct VarTable<true> {
-    static constexpr int W = GD_CT_WINDOW;
-    static constexpr int ENTRIES = window_plan<W>::ENTRIES;
-    using type = ScanTable<ENTRIES>;
-    static __device__ __forceinline__ type at(uint4 *ws, int which, int ntab) {
-        const uint32_t wave = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6);
-        return type{ws + ((size_t)wave * ntab + which) * scan_table_wave_u4<ENTRIES>() + (threadIdx.x & 63u)};
-    }
-};
-// uint4 of workspace per resident lane and table
-template <bool CT>
-constexpr int var_table_lane_u4() { return CT ? scan_table_wave_u4<VarTable<true>::ENTRIES>() / 64 : TABLE_U4; }
 
-// config 2 with digit-addressed tables (public scalars): scaled[i] = scalar[i] * base[i]
-// (ref: goldilocks_448_point_scalarmul).  out may alias base (the host-array path multiplies in place): no
-// __restrict__ on that pair.
+// ================================================================== digit-addressed tables (public scalars)
+
+// config 2: scaled[i] = scalar[i] * base[i]   (ref: goldilocks_448_point_scalarmul).
+// out may alias base (the host-array path multiplies in place): no __restrict__ on that pair.
 __device__ __forceinline__ void point_scalarmul_body(uint64_t *out, const uint64_t *base,
                                                      const uint64_t *__restrict__ scalar, uint32_t n,
                                                      uint4 *__restrict__ workspace) {
-    constexpr bool CT = false;
-    constexpr int W = VarTable<CT>::W;
     __shared__ uint32_t s_bits[15 * BLOCK];
-    constexpr int STAGE_U4 = WAVE_STAGE_U4;
-    __shared__ uint4 s_stage[(BLOCK / 64) * STAGE_U4];
+    __shared__ uint4 s_stage[(BLOCK / 64) * WAVE_STAGE_U4];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
     const uint32_t l = threadIdx.x & 63u;
-    uint4 *stage = s_stage + (threadIdx.x >> 6) * STAGE_U4;
-    auto tab = VarTable<CT>::at(workspace, 0, 1);
+    uint4 *stage = s_stage + (threadIdx.x >> 6) * WAVE_STAGE_U4;
+    LaneTable tab = lane_table_at(workspace, 0, 1);
     // wave-uniform loop: the 64 lanes of a wave own 64 consecutive operations per round
     for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {
         const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
@@ -71,13 +41,98 @@ __device__ __forceinline__ void point_scalarmul_body(uint64_t *out, const uint64
         const sc k = wave_load_scalars(stage, scalar, i0, m, l);
         pt r = b;
         if (l < m) {
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(k));
-            build_window_table_w<W>(tab, b);
-            r = ladder_varbase_w<W>(bits, tab);
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(k));
+            build_window_table(tab, b);
+            r = ladder_varbase(bits, tab);
         }
         wave_store_points(stage, out, i0, m, l, r);
     }
 }
+
+// "next" row f2: wire-format scalarmul, 56 bytes in / 56 bytes out   (ref: goldilocks_448_direct_scalarmul)
+__device__ __forceinline__ void direct_scalarmul_body(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                                                      const uint8_t *__restrict__ base,
+                                                      const uint64_t *__restrict__ scalar, uint32_t n,
+                                                      int allow_identity, int short_circuit,
+                                                      uint4 *__restrict__ workspace,
+                                                      const uint64_t *__restrict__ point_base_abi) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    LaneTable tab = lane_table_at(workspace, 0, 1);
+    for (uint32_t i = lane; i < n; i += stride) {
+        uint32_t w[14];
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(base + 56 * (size_t)i);
+#pragma unroll
+        for (int k = 0; k < 14; k++) w[k] = src[k];
+        pt b;
+        bool ok = pt_decode_words(b, w, allow_identity != 0);
+        status[i] = ok ? -1 : 0;
+        if (!ok && short_circuit) continue;         // the encoding is public: so is this branch
+        if (!ok) b = pt_load_abi(point_base_abi);   // src/goldilocks.c:898: multiply the base point instead
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(scalar + 7 * (size_t)i)));
+        build_window_table(tab, b);
+        pt r = ladder_varbase(bits, tab);
+        pt_encode_words(w, r);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(scaled + 56 * (size_t)i);
+#pragma unroll
+        for (int k = 0; k < 14; k++) dst[k] = w[k];
+    }
+}
+
+// "next" row f4: (s1*B, s2*B) for one base   (ref: goldilocks_448_point_dual_scalarmul)
+// out1 may alias base.
+__device__ __forceinline__ void point_dual_scalarmul_body(uint64_t *out1, uint64_t *__restrict__ out2,
+                                                          const uint64_t *base, const uint64_t *__restrict__ s1,
+                                                          const uint64_t *__restrict__ s2, uint32_t n,
+                                                          uint4 *__restrict__ workspace) {
+    __shared__ uint32_t s_bits[30 * BLOCK];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    LaneTable tab = lane_table_at(workspace, 0, 1);
+    for (uint32_t i = lane; i < n; i += stride) {
+        LdsBits b1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(s1 + 7 * (size_t)i)));
+        LdsBits b2 = lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_signed(sc_load_abi(s2 + 7 * (size_t)i)));
+        build_window_table(tab, pt_load_abi(base + 32 * (size_t)i));
+        pt r1, r2;
+        ladder_dual(r1, r2, b1, b2, tab);
+        pt_store_abi(out1 + 32 * (size_t)i, r1);
+        pt_store_abi(out2 + 32 * (size_t)i, r2);
+    }
+}
+
+// combo[i] = s1[i]*b1[i] + s2[i]*b2[i]   (ref: goldilocks_448_point_double_scalarmul, src/goldilocks.c:467-541).
+// b1 == nullptr: b1 is the base point -- goldilocks_448_base_double_scalarmul_non_secret, public scalars by
+// contract (src/goldilocks.c:1260-1330): s2*b2 by the one-table ladder, then s1*B as 28 additions from the base
+// point's 16-bit window table onto the same accumulator (no doublings for the base point's half).
+// out may alias b2.
+__device__ __forceinline__ void double_scalarmul_body(uint64_t *out, const uint64_t *__restrict__ b1,
+                                                      const uint64_t *__restrict__ s1, const uint64_t *b2,
+                                                      const uint64_t *__restrict__ s2, uint32_t n,
+                                                      uint4 *__restrict__ workspace,
+                                                      const uint4 *__restrict__ bwt) {
+    __shared__ uint32_t s_bits[30 * BLOCK];
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    LaneTable t2 = lane_table_at(workspace, 0, 2), t1 = lane_table_at(workspace, 1, 2);
+    for (uint32_t i = lane; i < n; i += stride) {
+        LdsBits bits2 = lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_signed(sc_load_abi(s2 + 7 * (size_t)i)));
+        build_window_table(t2, pt_load_abi(b2 + 32 * (size_t)i));
+        pt r;
+        if (b1) {  // uniform
+            LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(s1 + 7 * (size_t)i)));
+            build_window_table(t1, pt_load_abi(b1 + 32 * (size_t)i));
+            r = ladder_double(bits1, t1, bits2, t2);
+        } else {
+            r = ladder_varbase(bits2, t2);
+            LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(sc_load_abi(s1 + 7 * (size_t)i)));
+            ladder_bwt_onto(r, bits1, GlobalBwt{bwt});
+        }
+        pt_store_abi(out + 32 * (size_t)i, r);
+    }
+}
+
+// ================================================================== no table: the Montgomery ladder (secret scalars)
 
 // config 2, index-independent (the library default): scaled[i] = scalar[i] * base[i] by the table-free
 // Montgomery ladder of montgomery.hpp   (ref: goldilocks_448_point_scalarmul, constant time there:
@@ -132,101 +187,94 @@ __device__ __forceinline__ void point_scalarmul_ladder_body(uint64_t *out, const
     for (int k = 0; k < WAVE_STAGE_U4 / 64; k++) stage[k * 64 + l] = make_uint4(0, 0, 0, 0);
 }
 
-// "next" row f2: wire-format scalarmul, 56 bytes in / 56 bytes out   (ref: goldilocks_448_direct_scalarmul)
-template <bool CT>
-__device__ __forceinline__ void direct_scalarmul_body(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
-                                                      const uint8_t *__restrict__ base,
-                                                      const uint64_t *__restrict__ scalar, uint32_t n,
-                                                      int allow_identity, int short_circuit,
-                                                      uint4 *__restrict__ workspace,
-                                                      const uint64_t *__restrict__ point_base_abi) {
-    constexpr int W = VarTable<CT>::W;
+// "next" row f2, index-independent: decode, ladder, encode.  The decoder hands out u(P) with the point (one
+// exponentiation for both, point.hpp pt_decode_words_u), so this kernel needs no shared inversion and no workspace.
+__device__ __forceinline__ void direct_scalarmul_ladder_body(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+                                                             const uint8_t *__restrict__ base,
+                                                             const uint64_t *__restrict__ scalar, uint32_t n,
+                                                             int allow_identity, int short_circuit,
+                                                             const uint64_t *__restrict__ point_base_abi) {
     __shared__ uint32_t s_bits[15 * BLOCK];
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
-    auto tab = VarTable<CT>::at(workspace, 0, 1);
     for (uint32_t i = lane; i < n; i += stride) {
         uint32_t w[14];
         const uint32_t *src = reinterpret_cast<const uint32_t *>(base + 56 * (size_t)i);
 #pragma unroll
         for (int k = 0; k < 14; k++) w[k] = src[k];
         pt b;
-        bool ok = pt_decode_words(b, w, allow_identity != 0);
+        fe u;
+        const bool ok = pt_decode_words_u(b, u, w, allow_identity != 0);
         status[i] = ok ? -1 : 0;
         if (!ok && short_circuit) continue;         // the encoding is public: so is this branch
-        if (!ok) b = pt_load_abi(point_base_abi);   // src/goldilocks.c:898: multiply the base point instead
-        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(sc_load_abi(scalar + 7 * (size_t)i)));
-        build_window_table_w<W>(tab, b);
-        pt r = ladder_varbase_w<W>(bits, tab);
+        if (!ok) {                                  // src/goldilocks.c:898: multiply the base point instead
+            b = pt_load_abi(point_base_abi);
+            u = fe_mul(fe_add(b.y, b.z), fe_invert(ml_denominator(b)));
+        }
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(scalar + 7 * (size_t)i)));
+        const pt r = ml_scalarmul_u(b, u, bits);
         pt_encode_words(w, r);
         uint32_t *dst = reinterpret_cast<uint32_t *>(scaled + 56 * (size_t)i);
 #pragma unroll
         for (int k = 0; k < 14; k++) dst[k] = w[k];
     }
-    if (CT) lds_wipe_lane(s_bits + threadIdx.x, 15);
+    lds_wipe_lane(s_bits + threadIdx.x, 15);
 }
 
-// "next" row f4: (s1*B, s2*B) for one base   (ref: goldilocks_448_point_dual_scalarmul)
-// out1 may alias base.
-template <bool CT>
-__device__ __forceinline__ void point_dual_scalarmul_body(uint64_t *out1, uint64_t *__restrict__ out2,
-                                                          const uint64_t *base, const uint64_t *__restrict__ s1,
-                                                          const uint64_t *__restrict__ s2, uint32_t n,
-                                                          uint4 *__restrict__ workspace) {
-    constexpr int W = VarTable<CT>::W;
-    __shared__ uint32_t s_bits[30 * BLOCK];
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    auto tab = VarTable<CT>::at(workspace, 0, 1);
-    for (uint32_t i = lane; i < n; i += stride) {
-        LdsBits b1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(sc_load_abi(s1 + 7 * (size_t)i)));
-        LdsBits b2 = lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_window<W>(sc_load_abi(s2 + 7 * (size_t)i)));
-        build_window_table_w<W>(tab, pt_load_abi(base + 32 * (size_t)i));
-        pt r1, r2;
-        ladder_dual_w<W>(r1, r2, b1, b2, tab);
+// "next" row f4, index-independent: two ladders from one u(P); the inversion behind it is shared along the lane
+// as in the headline kernel (ML_SLOT_U4 uint4 of workspace per operation).  out1 may alias base.
+__device__ __forceinline__ void point_dual_scalarmul_ladder_body(uint64_t *out1, uint64_t *__restrict__ out2,
+                                                                 const uint64_t *base, const uint64_t *__restrict__ s1,
+                                                                 const uint64_t *__restrict__ s2, uint32_t n,
+                                                                 uint4 *__restrict__ workspace) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    InvChain ch;
+    ch.begin();
+    for_each_op<true>(n, [&](uint32_t i, bool live) {
+        ch.push(workspace + (size_t)ML_SLOT_U4 * i, ml_denominator(pt_load_abi(base + 32 * (size_t)i)), live);
+    });
+    ch.invert();
+    for_each_op_reverse(n, [&](uint32_t i) {
+        const pt b = pt_load_abi(base + 32 * (size_t)i);
+        const fe u = fe_mul(fe_add(b.y, b.z), ch.pop(workspace + (size_t)ML_SLOT_U4 * i));
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s1 + 7 * (size_t)i)));
+        const pt r1 = ml_scalarmul_u(b, u, bits);
+        bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s2 + 7 * (size_t)i)));
+        const pt r2 = ml_scalarmul_u(b, u, bits);
         pt_store_abi(out1 + 32 * (size_t)i, r1);
         pt_store_abi(out2 + 32 * (size_t)i, r2);
-    }
-    if (CT) lds_wipe_lane(s_bits + threadIdx.x, 30);
+    });
+    lds_wipe_lane(s_bits + threadIdx.x, 15);
 }
 
-// combo[i] = s1[i]*b1[i] + s2[i]*b2[i]   (ref: goldilocks_448_point_double_scalarmul, constant time there:
-// src/goldilocks.c:467-541).  b1 == nullptr (CT = false only): b1 is the base point --
-// goldilocks_448_base_double_scalarmul_non_secret, public scalars by contract (src/goldilocks.c:1260-1330):
-// s2*b2 by the one-table ladder, then s1*B as 28 additions from the base point's 16-bit window table onto the
-// same accumulator (no doublings for the base point's half).
-// out may alias b2.
-template <bool CT>
-__device__ __forceinline__ void double_scalarmul_body(uint64_t *out, const uint64_t *__restrict__ b1,
-                                                      const uint64_t *__restrict__ s1, const uint64_t *b2,
-                                                      const uint64_t *__restrict__ s2, uint32_t n,
-                                                      uint4 *__restrict__ workspace,
-                                                      const uint4 *__restrict__ bwt) {
-    constexpr int W = VarTable<CT>::W;
-    __shared__ uint32_t s_bits[30 * BLOCK];
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    auto t2 = VarTable<CT>::at(workspace, 0, 2);
-    auto t1 = VarTable<CT>::at(workspace, 1, 2);
-    for (uint32_t i = lane; i < n; i += stride) {
-        LdsBits bits2 =
-            lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_window<W>(sc_load_abi(s2 + 7 * (size_t)i)));
-        build_window_table_w<W>(t2, pt_load_abi(b2 + 32 * (size_t)i));
-        pt r;
-        if (CT || b1) {  // uniform
-            LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_window<W>(sc_load_abi(s1 + 7 * (size_t)i)));
-            build_window_table_w<W>(t1, pt_load_abi(b1 + 32 * (size_t)i));
-            r = ladder_double_w<W>(bits1, t1, bits2, t2);
-        } else {
-            if constexpr (!CT) {
-                r = ladder_varbase_w<W>(bits2, t2);
-                LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(sc_load_abi(s1 + 7 * (size_t)i)));
-                ladder_bwt_onto(r, bits1, GlobalBwt{bwt});
-            }
-        }
-        pt_store_abi(out + 32 * (size_t)i, r);
-    }
-    if (CT) lds_wipe_lane(s_bits + threadIdx.x, 30);
+// combo[i] = s1[i]*b1[i] + s2[i]*b2[i], index-independent: two ladders and one addition; both denominators of an
+// operation go into the lane's chain (2 * ML_SLOT_U4 uint4 of workspace per operation).  out may alias b2.
+__device__ __forceinline__ void double_scalarmul_ladder_body(uint64_t *out, const uint64_t *__restrict__ b1,
+                                                             const uint64_t *__restrict__ s1, const uint64_t *b2,
+                                                             const uint64_t *__restrict__ s2, uint32_t n,
+                                                             uint4 *__restrict__ workspace) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    InvChain ch;
+    ch.begin();
+    for_each_op<true>(n, [&](uint32_t i, bool live) {
+        uint4 *slot = workspace + (size_t)(2 * ML_SLOT_U4) * i;
+        ch.push(slot, ml_denominator(pt_load_abi(b1 + 32 * (size_t)i)), live);
+        ch.push(slot + ML_SLOT_U4, ml_denominator(pt_load_abi(b2 + 32 * (size_t)i)), live);
+    });
+    ch.invert();
+    for_each_op_reverse(n, [&](uint32_t i) {
+        const uint4 *slot = workspace + (size_t)(2 * ML_SLOT_U4) * i;
+        const pt q = pt_load_abi(b2 + 32 * (size_t)i);           // popped in the reverse order of the pushes
+        const fe uq = fe_mul(fe_add(q.y, q.z), ch.pop(slot + ML_SLOT_U4));
+        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s2 + 7 * (size_t)i)));
+        const pt rq = ml_scalarmul_u(q, uq, bits);
+        const pt p = pt_load_abi(b1 + 32 * (size_t)i);
+        const fe up = fe_mul(fe_add(p.y, p.z), ch.pop(slot));
+        bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s1 + 7 * (size_t)i)));
+        const pt rp = ml_scalarmul_u(p, up, bits);
+        pt_store_abi(out + 32 * (size_t)i, pt_add(rp, rq, false));
+    });
+    lds_wipe_lane(s_bits + threadIdx.x, 15);
 }
 
 }  // namespace gd

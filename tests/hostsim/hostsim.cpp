@@ -173,16 +173,6 @@ void hs_sc_decode_long(uint64_t *o, const uint8_t *in, size_t len) {
     sc_to_abi(o, sc_decode_long_bytes(in, len));
 }
 
-// 4-bit windows (the ladder the index-independent kernels run): same group element as the 5-bit one
-void hs_point_scalarmul_w4(uint64_t *out, const uint64_t *base, const uint64_t *scalar) {
-    sc r = sc_recode_window<4>(sc_from_abi(scalar));
-    HostBits bits;
-    for (int i = 0; i < 14; i++) bits.w[i] = r.w[i];
-    bits.w[14] = 0;
-    HostTable tab;
-    build_window_table_w<4>(tab, pt_from_abi(base));
-    pt_to_abi(out, ladder_varbase_w<4>(bits, tab));
-}
 // the table-free ladder of the index-independent variable-base kernel (montgomery.hpp)
 void hs_point_scalarmul_ladder(uint64_t *out, const uint64_t *base, const uint64_t *scalar) {
     const pt b = pt_from_abi(base);
@@ -192,10 +182,28 @@ void hs_point_scalarmul_ladder(uint64_t *out, const uint64_t *base, const uint64
     bits.w[14] = 0;
     pt_to_abi(out, ml_scalarmul(b, fe_invert(ml_denominator(b)), bits));
 }
+// wire format in and out through the ladder: the decoder that also yields u(P) (point.hpp pt_decode_words_u)
+int hs_direct_scalarmul_ladder(uint8_t *out, const uint8_t *in, const uint64_t *scalar, int allow_identity) {
+    uint32_t w[14];
+    bytes_to_words(w, in, 56, 14);
+    pt b;
+    fe u;
+    const bool ok = pt_decode_words_u(b, u, w, allow_identity != 0);
+    pt ref;
+    const bool ok2 = pt_decode_words(ref, w, allow_identity != 0);
+    if (ok != ok2 || (ok && !(fe_eq(b.x, ref.x) && fe_eq(b.y, ref.y)))) return 7;   // must be the plain decoder's point exactly
+    const sc r = sc_reduce(sc_from_abi(scalar));
+    HostBits bits;
+    for (int i = 0; i < 14; i++) bits.w[i] = r.w[i];
+    bits.w[14] = 0;
+    pt_encode_words(w, ml_scalarmul_u(b, u, bits));
+    words_to_bytes(out, w, 56);
+    return ok ? -1 : 0;
+}
 // Multiply-accumulates (v_mad_u64_u32 on the device) of one call of a building block; the counts
 // do not depend on the data.  what: 0 fe_mul, 1 fe_sqr, 2 fe_mulw, 3 pt_double, 4 pt_double + T,
 // 5 pt_add_niels + T, 6 niels_to_pt, 7 fe_isr, 8 pt_decode_eddsa, 9 pt_add (full), 10 pt_eq,
-// 11 variable base W = 5 (table + ladder), 12 variable base W = 4, 13 comb ladder, 14 the 4 x 7 x 16 comb ladder,
+// 11 variable base W = 5 (table + ladder), 12 unused, 13 comb ladder, 14 the 4 x 7 x 16 comb ladder,
 // 15 variable base by the Montgomery ladder (with its own inversion)
 void hs_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *scalar);
 void hs_precomputed_scalarmul(uint64_t *out, const uint64_t *table, const uint64_t *scalar);
@@ -222,7 +230,7 @@ unsigned long long hs_mac_count_of(int what, const uint64_t *point, const uint64
     case 9: (void)pt_add(p, q, false); break;
     case 10: (void)pt_eq(p, q); break;
     case 11: hs_point_scalarmul(out, point, scalar); break;
-    case 12: hs_point_scalarmul_w4(out, point, scalar); break;
+    case 12: return 0;   // (was: 4-bit windows of the scan tables, gone with them)
     case 13: hs_precomputed_scalarmul(out, comb_table, scalar); break;
     case 15: hs_point_scalarmul_ladder(out, point, scalar); break;
     case 14: hs_comb_big_scalarmul(out, comb_table, scalar); c = 0; hs_comb_big_scalarmul(out, comb_table, scalar); break;   // the table is built by the first call

@@ -232,27 +232,6 @@ def test_big_comb_of_the_base_point_matches_oracle(H, O):
         assert (_gen.oracle_encode(out.reshape(1, 32))[0] == want[i]).all(), hex(vals[i])
 
 
-def test_four_bit_window_ladder_matches_oracle(H, O):
-    """The 4-bit-window ladder of the index-independent kernels (recoding with 2^448 - 1, 8-entry table)."""
-    rnd = random.Random(9)
-    bases = _gen.oracle_fixed(O, _gen.stream_scalars(12, b"w4/base"))
-    vals = [0, 1, 2, Q - 1, Q - 2, 2**445, 2**444 - 1, 7, 8, 9, 15, 16] 
-    scal = _gen.scalars_from_ints(vals)
-    want = _gen.oracle_encode(_gen.oracle_varbase(O, bases, scal))
-    out = np.empty((12, 32), dtype=np.uint64)
-    for i in range(12):
-        H.hs_point_scalarmul_w4(out[i].ctypes.data_as(C.c_void_p), bases[i].ctypes.data_as(C.c_void_p),
-                                scal[i].ctypes.data_as(C.c_void_p))
-    assert (_gen.oracle_encode(out) == want).all()
-    s2 = _gen.stream_scalars(8, b"w4/rand")
-    b2 = _gen.oracle_fixed(O, _gen.stream_scalars(8, b"w4/base2"))
-    o2 = np.empty((8, 32), dtype=np.uint64)
-    for i in range(8):
-        H.hs_point_scalarmul_w4(o2[i].ctypes.data_as(C.c_void_p), b2[i].ctypes.data_as(C.c_void_p),
-                                s2[i].ctypes.data_as(C.c_void_p))
-    assert (_gen.oracle_encode(o2) == _gen.oracle_encode(_gen.oracle_varbase(O, b2, s2))).all()
-
-
 def test_half_size_pair_of_a_challenge(H):
     """lattice.hpp: (rho, tau) with rho == tau * h (mod q), 0 <= rho < 2^223, 0 < |tau| < 2^223: exactly the
     first pair below 2^223 of the remainder sequence of (q, h), for random and degenerate challenges (0, 1,
