@@ -117,11 +117,22 @@ GD_FN void euclid_step_exact(wide15 &r0, int8w &t0, wide15 &r1, int8w &t1) {
     t1 = tt;
 }
 
-GD_FN double fast_rcp(double v) {   // relative error far below 2^-21 is all that is asked of it
+// The reciprocal behind the single-precision quotient estimate.  Its accuracy affects SPEED ONLY, never the
+// result: the estimate q is corrected by one either way from its remainder, and a step is taken only if the
+// remainders of BOTH bracketing quotients are in range (rem, rem2 below) -- otherwise the inner loop stops and
+// the step is made exactly at full precision.  The device uses v_rcp_f64 (relative error about 2^-23 on this
+// part); the host checker build can perturb its exact 1/v by a relative gd_rcp_perturb() to run the same paths.
+#if !defined(__HIPCC__)
+inline double &gd_rcp_perturb() {
+    static double rel = 0.0;
+    return rel;
+}
+#endif
+GD_FN double fast_rcp(double v) {
 #if defined(__HIPCC__)
     return __builtin_amdgcn_rcp(v);
 #else
-    return 1.0 / v;
+    return (1.0 / v) * (1.0 + gd_rcp_perturb());
 #endif
 }
 

@@ -368,6 +368,9 @@ void hs_half_size_pair(uint32_t *rho, uint32_t *tau, const uint64_t *h) {
     for (int i = 0; i < 8; i++) tau[i] = t.w[i];
 }
 
+// relative error injected into the quotient estimate's reciprocal (lattice.hpp fast_rcp), to emulate v_rcp_f64
+void hs_set_rcp_perturb(double rel) { gd_rcp_perturb() = rel; }
+
 void hs_mac_counter_reset(void) { gf_mac_counter() = 0; }
 unsigned long long hs_mac_counter_get(void) { return gf_mac_counter(); }
 

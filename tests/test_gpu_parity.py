@@ -564,3 +564,43 @@ def test_long_messages_and_contexts(ga, O):
         assert bytes(w) == sig[i].tobytes(), lens[i]
     bad = [m[:-1] + bytes([m[-1] ^ 1]) if m else b"x" for m in msgs]
     assert (ga.ed448_verify_batch(sig, pk, bad, context=ctx) == 0).all()
+
+
+@pytest.mark.parametrize("wave_path", [True, False])
+def test_device_offsets_with_an_oversize_message(ga, O, wave_path):
+    """Messages behind device-resident offsets (msg_offsets != NULL): msg_len is ignored there, so a garbage
+    msg_len must not fail the call; and a lane whose offsets claim GOLDILOCKS_AMD_MAX_MESSAGE_BYTES or more cannot
+    be hashed by the 32-bit byte counters -- signing writes an all-zero signature for it and verification rejects
+    it (include/goldilocks_amd.h), the other lanes are untouched.  The oversize message itself is never read."""
+    import torch
+    n = 4
+    saved = ga.get_wave_batch_max()
+    ga.set_wave_batch_max(saved if wave_path else 0)
+    try:
+        sk = np.frombuffer(_gen.stream(b"oversize/sk", 57 * n), np.uint8).reshape(n, 57).copy()
+        pk = ga.ed448_derive_public_key_batch(sk)
+        msgs = [b"abc", b"", b"0123456789" * 3, b"x"]
+        order = [0, 2, 3, 1]                                   # the oversize lane last: the others keep real bytes
+        blob = np.frombuffer(b"".join(msgs[i] for i in order[:3]), np.uint8).copy()
+        off = np.zeros(n + 1, np.uint64)
+        off[1:4] = np.cumsum([len(msgs[i]) for i in order[:3]])
+        off[4] = off[3] + np.uint64(0x80000000)              # the last lane: 2^31 "bytes"
+        sk_o, pk_o = sk[order], pk[order]
+        d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        d_sk, d_pk, d_blob = d(sk_o), d(pk_o), d(blob)
+        d_off = torch.from_numpy(off.view(np.int64)).cuda()
+        sig = torch.full((n, 114), 0x55, dtype=torch.uint8, device="cuda")
+        garbage_len = 2**64 - 1                                # ignored when offsets are given
+        ga.dev("ed448_sign", sig.data_ptr(), d_sk.data_ptr(), d_pk.data_ptr(), d_blob.data_ptr(), d_off.data_ptr(),
+               garbage_len, 0, None, 0, n, None)
+        st = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+        ga.dev("ed448_verify", st.data_ptr(), sig.data_ptr(), d_pk.data_ptr(), d_blob.data_ptr(), d_off.data_ptr(),
+               garbage_len, 0, None, 0, n, None)
+        torch.cuda.synchronize()
+        sig_h, st_h = sig.cpu().numpy(), st.cpu().numpy()
+        assert (sig_h[3] == 0).all() and list(st_h) == [-1, -1, -1, 0]
+        want = ga.ed448_sign_batch(sk_o[:3], pk_o[:3], [msgs[i] for i in order[:3]])
+        assert (sig_h[:3] == want).all()
+        assert (_gen.oracle_verify(O, sig_h[:3], pk_o[:3], [msgs[i] for i in order[:3]]) == -1).all()
+    finally:
+        ga.set_wave_batch_max(saved)
