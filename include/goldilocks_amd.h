@@ -340,6 +340,9 @@ GOLDILOCKS_AMD_API int goldilocks_amd_get_table_access(void);   /* the process-w
 #define GOLDILOCKS_AMD_CALL_TABLES_FAST 1u
 #define GOLDILOCKS_AMD_CALL_TABLES_INDEX_INDEPENDENT 2u
 #define GOLDILOCKS_AMD_CALL_TABLES_MASK 3u
+/* Test hook: how many mode-dependent calls of the CALLING THREAD ran with digit-addressed tables (counts[0]) and
+ * index-independently (counts[1]) so far -- what a call's flags and the default resolved to when it launched. */
+GOLDILOCKS_AMD_API void goldilocks_amd_thread_mode_counts(uint64_t counts[2]);
 /* Small batches.  One lane's ladder takes 2.1-2.8 ms however few operations a call has, so batches of
  * up to `n` variable-base, double-base or dual multiplications -- 3n/4 fixed-base multiplications or X448
  * shared secrets, n/2 verifications, wire-format multiplications, key derivations, X448 key generations

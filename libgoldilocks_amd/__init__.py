@@ -83,6 +83,7 @@ FUNCTIONS = {
     "goldilocks_amd_use_devices": (C.c_int, "pi"),
     "goldilocks_amd_set_table_access": (C.c_int, "i"),
     "goldilocks_amd_get_table_access": (C.c_int, ""),
+    "goldilocks_amd_thread_mode_counts": (None, "p"),
     "goldilocks_amd_set_wave_batch_max": (None, "z"),
     "goldilocks_amd_get_wave_batch_max": (C.c_size_t, ""),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
@@ -442,6 +443,13 @@ def get_wave_batch_max():
 
 def get_table_access():
     return lib().goldilocks_amd_get_table_access()
+
+
+def thread_mode_counts():
+    """(fast, index-independent): how the mode-dependent calls of THIS thread resolved so far (test hook)."""
+    c = (C.c_uint64 * 2)()
+    lib().goldilocks_amd_thread_mode_counts(C.addressof(c))
+    return int(c[0]), int(c[1])
 
 
 def device_info():
