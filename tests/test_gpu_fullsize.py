@@ -221,9 +221,18 @@ def test_sharded_host_batches_match_single_device(ga, O):
                 ga.point_encode_batch(want_var[:1])).all()
     finally:
         ga.use_devices(None)
+    # the devices (and the table access) of ONE call, the process-wide list untouched (the *_batch_ex entry points)
+    call_fixed = ga.precomputed_scalarmul_batch(k, devices=[0, 0])
+    call_var = ga.point_scalarmul_batch(call_fixed, s, flags=ga.CALL_TABLES_FAST, devices=[0, 0, 0, 0])
+    call_st = ga.ed448_verify_batch(sigs, pks, msgs, devices=[0, 0, 0])
+    with pytest.raises(ga.GoldilocksAmdError):
+        ga.point_scalarmul_batch(call_fixed, s, devices=[0, 99])
+    with pytest.raises(ga.GoldilocksAmdError):
+        ga.point_scalarmul_batch(call_fixed, s, flags=8)
     # group elements, not raw limbs: a shard of 4 099 operations runs one operation per wave, the
     # unsharded 12 299 one per lane -- different projective representatives of the same points
     enc = ga.point_encode_batch
+    assert (enc(call_fixed) == enc(want_fixed)).all() and (enc(call_var) == enc(want_var)).all() and (call_st == want_st).all()
     assert (enc(got_fixed) == enc(want_fixed)).all() and (enc(got_var) == enc(want_var)).all()
     assert (got_st == want_st).all() and got_st[5] == 0 and got_st[699] == 0 and (got_st == -1).sum() == 698
     assert (ga.point_encode_batch(got_var[:64]) == _gen.oracle_encode(_gen.oracle_varbase(O, want_fixed[:64], s[:64]))).all()

@@ -22,6 +22,10 @@ Q="--no-cpu-baseline --no-configs --no-end-to-end"
 python3 "$BENCH" > "$DST/bench_default.json" 2> "$OUT/bench_default.err"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_default" -- \
     python3 "$BENCH" --steps 5 --warmup 1 > "$OUT/stats_default.log" 2>&1
+# ... and without its end_to_end leg (which runs the same kernels in one-residency chunks): per-kernel averages of
+# full-size launches only, comparable with the line's kernel_ms_avg figures
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_defaultresident" -- \
+    python3 "$BENCH" --steps 5 --warmup 1 --no-end-to-end > "$OUT/stats_defaultresident.log" 2>&1
 
 for wl in varbase fixed base verify sign x448 direct; do
     python3 "$BENCH" --workload $wl $Q > "$DST/bench_$wl.json" 2> "$OUT/bench_$wl.err"
