@@ -596,12 +596,13 @@ def run_rank(args):
         configs = {}
         for key, cname, access in CONFIGS:
             cw = make_workload(cname, cx, access)
-            _, cworst, cms = time_workload(torch, shard, cw, 5, 1, None, None)
+            csteps, cwarm = 8, 3       # (the clocks of an idle GPU take three to four launches to come back up)
+            _, cworst, cms = time_workload(torch, shard, cw, csteps, cwarm, None, None)
             cok, ctext, _ = cw["check"]()
             cavg = sum(cms) / len(cms)
             r = roofline(cname, cw["kernel"], n, cavg, access)
-            configs[key] = {"value": n * 5 / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
-                            "table_access": access, "steps": 5, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
+            configs[key] = {"value": n * csteps / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
+                            "table_access": access, "steps": csteps, "warmup": cwarm, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
                             "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit")},
                             "mac_frac": r["mac"]["frac"] if "mac" in r else None, "check": ctext,
                             "parity_spot_check": "ok" if cok else "FAILED"}
