@@ -191,37 +191,9 @@ GD_FN void shake256_114(uint32_t out[29], const MSG &src, uint32_t total, STAGE 
 // NBYTES-byte little-endian integer (packed in words, unused high bytes zero) mod q: the value of the
 // reference's scalar_decode_long (src/scalar.c:257-293, which folds 56 bytes at a time with Montgomery products:
 // six of them for the 114 bytes of a challenge), computed by folding at the modulus' own size: q = 2^446 - c with
-// c of 224 bits, so x = lo + 2^446 hi == lo + c hi (mod q).  114 bytes shrink 912 -> 691 -> 470 -> 447 bits in three
-// folds (105 + 56 + 7 word products), 57 bytes in one; one conditional subtraction makes the result canonical.
-GD_CONST uint32_t SC_C[7] = {0x54a7bb0du, 0xdc873d6du, 0x723a70aau, 0xde933d8du, 0x5129c96fu, 0x3bb124b6u, 0x8335dc16u};
-// out[NIN' = 14 + ...]: x[NIN] folded once.  NHI = words of x >> 446 that can be nonzero.
-template <int NIN, int NHI, int NOUT>
-GD_FN void sc_fold(uint32_t (&out)[NOUT], const uint32_t (&x)[NIN]) {
-    static_assert(NOUT >= NHI + 8 && NOUT >= 15 && NIN >= 13 + NHI, "sizes");
-    uint32_t xp[NIN + 1], hi[NHI];    // (one zero word of padding: the last shifted read needs no bounds test)
-#pragma unroll
-    for (int k = 0; k <= NIN; k++) xp[k] = k < NIN ? x[k] : 0u;
-#pragma unroll
-    for (int k = 0; k < NHI; k++) hi[k] = xp[13 + k] >> 30 | xp[14 + k] << 2;
-#pragma unroll
-    for (int k = 0; k < NOUT; k++) out[k] = k < 13 ? x[k] : k == 13 ? x[13] & 0x3fffffffu : 0u;
-#pragma unroll
-    for (int i = 0; i < NHI; i++) {     // out += c * hi[i] << (32 i)
-        uint64_t carry = 0;
-#pragma unroll
-        for (int j = 0; j < 7; j++) {
-            carry += (uint64_t)hi[i] * SC_C[j] + out[i + j];
-            out[i + j] = (uint32_t)carry;
-            carry >>= 32;
-        }
-#pragma unroll
-        for (int k = i + 7; k < NOUT; k++) {   // (only the first of these can see a nonzero carry twice in a row)
-            carry += out[k];
-            out[k] = (uint32_t)carry;
-            carry >>= 32;
-        }
-    }
-}
+// c of 224 bits, so x = lo + 2^446 hi == lo + c hi (mod q) (sc14.hpp sc_fold).  114 bytes shrink 912 -> 691 -> 470 ->
+// 447 bits in three folds (105 + 56 + 7 word products), 57 bytes in one; one conditional subtraction makes the
+// result canonical.
 template <int NBYTES>
 GD_FN sc sc_decode_long_words(const uint32_t *w) {
     static_assert(NBYTES == 57 || NBYTES == 72 || NBYTES == 114, "only the shapes EdDSA needs");
@@ -245,11 +217,7 @@ GD_FN sc sc_decode_long_words(const uint32_t *w) {
         for (int i = 0; i < 15; i++) x[i] = w[i];
         sc_fold<15, 1, 15>(y, x);         // 456 bits -> < 2^446 + 2^234
     }
-    sc t;
-#pragma unroll
-    for (int i = 0; i < 14; i++) t.w[i] = y[i];
-    // y < 2^446 + 2^355 < 2 q and y[14] == 0: one conditional subtraction
-    return sc_subx(t, sc_const(SC_Q), 0);
+    return sc_final(y);   // y < 2^446 + 2^355 < 2 q: one conditional subtraction
 }
 
 #if !defined(__HIPCC__)

@@ -1,7 +1,7 @@
 // sc14.hpp -- scalars mod q (q = group order, 446 bits) as 14 x u32 words, one scalar
 // per lane.  Restates what the hot path needs from the reference's src/scalar.c:
-// add (:176-189), sub (:168-174), halve (:316-332), Montgomery product (:55-91),
-// decode_long (:257-293).  None of this is performance critical (< 0.1 % of a
+// add (:176-189), sub (:168-174), halve (:316-332), product and decode_long (:55-100, :257-293: by folding at
+// the modulus' size here instead of Montgomery products -- same values).  None of this is performance critical (< 0.1 % of a
 // scalarmul), so it is written for clarity with 64-bit carries.
 #pragma once
 #include "gf28.hpp"
@@ -16,10 +16,6 @@ struct sc {
 GD_CONST uint32_t SC_Q[14] = {0xab5844f3u, 0x2378c292u, 0x8dc58f55u, 0x216cc272u, 0xaed63690u,
                               0xc44edb49u, 0x7cca23e9u, 0xffffffffu, 0xffffffffu, 0xffffffffu,
                               0xffffffffu, 0xffffffffu, 0xffffffffu, 0x3fffffffu};
-// R^2 mod q, R = 2^448 (src/scalar.c:20-22)
-GD_CONST uint32_t SC_R2[14] = {0x049b9b60u, 0xe3539257u, 0xc1b195d9u, 0x7af32c4bu, 0x88ea1859u,
-                               0x0d66de23u, 0x5ee4d838u, 0xae17cf72u, 0xa3c47c44u, 0x1a9cc14bu,
-                               0xe4d070afu, 0x2052bcb7u, 0xf823b729u, 0x3402a939u};
 // (2^450 - 1) mod q: signed-window recoding offset (src/goldilocks.c:33-37)
 GD_CONST uint32_t SC_ADJ[14] = {0x4a7bb0cfu, 0xc873d6d5u, 0x23a70aadu, 0xe933d8d7u, 0x129c96fdu,
                                 0xbb124b65u, 0x335dc163u, 0x00000008u, 0, 0, 0, 0, 0, 0};
@@ -29,8 +25,6 @@ GD_CONST uint32_t SC_ADJ8[14] = {0x529eec33u, 0x721cf5b5u, 0xc8e9c2abu, 0x7a4cf6
 // (2^456 - 1) mod q: the same for 38 signed 12-bit windows (experiment, -DGD_BWT_BITS=12)
 GD_CONST uint32_t SC_ADJ12[14] = {0x9eec33ffu, 0x1cf5b552u, 0xe9c2ab72u, 0x4cf635c8u, 0xa725bf7au,
                                   0xc492d944u, 0xd77058eeu, 0x0000020cu, 0, 0, 0, 0, 0, 0};
-// -q^-1 mod 2^32 (low word of src/scalar.c:17 MONTGOMERY_FACTOR)
-constexpr uint32_t SC_MONT32 = 0xae918bc5u;
 
 GD_FN sc sc_zero() {
     sc r;
@@ -94,48 +88,75 @@ GD_FN sc sc_halve(const sc &a) {
     return o;
 }
 
-// a*b/2^448 mod q, word-serial Montgomery (src/scalar.c:55-91 with 32-bit words;
-// -q^-1 mod 2^32 is the low half of the 64-bit factor, so the result is the same
-// residue and, after the final conditional subtraction, the same canonical value).
-GD_FN sc sc_montmul(const sc &a, const sc &b) {
-    uint32_t acc[15];
+// Reduction mod q by folding at the modulus' own size: q = 2^446 - c with c of 224 bits, so
+// x = lo + 2^446 hi == lo + c hi (mod q).  (The reference multiplies and reduces with Montgomery products,
+// src/scalar.c:55-100; only values are observable, and these are the same canonical ones.)
+GD_CONST uint32_t SC_C[7] = {0x54a7bb0du, 0xdc873d6du, 0x723a70aau, 0xde933d8du, 0x5129c96fu, 0x3bb124b6u, 0x8335dc16u};
+// out[NIN' = 14 + ...]: x[NIN] folded once.  NHI = words of x >> 446 that can be nonzero.
+template <int NIN, int NHI, int NOUT>
+GD_FN void sc_fold(uint32_t (&out)[NOUT], const uint32_t (&x)[NIN]) {
+    static_assert(NOUT >= NHI + 8 && NOUT >= 15 && NIN >= 13 + NHI, "sizes");
+    uint32_t xp[NIN + 1], hi[NHI];    // (one zero word of padding: the last shifted read needs no bounds test)
 #pragma unroll
-    for (int i = 0; i < 15; i++) acc[i] = 0;
-    uint32_t hi_carry = 0;
-    for (int i = 0; i < 14; i++) {
-        uint32_t m = a.w[i];
-        uint64_t chain = 0;
+    for (int k = 0; k <= NIN; k++) xp[k] = k < NIN ? x[k] : 0u;
 #pragma unroll
-        for (int j = 0; j < 14; j++) {
-            chain += (uint64_t)m * b.w[j] + acc[j];
-            acc[j] = (uint32_t)chain;
-            chain >>= 32;
+    for (int k = 0; k < NHI; k++) hi[k] = xp[13 + k] >> 30 | xp[14 + k] << 2;
+#pragma unroll
+    for (int k = 0; k < NOUT; k++) out[k] = k < 13 ? x[k] : k == 13 ? x[13] & 0x3fffffffu : 0u;
+#pragma unroll
+    for (int i = 0; i < NHI; i++) {     // out += c * hi[i] << (32 i)
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 7; j++) {
+            carry += (uint64_t)hi[i] * SC_C[j] + out[i + j];
+            out[i + j] = (uint32_t)carry;
+            carry >>= 32;
         }
-        acc[14] = (uint32_t)chain;
-        m = acc[0] * SC_MONT32;
-        chain = 0;
 #pragma unroll
-        for (int j = 0; j < 14; j++) {
-            chain += (uint64_t)m * SC_Q[j] + acc[j];
-            if (j) acc[j - 1] = (uint32_t)chain;
-            chain >>= 32;
+        for (int k = i + 7; k < NOUT; k++) {   // (only the first of these can see a nonzero carry twice in a row)
+            carry += out[k];
+            out[k] = (uint32_t)carry;
+            carry >>= 32;
         }
-        chain += (uint64_t)acc[14] + hi_carry;
-        acc[13] = (uint32_t)chain;
-        hi_carry = (uint32_t)(chain >> 32);
     }
+}
+// x (15 words, below 2 q) -> canonical
+GD_FN sc sc_final(const uint32_t (&y)[15]) {
     sc t;
 #pragma unroll
-    for (int i = 0; i < 14; i++) t.w[i] = acc[i];
-    return sc_subx(t, sc_const(SC_Q), hi_carry);
+    for (int i = 0; i < 14; i++) t.w[i] = y[i];
+    return sc_subx(t, sc_const(SC_Q), 0);
 }
-GD_FN sc sc_mul(const sc &a, const sc &b) { return sc_montmul(sc_montmul(a, b), sc_const(SC_R2)); }
+// a*b mod q: schoolbook (196 word products), then 896 -> 675 -> 454 -> 447 bits in three folds
+GD_FN sc sc_mul(const sc &a, const sc &b) {
+    uint32_t x[28];
+#pragma unroll
+    for (int i = 0; i < 28; i++) x[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 14; i++) {
+        uint64_t carry = 0;
+#pragma unroll
+        for (int j = 0; j < 14; j++) {
+            carry += (uint64_t)a.w[i] * b.w[j] + x[i + j];
+            x[i + j] = (uint32_t)carry;
+            carry >>= 32;
+        }
+        x[i + 14] = (uint32_t)carry;
+    }
+    uint32_t y1[23], y2[16], y[15];
+    sc_fold<28, 15, 23>(y1, x);
+    sc_fold<23, 8, 16>(y2, y1);
+    sc_fold<16, 1, 15>(y, y2);
+    return sc_final(y);
+}
 
-// Reduce an arbitrary 448-bit word string mod q ("ham-handed reduce", scalar.c:246)
+// Reduce an arbitrary 448-bit word string mod q ("ham-handed reduce", scalar.c:246): one fold
 GD_FN sc sc_reduce(const sc &a) {
-    sc one = sc_zero();
-    one.w[0] = 1;
-    return sc_mul(a, one);
+    uint32_t x[15], y[15];
+#pragma unroll
+    for (int i = 0; i < 15; i++) x[i] = i < 14 ? a.w[i] : 0u;
+    sc_fold<15, 1, 15>(y, x);
+    return sc_final(y);
 }
 
 // s' = (s + 2^450 - 1)/2 mod q: recoding for signed fixed windows
