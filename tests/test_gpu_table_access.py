@@ -99,9 +99,60 @@ def test_both_modes_on_every_variable_base_entry_point(ga, O, modes):
             assert (r["dual1"] == want_mul).all() and (r["dual2"] == want_mul2).all(), (mode, "dual", n)
 
 
+def test_exceptional_bases_and_scalars_in_both_modes(ga, O, modes):
+    """What the table-free ladder (csrc/montgomery.hpp) treats by select, through every variable-base entry point
+    that has a ladder, in both modes and through both dispatch paths (one operation per wave / per lane): the
+    identity and the 2-torsion point (0, -1) as bases; bases with a 2-torsion component P + (0, -1) = (-x, -y)
+    (order 2q: the same class as s P); scalars 0, 1, q - 1 (where (s + 1) P is the identity and the recovery of
+    the second coordinate degenerates), q - 2, and scalars that are not reduced (q + 5, 2 q + 1 as raw words)."""
+    from _libs import Q, P, Gf
+    vals = [0, 1, 2, Q - 1, Q - 2, (Q + 1) // 2, 2**445, 5]
+    n = 4 * len(vals)
+    scal = np.concatenate([_gen.scalars_from_ints(vals)] * 4)
+    pts = _gen.oracle_fixed(O, _gen.stream_scalars(len(vals), b"ta/exc/base"))
+    ident = np.zeros(32, np.uint64); ident[8] = 1; ident[16] = 1
+    t2 = ident.copy(); t2[8:16] = np.frombuffer(Gf.from_int(P - 1), np.uint64)
+    shifted = pts.copy()
+    for i in range(len(vals)):
+        for fld in (0, 8):
+            v = sum(int(shifted[i][fld + k]) << (56 * k) for k in range(8)) % P
+            shifted[i][fld:fld + 8] = np.frombuffer(Gf.from_int((P - v) % P), np.uint64)
+    bases = np.concatenate([pts, shifted, np.repeat(ident.reshape(1, 32), len(vals), 0), np.repeat(t2.reshape(1, 32), len(vals), 0)])
+    raw = np.empty((2, 7), np.uint64)
+    raw[0] = np.frombuffer((Q + 5).to_bytes(56, "little"), np.uint64)
+    raw[1] = np.frombuffer((2 * Q + 1).to_bytes(56, "little"), np.uint64)
+    bases = np.concatenate([bases, pts[:2]]); scal = np.concatenate([scal, raw]); n += 2
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, bases, scal))
+    assert (want[2 * len(vals):4 * len(vals)] == 0).all()                   # the identity's class
+    assert (want[:len(vals)] == want[len(vals):2 * len(vals)]).all()        # the 2-torsion shift changes nothing
+    s2 = _gen.stream_scalars(n, b"ta/exc/s2")
+    saved = ga.get_wave_batch_max()
+    try:
+        for wave_max in (saved, 0):
+            ga.set_wave_batch_max(wave_max)
+
+            def body():
+                o1, o2 = ga.point_dual_scalarmul_batch(bases, scal, s2)
+                dbl = ga.point_double_scalarmul_batch(bases, scal, bases, s2)      # s P + s2 P = (s + s2) P
+                return dict(mul=ga.point_encode_batch(ga.point_scalarmul_batch(bases, scal)), dual1=ga.point_encode_batch(o1),
+                            dual2=ga.point_encode_batch(o2), dbl=ga.point_encode_batch(dbl))
+            sums = np.empty((n, 7), np.uint64)
+            for i in range(n):
+                a = int.from_bytes(scal[i].tobytes(), "little"); b = int.from_bytes(s2[i].tobytes(), "little")
+                sums[i] = np.frombuffer(((a + b) % Q).to_bytes(56, "little"), np.uint64)
+            want_sum = _gen.oracle_encode(_gen.oracle_varbase(O, bases, sums))
+            want2 = _gen.oracle_encode(_gen.oracle_varbase(O, bases, s2))
+            for mode, r in modes(body).items():
+                assert (r["mul"] == want).all(), (mode, wave_max, np.nonzero((r["mul"] != want).any(1))[0])
+                assert (r["dual1"] == want).all() and (r["dual2"] == want2).all(), (mode, wave_max)
+                assert (r["dbl"] == want_sum).all(), (mode, wave_max)
+    finally:
+        ga.set_wave_batch_max(saved)
+
+
 def test_index_independent_scan_on_a_full_residency(ga, O):
-    """More operations than resident lanes (grid-stride rounds, partial last wave) through the scan
-    tables; a sample of lanes against the oracle and all of them against the fast tables on the device."""
+    """More operations than resident lanes (grid-stride rounds, partial last wave) through the table-free
+    ladder; a sample of lanes against the oracle and all of them against the fast tables on the device."""
     import torch
     info = ga.device_info()
     n = info["compute_units"] * 2 * 256 + 1000 + 37

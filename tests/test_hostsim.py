@@ -332,6 +332,14 @@ def test_table_free_ladder_matches_oracle_and_golden_f1(H, O):
     assert (_gen.oracle_encode(got) == want).all()
     for i in range(len(vals)):   # complete extended points: on the curve, X Y = Z T
         assert H.hs_point_valid(got[i].ctypes.data_as(C.c_void_p)) == -1, hex(vals[i])
+    # bases with a 2-torsion component, P + (0, -1) = (-x, -y): order 2q, the same class as s*P for every s
+    shifted = bases.copy()
+    for i in range(len(vals)):
+        for fld in (0, 8):                               # X and Y negated limb-wise mod p (T = XY/Z unchanged)
+            v = sum(int(shifted[i][fld + k]) << (56 * k) for k in range(8)) % P
+            shifted[i][fld:fld + 8] = np.frombuffer(Gf.from_int((P - v) % P), np.uint64)
+    assert (_gen.oracle_encode(_gen.oracle_varbase(O, shifted, scal)) == want).all()      # the reference agrees
+    assert (_gen.oracle_encode(run(shifted, scal)) == want).all()
     # the identity and (0, -1) as bases: the identity's class whatever the scalar
     ident = np.zeros(32, np.uint64); ident[8] = 1; ident[16] = 1
     t2 = ident.copy(); t2[8:16] = np.frombuffer(Gf.from_int(P - 1), np.uint64)
