@@ -203,23 +203,26 @@ struct LaneTable {  // this lane's window table in the HBM workspace, lane-conti
 // table's own memory every iteration of the build pays that (tools/verifyphases: the table builds of
 // verification ran at 14-18 clocks per multiply-accumulate against the ladder's 10, and at the ladder's rate
 // with the stores left out).  From LDS the step comes back at once and the stores drain behind the next addition.
-// Piece-major ([piece][lane], 16 bytes each): conflict-free.
+// Piece-major ([piece][lane], 16 bytes each): conflict-free.  STRIDE = lanes per piece row: 256 for a region of
+// the block (+ threadIdx.x), 64 for a region of the wave (+ lane in the wave), which a kernel may reuse for its
+// wave's I/O staging between operations.
 constexpr int STEP_LDS_U4 = 16 * 256;   // uint4 per 256-lane block
+template <int STRIDE = 256>
 struct LdsStepTable {
     static constexpr bool direct = true;
     uint4 *p;        // this lane's table in the workspace
-    uint4 *lds;      // the block's step region + threadIdx.x
+    uint4 *lds;      // the step region + this lane's position in a piece row
     __device__ __forceinline__ void store(int k, const pniels &e) const { pniels_store(p + 16 * k, e); }
     __device__ __forceinline__ pniels load(uint32_t k) const { return pniels_load(p + 16 * k); }
     __device__ __forceinline__ pniels lookup(uint32_t idx) const { return load(idx); }
     __device__ __forceinline__ void put_piece(int i, const fe &f) const {
-        lds[(4 * i + 0) * 256] = make_uint4(f.v[0], f.v[1], f.v[2], f.v[3]);
-        lds[(4 * i + 1) * 256] = make_uint4(f.v[4], f.v[5], f.v[6], f.v[7]);
-        lds[(4 * i + 2) * 256] = make_uint4(f.v[8], f.v[9], f.v[10], f.v[11]);
-        lds[(4 * i + 3) * 256] = make_uint4(f.v[12], f.v[13], f.v[14], f.v[15]);
+        lds[(4 * i + 0) * STRIDE] = make_uint4(f.v[0], f.v[1], f.v[2], f.v[3]);
+        lds[(4 * i + 1) * STRIDE] = make_uint4(f.v[4], f.v[5], f.v[6], f.v[7]);
+        lds[(4 * i + 2) * STRIDE] = make_uint4(f.v[8], f.v[9], f.v[10], f.v[11]);
+        lds[(4 * i + 3) * STRIDE] = make_uint4(f.v[12], f.v[13], f.v[14], f.v[15]);
     }
     __device__ __forceinline__ fe get_piece(int i) const {
-        return fe_from_u4(lds[(4 * i + 0) * 256], lds[(4 * i + 1) * 256], lds[(4 * i + 2) * 256], lds[(4 * i + 3) * 256]);
+        return fe_from_u4(lds[(4 * i + 0) * STRIDE], lds[(4 * i + 1) * STRIDE], lds[(4 * i + 2) * STRIDE], lds[(4 * i + 3) * STRIDE]);
     }
     __device__ __forceinline__ void put_step(const pniels &e) const {
         put_piece(0, e.a);

@@ -43,8 +43,8 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
     // wave-uniform: a lane without a signature of its own in the last round verifies the batch's last one once more
     // and stores nothing.
     __shared__ uint4 s_step[STEP_LDS_U4];   // the table builds' step (LdsStepTable)
-    LdsStepTable a_tab{lane_table_at(workspace, 0, 2).p, s_step + threadIdx.x},
-                 r_tab{lane_table_at(workspace, 1, 2).p, s_step + threadIdx.x};
+    LdsStepTable<> a_tab{lane_table_at(workspace, 0, 2).p, s_step + threadIdx.x},
+                   r_tab{lane_table_at(workspace, 1, 2).p, s_step + threadIdx.x};
     const uint32_t rounds = (n + stride - 1) / stride;
     for (uint32_t r = 0; r < rounds; r++) {
         const uint32_t slot = lane + r * stride;

@@ -86,10 +86,12 @@ GD_FN pt ladder_varbase_w(const BITS &bits, const TABLE &table) {
     for (int pos = window_plan<W>::TOP - W; pos >= 0; pos -= W) {
         signed_digit_w<W>(window_w<W>(bits, pos), idx, neg);
 #pragma unroll 1
-        for (int j = 0; j < W; j++) pt_double(acc, j == W - 1);
-        // all of the entry's loads are issued together, behind the doublings (read field by field, each
-        // right before its product, the same kernel measures 0.8 % slower: profiles/r02/experiments.md)
+        for (int j = 0; j < W - 1; j++) pt_double(acc, false);
+        // the entry's reads are issued before the window's last doubling (public digits only reach this ladder):
+        // a field operation's worth of arithmetic for the memory to hide behind
         pniels e = table.lookup(idx);
+        gd_keep_order();
+        pt_double(acc, true);
         // T is only needed by a following addition, i.e. never after the last window's
         // add -- except that the caller wants a complete extended point at pos == 0.
         pt_add_pniels(acc, e, neg, pos == 0);

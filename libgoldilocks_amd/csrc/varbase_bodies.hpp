@@ -28,12 +28,15 @@ __device__ __forceinline__ void point_scalarmul_body(uint64_t *out, const uint64
                                                      const uint64_t *__restrict__ scalar, uint32_t n,
                                                      uint4 *__restrict__ workspace) {
     __shared__ uint32_t s_bits[15 * BLOCK];
-    __shared__ uint4 s_stage[(BLOCK / 64) * WAVE_STAGE_U4];
+    // 16 KiB per wave: the table build's step (LdsStepTable, piece rows of 64 lanes) and, between operations, the
+    // wave's I/O staging (its first 8 KiB) -- never in use together
+    __shared__ uint4 s_wave[(BLOCK / 64) * 16 * 64];
+    static_assert(WAVE_STAGE_U4 <= 16 * 64, "the I/O staging fits the wave's step region");
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
     const uint32_t l = threadIdx.x & 63u;
-    uint4 *stage = s_stage + (threadIdx.x >> 6) * WAVE_STAGE_U4;
-    LaneTable tab = lane_table_at(workspace, 0, 1);
+    uint4 *stage = s_wave + (threadIdx.x >> 6) * 16 * 64;
+    LdsStepTable<64> tab{lane_table_at(workspace, 0, 1).p, stage + l};
     // wave-uniform loop: the 64 lanes of a wave own 64 consecutive operations per round
     for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {
         const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
