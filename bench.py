@@ -306,11 +306,12 @@ def verify_inputs(cx):
 
 # ---------------------------------------------------------------------------------------- end to end
 
-def end_to_end(cx, reps=3):
+def end_to_end(cx, reps=5):
     """The host-array entry points (goldilocks_448_point_scalarmul_batch, _precomputed_scalarmul_batch,
     goldilocks_ed448_verify_batch): pageable host arrays in, host arrays out -- H2D, kernels and D2H inside
     the timed call, library defaults (index-independent tables).  One untimed call first (it sizes the
-    library's staging pool), then the median of `reps`.  Output arrays are allocated and touched beforehand:
+    library's staging pool), then the median of `reps` (every call's time is on the line too: a call whose
+    transfers do not keep the GPU busy finds its clocks down, and the rate of such a call can be a third lower).  Output arrays are allocated and touched beforehand:
     what is timed is the library, not the page faults of a fresh numpy array."""
     ga, np, n = cx.ga, cx.np, cx.n
     L = ga.lib()
@@ -345,7 +346,8 @@ def end_to_end(cx, reps=3):
                 raise RuntimeError(L.goldilocks_amd_last_error().decode())
         t = sorted(times)[len(times) // 2]
         res[name] = {"value": n / t, "unit": WORKLOADS[name]["unit"], "ms_per_call": t * 1e3, "entry_point": what,
-                     "pcie_bytes_per_op": nbytes, "host_memory": "pageable", "reps": reps}
+                     "pcie_bytes_per_op": nbytes, "host_memory": "pageable", "reps": reps,
+                     "ms_every_call": [round(x * 1e3, 2) for x in times]}
     ok = bool(((st == -1) == ~v["bad"]).all())
     res["verify"]["check"] = "accepted lanes == uncorrupted lanes" if ok else "FAILED"
     return res, ok
