@@ -77,8 +77,15 @@ WORKLOADS = {
                  desc="goldilocks_448_precomputed_scalarmul(precomputed_base), 16-bit window table"),
     # half-size scalars (csrc/lattice.hpp): two decodings + two window tables + one 45-window ladder over both
     # points + two correcting additions + 28 base-point additions
-    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=611_480,
-                   desc="goldilocks_ed448_verify, 32-byte messages, 1% corrupted"),
+    # macs: every lane decodes its key and builds the key's table itself; macs_shared_keys: the key has a pooled table
+    # (one decoding and one table per DISTINCT key of the batch, kernels_verify.hip) -- what 2^20 signatures of 2^10
+    # keys run at; the per-key work is (64 728 + 24 624) * 2^10 / 2^20 = 87 MACs per signature more
+    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=522_128 + 87, macs_own_key=611_480,
+                   macs_shared_keys=522_128, keys=1024,
+                   desc="goldilocks_ed448_verify, 32-byte messages, 2^10 distinct keys (SURVEY 8d), 1% corrupted"),
+    "verify_distinct": dict(metric="Ed448 verifies/sec, every signature under its own key", unit="verifies/s", bytes=207,
+                            macs=611_480, keys=None,
+                            desc="goldilocks_ed448_verify, 32-byte messages, as many distinct keys as signatures, 1% corrupted"),
     "sign": dict(metric="Ed448 signatures/sec", unit="signatures/s", bytes=260, macs=None,
                  desc="goldilocks_ed448_sign, 32-byte messages, no context"),
     "x448": dict(metric="X448 shared secrets/sec", unit="shared secrets/s", bytes=172, macs=None,
@@ -263,7 +270,7 @@ def make_workload(name, cx, access):
         return dict(step=step, kernel="k_x448", check=check)
     # verify: signatures over 32-byte messages from 1024 distinct keys, produced by the
     # library's own derive/sign kernels (bit-exact vs the reference: tests/test_gpu_parity.py); 1 % corrupted
-    v = verify_inputs(cx)
+    v = verify_inputs(cx, distinct=name == "verify_distinct")
     d_sig, d_pk, d_msg = (torch.from_numpy(v[k]).cuda() for k in ("sig", "pk", "msg"))
     status = torch.empty(n, dtype=torch.int32, device="cuda")
     step = lambda: ga.dev("ed448_verify", status.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(),
@@ -280,28 +287,42 @@ def make_workload(name, cx, access):
     return dict(step=step, kernel="k_ed448_verify", check=check, sample=sample)
 
 
-def verify_inputs(cx):
-    """BASELINE config 4's synthetic input (host arrays): n signatures over 32-byte messages from 1024 keys,
-    1 % corrupted (and lane 5 always, so that the oracle's sample of the first lanes holds a reject)."""
-    if getattr(cx, "_verify", None) is None:
+def verify_inputs(cx, distinct=False):
+    """BASELINE config 4's synthetic input (host arrays): n signatures over 32-byte messages from 1024 keys
+    (SURVEY 8d), 1 % corrupted (and lane 5 always, so that the oracle's sample of the first lanes holds a reject).
+    distinct: every signature under a key of its own instead (what a verifier sees when no key repeats)."""
+    attr = "_verify_distinct" if distinct else "_verify"
+    if getattr(cx, attr, None) is None:
         import _gen
         ga, np, n = cx.ga, cx.np, cx.n
-        nk, nsig = 1024, 4096
-        sk_k = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/sk" % cx.rank, 57 * nk), np.uint8).reshape(nk, 57)
-        pk_k = ga.ed448_derive_public_key_batch(sk_k)
-        key_of = np.arange(nsig) % nk
-        msg_h = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/msg" % cx.rank, 32 * nsig), np.uint8).reshape(nsig, 32)
-        sigs = ga.ed448_sign_batch(sk_k[key_of], pk_k[key_of], [m.tobytes() for m in msg_h])
-        pks = pk_k[key_of]
-        idx = np.random.default_rng(cx.rank).integers(0, nsig, n)
         bad = np.random.default_rng(cx.rank + 99).random(n) < 0.01
         if n > 5:
             bad[5] = True
-        sig_h = sigs[idx]
+        if distinct:
+            torch = cx.torch
+            sk = torch.from_numpy(np.frombuffer(_gen.stream(b"bench_verify_v1/%d/sk-distinct" % cx.rank, 57 * n), np.uint8)
+                                  .reshape(n, 57).copy()).cuda()
+            msg = torch.from_numpy(np.frombuffer(_gen.stream(b"bench_verify_v1/%d/msg-distinct" % cx.rank, 32 * n), np.uint8)
+                                   .reshape(n, 32).copy()).cuda()
+            pk = torch.empty((n, 57), dtype=torch.uint8, device="cuda")
+            sig = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
+            ga.dev("ed448_derive_public_key", pk.data_ptr(), sk.data_ptr(), n, None)
+            ga.dev("ed448_sign", sig.data_ptr(), sk.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0, None, 0, n, None)
+            torch.cuda.synchronize()
+            sig_h, pk_h, msg_h = sig.cpu().numpy(), pk.cpu().numpy(), msg.cpu().numpy()
+        else:
+            nk, nsig = 1024, 4096
+            sk_k = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/sk" % cx.rank, 57 * nk), np.uint8).reshape(nk, 57)
+            pk_k = ga.ed448_derive_public_key_batch(sk_k)
+            key_of = np.arange(nsig) % nk
+            msgs = np.frombuffer(_gen.stream(b"bench_verify_v1/%d/msg" % cx.rank, 32 * nsig), np.uint8).reshape(nsig, 32)
+            sigs = ga.ed448_sign_batch(sk_k[key_of], pk_k[key_of], [m.tobytes() for m in msgs])
+            idx = np.random.default_rng(cx.rank).integers(0, nsig, n)
+            sig_h, pk_h, msg_h = sigs[idx], pk_k[key_of][idx], msgs[idx]
+        sig_h = np.ascontiguousarray(sig_h)
         sig_h[bad, 5] ^= 0x20
-        cx._verify = dict(sig=np.ascontiguousarray(sig_h), pk=np.ascontiguousarray(pks[idx]),
-                          msg=np.ascontiguousarray(msg_h[idx]), bad=bad)
-    return cx._verify
+        setattr(cx, attr, dict(sig=sig_h, pk=np.ascontiguousarray(pk_h), msg=np.ascontiguousarray(msg_h), bad=bad))
+    return getattr(cx, attr)
 
 
 # ---------------------------------------------------------------------------------------- end to end
@@ -532,6 +553,7 @@ def run_stub(args, shard, rank, world):
 CONFIGS = (("fixed", "fixed", "index-independent"),          # config 3: a caller's comb table, staged in LDS
            ("base", "base", "index-independent"),            # ... the built-in base point, library default
            ("verify", "verify", "index-independent"),        # config 4 (public data: the mode changes nothing)
+           ("verify_distinct_keys", "verify_distinct", "index-independent"),   # ... when no key repeats
            ("varbase_fast", "varbase", "fast"),              # the opt-in for public scalars
            ("base_fast", "base", "fast"))
 

@@ -86,6 +86,7 @@ FUNCTIONS = {
     "goldilocks_amd_thread_mode_counts": (None, "p"),
     "goldilocks_amd_set_wave_batch_max": (None, "z"),
     "goldilocks_amd_get_wave_batch_max": (C.c_size_t, ""),
+    "goldilocks_amd_set_verify_key_pool": (None, "zz"),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -439,6 +440,15 @@ def set_wave_batch_max(n):
 
 def get_wave_batch_max():
     return lib().goldilocks_amd_get_wave_batch_max()
+
+
+KEY_POOL_DEFAULT, KEY_POOL_MIN_BATCH_DEFAULT = 65536, 1 << 18
+
+
+def set_verify_key_pool(keys=KEY_POOL_DEFAULT, min_batch=KEY_POOL_MIN_BATCH_DEFAULT):
+    """Verification shares one decoding and one window table between the signatures of a key: a pool of `keys`
+    tables for batches of at least `min_batch` signatures (0 keys turns it off)."""
+    lib().goldilocks_amd_set_verify_key_pool(int(keys), int(min_batch))
 
 
 def get_table_access():

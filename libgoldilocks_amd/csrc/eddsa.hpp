@@ -343,54 +343,53 @@ GD_FN LatticePair ed448_verify_lattice_pair(const Ed448Msg &m, STAGE &stage) {
     return pr;
 }
 // V - [doit] * (entry 0 of the table)
+// V -+ [doit] * (entry 0 of the table): minus, or plus if the table holds the other sign's multiples
 template <class AT>
-GD_FN void lattice_subtract_once(pt &V, const AT &tab, bool doit) {
+GD_FN void lattice_subtract_once(pt &V, const AT &tab, bool doit, bool flip) {
     pt W = V;
-    pt_add_pniels(W, tab.load(0), true, true);
+    pt_add_pniels(W, tab.load(0), !flip, true);
     V.x = fe_select(V.x, W.x, doit);
     V.y = fe_select(V.y, W.y, doit);
     V.z = fe_select(V.z, W.z, doit);
     V.t = fe_select(V.t, W.t, doit);
 }
-// phase 2: decode A and R, walk, add the base point's part, test
+// phase 2: decode A and R, walk, add the base point's part, test.
+// The key's table holds the multiples of +A whatever the sign of tau (the digits' signs are flipped at the lookups
+// instead), so that it can be SHARED: a batch's signatures of one key need its decoding and its table once
+// (kernels_verify.hip: k_verify_dedupe, k_verify_key_tables).  shared_key: a_tab already holds A's table and
+// key_ok says whether A decoded; otherwise this lane decodes the key and fills a_tab itself.
 template <class FB, class AT, class BITS, class MKBITS>
 GD_FN bool ed448_verify_lattice_walk(const Ed448Msg &m, const LatticePair &pr, const BITS &bits1, const BITS &bits2,
-                                     const FB &fb, AT &a_tab, AT &r_tab, MKBITS &mkbits) {
-    bool ok;
-    {
-        // both points are decoded in ONE instruction stream (their exponentiations interleaved); R waits in its
-        // table's memory (slot 0, as a plain four-field record) while the key's table is built
-        uint32_t wa[15], wr[15];
-        load_bytes_as_words(wa, m.b, 57, 15);                                 // public key
-        load_bytes_as_words(wr, m.a, 57, 15);                                 // R = sig[0:57]
-        pt A, R;
-        bool oka, okr;
-        pt_decode_eddsa_words2(A, R, oka, okr, wa, wr);
-        ok = oka && okr;
-        pniels park;
-        park.a = R.x; park.b = R.y; park.cn = R.z; park.z = R.t;
-        r_tab.store(0, park);
-        build_window_table(a_tab, pr.tau_pos ? pt_negate(A) : A);             // PA
+                                     const FB &fb, AT &a_tab, AT &r_tab, MKBITS &mkbits, bool shared_key, bool key_ok) {
+    uint32_t w[15];
+    bool ok = key_ok;
+    if (!shared_key) {
+        pt A;
+        load_bytes_as_words(w, m.b, 57, 15);                                  // public key
+        ok = pt_decode_eddsa_words(A, w);
+        build_window_table(a_tab, A);
     }
     {
-        const pniels park = r_tab.load(0);
         pt R;
-        R.x = park.a; R.y = park.b; R.z = park.cn; R.t = park.z;
-        build_window_table(r_tab, pt_negate(R));                              // PR
+        load_bytes_as_words(w, m.a, 57, 15);                                  // R = sig[0:57]
+        ok = pt_decode_eddsa_words(R, w) && ok;
+        build_window_table(r_tab, pt_negate(R));                              // PR = -R
     }
-    pt V = ladder_double_var(bits1, a_tab, bits2, r_tab, LATTICE_WINDOWS);
-    lattice_subtract_once(V, a_tab, pr.rho_even);
-    lattice_subtract_once(V, r_tab, pr.tau_even);
+    // PA = -+A by the sign of tau: the table of +A with every digit of rho flipped when tau is positive
+    pt V = ladder_double_var(bits1, a_tab, pr.tau_pos, bits2, r_tab, LATTICE_WINDOWS);
+    lattice_subtract_once(V, a_tab, pr.rho_even, pr.tau_pos);
+    lattice_subtract_once(V, r_tab, pr.tau_even, false);
     fb.add_to(V, pr.ts, mkbits);                                              // + (|tau| S)*B
     return ok && fe_is_zero(V.x);
 }
 // MKBITS: mkbits.words(w15, slot) turns 15 words into a BITS reader.
 template <class FB, class AT, class STAGE, class MKBITS>
-GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &r_tab, STAGE &stage, MKBITS &mkbits) {
+GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &r_tab, STAGE &stage, MKBITS &mkbits,
+                                bool shared_key = false, bool key_ok = true) {
     const LatticePair pr = ed448_verify_lattice_pair(m, stage);
     auto bits1 = mkbits.words(pr.b1, 0);
     auto bits2 = mkbits.words(pr.b2, 1);
-    return ed448_verify_lattice_walk(m, pr, bits1, bits2, fb, a_tab, r_tab, mkbits);
+    return ed448_verify_lattice_walk(m, pr, bits1, bits2, fb, a_tab, r_tab, mkbits, shared_key, key_ok);
 }
 
 // ------------------------------------------------------------------ key derivation and signing

@@ -382,47 +382,6 @@ GD_FN fe fe_isr(const fe &x, bool *ok) {
     return r;
 }
 
-// The same exponentiation for TWO independent inputs in one instruction stream.  A squaring chain is strictly
-// serial; two of them statement by statement give the scheduler twice the independent work per wave, which is
-// what a SIMD shared by only two waves lacks while both sit in such a chain (verification decodes the key and R:
-// tools/verifyphases measures the single chains at 11.5-12 clocks per multiply-accumulate against the ladder's 9.7).
-GD_FN void fe_sqrn2(fe &x, fe &y, int n) {
-    for (int i = 0; i < n; i++) {
-        x = fe_sqr(x);
-        y = fe_sqr(y);
-    }
-}
-GD_FN void fe_isr2(fe &rx, fe &ry, const fe &x, const fe &y, bool *okx, bool *oky) {
-    const fe x1 = fe_weak(x), y1 = fe_weak(y);
-    fe a = fe_mul(fe_sqr(x1), x1), b = fe_mul(fe_sqr(y1), y1);                 // e2
-    const fe a3 = fe_mul(fe_sqr(a), x1), b3 = fe_mul(fe_sqr(b), y1);           // e3
-    a = a3; b = b3;
-    fe_sqrn2(a, b, 3);
-    a = fe_mul(a, a3); b = fe_mul(b, b3);                                      // e6
-    fe_sqrn2(a, b, 3);
-    const fe a9 = fe_mul(a, a3), b9 = fe_mul(b, b3);                           // e9
-    a = a9; b = b9;
-    fe_sqrn2(a, b, 9);
-    const fe a18 = fe_mul(a, a9), b18 = fe_mul(b, b9);                         // e18
-    a = fe_mul(fe_sqr(a18), x1); b = fe_mul(fe_sqr(b18), y1);                  // e19
-    fe_sqrn2(a, b, 18);
-    const fe a37 = fe_mul(a, a18), b37 = fe_mul(b, b18);                       // e37
-    a = a37; b = b37;
-    fe_sqrn2(a, b, 37);
-    a = fe_mul(a, a37); b = fe_mul(b, b37);                                    // e74
-    fe_sqrn2(a, b, 37);
-    const fe a111 = fe_mul(a, a37), b111 = fe_mul(b, b37);                     // e111
-    a = a111; b = b111;
-    fe_sqrn2(a, b, 111);
-    const fe a222 = fe_mul(a, a111), b222 = fe_mul(b, b111);                   // e222
-    a = fe_mul(fe_sqr(a222), x1); b = fe_mul(fe_sqr(b222), y1);                // e223
-    fe_sqrn2(a, b, 223);
-    rx = fe_mul(a, a222);
-    ry = fe_mul(b, b222);
-    *okx = fe_eq(fe_mul(fe_sqr(rx), x1), fe_one());
-    *oky = fe_eq(fe_mul(fe_sqr(ry), y1), fe_one());
-}
-
 // 1/x (0 -> 0)  (cf. gf_invert, src/goldilocks.c:69-80)
 GD_FN fe fe_invert(const fe &x) {
     bool ok;

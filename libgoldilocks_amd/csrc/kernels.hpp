@@ -31,6 +31,7 @@ constexpr int BLOCK = 256;          // 4 waves: one per SIMD
 #endif
 constexpr int WAVES_PER_SIMD = GD_WAVES_PER_SIMD;   // 2 blocks per CU -> 256-VGPR budget per lane
 constexpr int TABLE_U4 = 17 * 16;    // uint4 per lane window table (16 entries + 1 build slot, x 4 fe x 4 uint4)
+constexpr int KEY_TABLE_U4 = 16 * 16;   // uint4 per pooled key table of verification: 16 entries of 256 bytes
 constexpr int PRECOMP_U4 = 80 * 20 + 64;  // uint4 per lane for k_precompute: 80 x 5 fe + 4 doubled teeth
 // per-OPERATION workspace of the kernels that share one inversion between a lane's operations
 // (fixed_bodies.hpp): numerator(s) | denominator | prefix product [| nonce | secret scalar]
@@ -437,7 +438,17 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
                          const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                          const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
                          const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
-                         uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt);
+                         uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt,
+                         const uint32_t *__restrict__ rep, const uint32_t *__restrict__ slot_of,
+                         const uint4 *__restrict__ pool, const uint8_t *__restrict__ key_ok,
+                         const uint32_t *__restrict__ ctrl);
+// one decoding and one window table per distinct public key of a verification batch (kernels_verify.hip)
+GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slot_of, uint32_t *__restrict__ key_list,
+                          uint32_t *__restrict__ hash_slots, uint32_t hash_mask, uint32_t *__restrict__ ctrl,
+                          const uint8_t *__restrict__ pk, uint32_t n);
+GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, uint32_t *__restrict__ ctrl,
+                              const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk, uint32_t n,
+                              uint32_t capacity);
 GD_KERNEL k_ed448_derive_public_key(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
                                     const uint4 *__restrict__ bwt, uint4 *__restrict__ workspace);
 GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,

@@ -251,54 +251,33 @@ GD_FN bool pt_decode_words_u(pt &p, fe &u, const uint32_t in[14], bool allow_ide
 }
 
 // RFC 8032 decoding followed by the 4-isogeny onto the twisted curve
-// (src/goldilocks.c:949-1004).  in: 57 bytes as 15 words (top 3 bytes of word 14 unused).  In three parts so
-// that two decodings can share one instruction stream through their exponentiation (pt_decode_eddsa_words2).
-struct eddsa_dec {
-    fe y2, num, y;
-    bool low, ok;
-};
-GD_FN fe pt_decode_eddsa_begin(eddsa_dec &d, const uint32_t in[15]) {   // -> what the inverse square root is taken of
-    const uint32_t last = in[14] & 0xff;
-    d.low = (last & 0x80) != 0;
-    d.ok = (last & 0x7f) == 0;
-    d.ok = fe_deserialize_words(d.y, in) && d.ok;
-    d.y2 = fe_sqr(d.y);
-    d.num = fe_weak(fe_sub<2>(fe_one(), d.y2));                          // 1 - y^2
-    const fe den = fe_weak(fe_add(fe_one(), fe_mulw(d.y2, NEG_EDWARDS_D)));   // 1 - d y^2, d = -39081
-    return fe_mul(d.num, den);
-}
-GD_FN bool pt_decode_eddsa_finish(pt &p, const eddsa_dec &d, const fe &isr, bool sq) {
-    fe x = fe_mul(isr, d.num);
-    x = fe_weak(fe_cond_neg(x, fe_lobit(x) != d.low));
+// (src/goldilocks.c:949-1004).  in: 57 bytes as 15 words (top 3 bytes of word 14 unused).
+GD_FN bool pt_decode_eddsa_words(pt &p, const uint32_t in[15]) {
+    uint32_t last = in[14] & 0xff;
+    bool low = (last & 0x80) != 0;
+    bool ok = (last & 0x7f) == 0;
+    fe y;
+    ok = fe_deserialize_words(y, in) && ok;
+    fe y2 = fe_sqr(y);
+    fe num = fe_weak(fe_sub<2>(fe_one(), y2));                           // 1 - y^2
+    fe den = fe_weak(fe_add(fe_one(), fe_mulw(y2, NEG_EDWARDS_D)));      // 1 - d y^2, d = -39081
+    bool sq;
+    fe isr = fe_isr(fe_mul(num, den), &sq);
+    ok = ok && sq;
+    fe x = fe_mul(isr, num);
+    x = fe_weak(fe_cond_neg(x, fe_lobit(x) != low));
     // isogeny: like doubling with Z = 1 but E = 2 - D (not 2 - T')
     fe c = fe_sqr(x);
-    fe a = d.y2;
-    fe dd = fe_add(c, a);                                                 // mag 2
-    fe b = fe_weak(fe_sub<4>(fe_sqr(fe_add(x, d.y)), dd));
+    fe a = y2;
+    fe d = fe_add(c, a);                                                  // mag 2
+    fe b = fe_weak(fe_sub<4>(fe_sqr(fe_add(x, y)), d));
     fe tt = fe_weak(fe_sub<2>(a, c));
-    fe e = fe_weak(fe_sub<4>(fe_small(2), dd));                           // 2 - D
+    fe e = fe_weak(fe_sub<4>(fe_small(2), d));                            // 2 - D
     p.x = fe_mul(e, b);
     p.z = fe_mul(tt, e);
-    p.y = fe_mul(dd, tt);
-    p.t = fe_mul(dd, b);
-    return d.ok && sq;
-}
-GD_FN bool pt_decode_eddsa_words(pt &p, const uint32_t in[15]) {
-    eddsa_dec d;
-    const fe n = pt_decode_eddsa_begin(d, in);
-    bool sq;
-    const fe isr = fe_isr(n, &sq);
-    return pt_decode_eddsa_finish(p, d, isr, sq);
-}
-// two decodings, their exponentiations statement by statement (gf28.hpp fe_isr2)
-GD_FN void pt_decode_eddsa_words2(pt &p, pt &q, bool &okp, bool &okq, const uint32_t inp[15], const uint32_t inq[15]) {
-    eddsa_dec dp, dq;
-    const fe np = pt_decode_eddsa_begin(dp, inp), nq = pt_decode_eddsa_begin(dq, inq);
-    fe ip, iq;
-    bool sp, sq;
-    fe_isr2(ip, iq, np, nq, &sp, &sq);
-    okp = pt_decode_eddsa_finish(p, dp, ip, sp);
-    okq = pt_decode_eddsa_finish(q, dq, iq, sq);
+    p.y = fe_mul(d, tt);
+    p.t = fe_mul(d, b);
+    return ok;
 }
 
 // Elligator 2 hash-to-curve, one 56-byte string -> point ("next" row f4; src/elligator.c:32-83).

@@ -298,12 +298,14 @@ GD_FN pt ladder_double(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, c
 // Public data (TABLE::direct): the first entry of a window is requested BEFORE the window's last doubling and
 // the second one before the first addition, so each read has a field operation's worth of arithmetic to hide
 // behind (with both requested after the doublings the first addition waited for memory 44 times per signature).
+// flip1: table 1 holds the multiples of P where those of -P are meant (a table shared by the signatures of one key
+// serves both signs of tau): every digit of scalar 1 changes sign.
 template <class BITS, class TABLE1, class TABLE2>
-GD_FN pt ladder_double_var(const BITS &bits1, const TABLE1 &t1, const BITS &bits2, const TABLE2 &t2, int nw) {
+GD_FN pt ladder_double_var(const BITS &bits1, const TABLE1 &t1, bool flip1, const BITS &bits2, const TABLE2 &t2, int nw) {
     uint32_t idx;
     bool neg;
     signed_digit(window5(bits1, 5 * (nw - 1)), idx, neg);
-    pt acc = pniels_to_pt(t1.lookup(idx), neg);
+    pt acc = pniels_to_pt(t1.lookup(idx), neg != flip1);
     signed_digit(window5(bits2, 5 * (nw - 1)), idx, neg);
     pt_add_pniels(acc, t2.lookup(idx), neg, false);
 #pragma unroll 1
@@ -319,7 +321,7 @@ GD_FN pt ladder_double_var(const BITS &bits1, const TABLE1 &t1, const BITS &bits
         pt_double(acc, true);
         const pniels e2 = t2.lookup(idx2);
         gd_keep_order();
-        pt_add_pniels(acc, e1, neg, true);
+        pt_add_pniels(acc, e1, neg != flip1, true);
         pt_add_pniels(acc, e2, neg2, true);
     }
     return acc;

@@ -204,7 +204,7 @@ int hs_direct_scalarmul_ladder(uint8_t *out, const uint8_t *in, const uint64_t *
 // do not depend on the data.  what: 0 fe_mul, 1 fe_sqr, 2 fe_mulw, 3 pt_double, 4 pt_double + T,
 // 5 pt_add_niels + T, 6 niels_to_pt, 7 fe_isr, 8 pt_decode_eddsa, 9 pt_add (full), 10 pt_eq,
 // 11 variable base W = 5 (table + ladder), 12 unused, 13 comb ladder, 14 the 4 x 7 x 16 comb ladder,
-// 15 variable base by the Montgomery ladder (with its own inversion)
+// 15 variable base by the Montgomery ladder (with its own inversion), 16 build_window_table (16 entries)
 void hs_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *scalar);
 void hs_precomputed_scalarmul(uint64_t *out, const uint64_t *table, const uint64_t *scalar);
 void hs_comb_big_scalarmul(uint64_t *out, const uint64_t *table, const uint64_t *scalar);
@@ -233,6 +233,7 @@ unsigned long long hs_mac_count_of(int what, const uint64_t *point, const uint64
     case 12: return 0;   // (was: 4-bit windows of the scan tables, gone with them)
     case 13: hs_precomputed_scalarmul(out, comb_table, scalar); break;
     case 15: hs_point_scalarmul_ladder(out, point, scalar); break;
+    case 16: { HostTable tab; build_window_table(tab, p); } break;
     case 14: hs_comb_big_scalarmul(out, comb_table, scalar); c = 0; hs_comb_big_scalarmul(out, comb_table, scalar); break;   // the table is built by the first call
     default: return 0;
     }
@@ -358,6 +359,23 @@ int hs_ed448_verify_lattice(const uint8_t *sig, const uint8_t *pk, const uint8_t
     HostMkBits mk;
     Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
     return ed448_verify_lattice(m, fb, ta, tr, stage, mk) ? -1 : 0;
+}
+// the same with the key's table built beforehand, as for a key shared by several signatures of a batch
+int hs_ed448_verify_lattice_shared_key(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen,
+                                       uint8_t prehashed, const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    FixedComb<HostComb> fb{comb};
+    HostTable ta, tr;
+    uint32_t w[15];
+    bytes_to_words(w, pk, 57, 15);
+    pt A;
+    const bool key_ok = pt_decode_eddsa_words(A, w);
+    build_window_table(ta, A);
+    HostStage stage;
+    HostMkBits mk;
+    Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
+    return ed448_verify_lattice(m, fb, ta, tr, stage, mk, true, key_ok) ? -1 : 0;
 }
 // the short pair of a challenge: rho (15 words), tau (8 words, two's complement)
 void hs_half_size_pair(uint32_t *rho, uint32_t *tau, const uint64_t *h) {

@@ -52,7 +52,7 @@ def test_default_line_carries_configs_end_to_end_and_cpu_baseline():
     assert line["n_gpus"] == 1 and line["config"]["parity_spot_check"] == "ok"
     assert line["roofline"]["kernel"] == "k_point_scalarmul_ct" and line["config"]["table_access"] == "index-independent"
     assert "oracle's goldilocks_448_point_scalarmul" in line["config"]["check"]
-    assert set(line["configs"]) == {"fixed", "base", "verify", "varbase_fast", "base_fast"}
+    assert set(line["configs"]) == {"fixed", "base", "verify", "verify_distinct_keys", "varbase_fast", "base_fast"}
     for c in line["configs"].values():
         assert c["parity_spot_check"] == "ok" and c["value"] > 0 and c["kernel_ms_avg"] > 0
         assert "equal the oracle's" in c["check"]                        # not a self-comparison

@@ -429,3 +429,64 @@ def test_config5_share_of_one_gpu_in_one_launch(ga, O, log2n):
     want = _gen.oracle_verify(O, sig[pick_d].cpu().numpy(), pk[pick_d].cpu().numpy(),
                               [m.tobytes() for m in msg[pick_d].cpu().numpy()])
     assert (st[pick_d].cpu().numpy() == want).all() and (want == 0).sum() >= 50
+
+
+def test_verification_shares_the_tables_of_repeated_keys(ga, O):
+    """For large batches the verification kernel decodes every DISTINCT public key once and builds its window table
+    once (goldilocks_amd_set_verify_key_pool; kernels_verify.hip).  Verdicts must not depend on it: the same batch
+    -- signatures of 37 keys, rejects of every kind, an undecodable key that many signatures share -- with the pool
+    off, with the default pool, with a pool of 5 keys (most keys do not get a table: lanes of both kinds in every
+    wave) and with a batch of all-distinct keys (no pool is used: more than half of the signatures bring their own)."""
+    import torch
+    n, nk = 1 << 17, 37
+    sk = np.frombuffer(_gen.stream(b"pool/sk", 57 * nk), np.uint8).reshape(nk, 57)
+    pk_k = ga.ed448_derive_public_key_batch(sk)
+    key_of = np.random.default_rng(5).integers(0, nk, n)
+    msg_h = np.frombuffer(_gen.stream(b"pool/msg", 24 * n), np.uint8).reshape(n, 24).copy()
+    sigs = ga.ed448_sign_batch(sk[key_of], pk_k[key_of], [m.tobytes() for m in msg_h])
+    pks = pk_k[key_of].copy()
+    idx = np.arange(n)
+    kind = idx % 16
+    sigs[kind == 3, 60] ^= 1                    # S
+    sigs[kind == 5, 9] ^= 0x40                  # R
+    msg_h[kind == 7, 0] ^= 1                    # message
+    pks[kind == 9, 11] ^= 2                     # a key of its own, most likely undecodable or wrong
+    bad_key = pk_k[0].copy(); bad_key[56] = 0x01   # byte 56 neither 0 nor 0x80: the reference rejects the key
+    pks[kind == 11] = bad_key                   # ... shared by n/16 signatures
+    want_bad = (kind == 3) | (kind == 5) | (kind == 7) | (kind == 9) | (kind == 11)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_sig, d_pk, d_msg = d(sigs), d(pks), d(msg_h)
+
+    def run(d_sig, d_pk, d_msg, m):
+        st = torch.full((m,), 7, dtype=torch.int32, device="cuda")
+        ga.dev("ed448_verify", st.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(), None, 24, 0, None, 0, m, None)
+        torch.cuda.synchronize()
+        return st.cpu().numpy()
+    try:
+        got = {}
+        for name, (keys, min_batch) in dict(off=(0, 0), default=(ga.KEY_POOL_DEFAULT, 1 << 16), tiny=(5, 1 << 16)).items():
+            ga.set_verify_key_pool(keys, min_batch)
+            got[name] = run(d_sig, d_pk, d_msg, n)
+        for name, st in got.items():
+            assert set(np.unique(st)) <= {-1, 0}, name
+            assert ((st == 0) >= want_bad).all(), name           # every corrupted lane is rejected
+            assert (st == got["off"]).all(), name                # and the pool changes no verdict
+        assert (got["off"] == 0).sum() <= want_bad.sum() and (got["off"][~want_bad] == -1).all()
+        pick = np.concatenate([np.arange(64), np.random.default_rng(6).integers(0, n, 192)])
+        want = _gen.oracle_verify(O, sigs[pick], pks[pick], [m.tobytes() for m in msg_h[pick]])
+        assert (got["default"][pick] == want).all()
+        # all-distinct keys: 2^16 signatures of 2^16 keys through the pooled entry point
+        m = 1 << 16
+        sk2 = np.frombuffer(_gen.stream(b"pool/sk2", 57 * m), np.uint8).reshape(m, 57).copy()
+        d_sk2 = d(sk2)
+        d_pk2 = torch.empty((m, 57), dtype=torch.uint8, device="cuda")
+        d_sig2 = torch.empty((m, 114), dtype=torch.uint8, device="cuda")
+        ga.dev("ed448_derive_public_key", d_pk2.data_ptr(), d_sk2.data_ptr(), m, None)
+        ga.dev("ed448_sign", d_sig2.data_ptr(), d_sk2.data_ptr(), d_pk2.data_ptr(), d_msg.data_ptr(), None, 24, 0, None, 0, m, None)
+        d_sig2[::9, 70] ^= 4
+        ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT, 1 << 15)
+        st2 = run(d_sig2, d_pk2, d_msg, m)
+        bad2 = (np.arange(m) % 9) == 0
+        assert ((st2 == -1) == ~bad2).all()
+    finally:
+        ga.set_verify_key_pool()

@@ -182,7 +182,7 @@ def test_mac_counts_match_bench(H, O):
     s = _gen.stream_scalars(1, b"mac-count")[0].copy()
     p = lambda a: a.ctypes.data_as(C.c_void_p)
     names = ["fe_mul", "fe_sqr", "fe_mulw", "dbl", "dbl_t", "add_niels_t", "niels_to_pt", "isr", "decode_eddsa",
-             "pt_add", "pt_eq", "varbase5", "varbase4", "comb", "comb_big", "ladder"]
+             "pt_add", "pt_eq", "varbase5", "varbase4", "comb", "comb_big", "ladder", "table16"]
     c = {name: H.hs_mac_count_of(i, p(base), p(s), p(comb)) for i, name in enumerate(names)}
     assert (c["fe_mul"], c["fe_sqr"], c["fe_mulw"]) == (192, 136, 16)
     assert c["dbl"] == 4 * 136 + 3 * 192 and c["dbl_t"] == c["dbl"] + 192
@@ -213,8 +213,13 @@ def test_mac_counts_match_bench(H, O):
         assert H.hs_ed448_verify_lattice(p(sigs[i]), p(pks[i]), m, C.c_size_t(32), C.c_uint8(0), None, C.c_uint8(0), p(comb)) == -1
         per.append(H.hs_mac_counter_get())
     assert len(set(per)) == 1                                                                  # the same work for every signature
-    assert W["verify"]["macs"] == per[0] - (c["comb"] + c["pt_add"]) + 28 * c["add_niels_t"]
-    assert W["verify"]["macs"] < 0.80 * 766_184        # the full-length ladder with one exponentiation (round 2's alternative)
+    own = per[0] - (c["comb"] + c["pt_add"]) + 28 * c["add_niels_t"]
+    assert W["verify"]["macs_own_key"] == W["verify_distinct"]["macs"] == own
+    assert own < 0.80 * 766_184        # the full-length ladder with one exponentiation (round 2's alternative)
+    # a key with a pooled table (shared by the signatures of a batch): its decoding and its table are not the lane's,
+    # but one lane's per distinct key: (decoding + table) * 2^10 keys / 2^20 signatures more per signature
+    assert W["verify"]["macs_shared_keys"] == own - c["decode_eddsa"] - c["table16"]
+    assert W["verify"]["macs"] == W["verify"]["macs_shared_keys"] + (c["decode_eddsa"] + c["table16"]) * W["verify"]["keys"] // 2**20
 
 
 def test_big_comb_of_the_base_point_matches_oracle(H, O):
@@ -294,12 +299,18 @@ def test_verification_with_half_size_scalars(H, O):
     mlist = [m.tobytes() for m in msgs]
     f7 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f7_verify_torsion.json")))["cases"]
     H.hs_ed448_verify_lattice.restype = C.c_int
+    H.hs_ed448_verify_lattice_shared_key.restype = C.c_int
     want = _gen.oracle_verify(O, sigs, pks, mlist)
     for i in range(n):
         m = (C.c_uint8 * len(mlist[i])).from_buffer_copy(mlist[i])
         got = H.hs_ed448_verify_lattice(sigs[i].ctypes.data_as(C.c_void_p), pks[i].ctypes.data_as(C.c_void_p), m,
                                         C.c_size_t(len(mlist[i])), C.c_uint8(0), None, C.c_uint8(0), tab)
         assert got == want[i], i
+        # ... and with the key decoded and its table built beforehand (a key shared by the signatures of a batch:
+        # one table of +A serves both signs of tau)
+        got = H.hs_ed448_verify_lattice_shared_key(sigs[i].ctypes.data_as(C.c_void_p), pks[i].ctypes.data_as(C.c_void_p), m,
+                                                   C.c_size_t(len(mlist[i])), C.c_uint8(0), None, C.c_uint8(0), tab)
+        assert got == want[i], ("shared key", i)
     assert (want == -1).sum() >= 10 and (want == 0).sum() >= 10
     accepted = rejected = 0
     for c in f7:
@@ -308,6 +319,8 @@ def test_verification_with_half_size_scalars(H, O):
         cb = (C.c_uint8 * max(1, len(ctx))).from_buffer_copy(ctx or b"\0")
         got = H.hs_ed448_verify_lattice(sig, pk, mb, C.c_size_t(len(msg)), C.c_uint8(c["prehashed"]), cb, C.c_uint8(len(ctx)), tab)
         assert got == c["verdict"], c["kind"]
+        assert H.hs_ed448_verify_lattice_shared_key(sig, pk, mb, C.c_size_t(len(msg)), C.c_uint8(c["prehashed"]), cb,
+                                                    C.c_uint8(len(ctx)), tab) == c["verdict"], ("shared key", c["kind"])
         accepted += got == -1; rejected += got == 0
     assert accepted >= 4 and rejected >= 4
 

@@ -342,7 +342,7 @@ GD_FN void dbl(spt &p) {
 }
 }  // namespace sgn
 
-enum Op { MUL, SQR, SQR_KAR, MUL_DIRECT, DBL, ADD_WEAK, SQR_OPDBL, DBL_SIGNED, ISR, ISR2 };
+enum Op { MUL, SQR, SQR_KAR, MUL_DIRECT, DBL, ADD_WEAK, SQR_OPDBL, DBL_SIGNED, ISR };
 
 template <int OP>
 __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
@@ -381,13 +381,6 @@ __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
                 bool ok;
                 x = fe_isr(x, &ok);
             }
-            if (OP == ISR2) {  // two of them statement by statement
-                bool okx, oky;
-                fe rx, ry;
-                fe_isr2(rx, ry, x, y, &okx, &oky);
-                x = rx;
-                y = ry;
-            }
         }
     }
 #pragma unroll
@@ -396,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
 
 template <int OP>
 static void run(const char *name, uint32_t *d_io, int macs, int waves_per_simd) {
-    const int n = (OP == ISR || OP == ISR2) ? 10 : 4000;
+    const int n = OP == ISR ? 10 : 4000;
     const int blocks = 256 * waves_per_simd;   // 256 CUs, 4 waves per block = 1 per SIMD
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0));
@@ -436,7 +429,6 @@ int main() {
         run<DBL_SIGNED>("dbl_signed", d, 4 * 136 + 3 * 192, w);
         run<ADD_WEAK>("add+weak", d, 0, w);
         run<ISR>("isr", d, 63152, w);
-        run<ISR2>("isr x 2", d, 2 * 63152, w);
     }
     return 0;
 }
