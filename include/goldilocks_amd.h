@@ -359,11 +359,11 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_wave_batch_max(size_t n);
 GOLDILOCKS_AMD_API size_t goldilocks_amd_get_wave_batch_max(void);
 /* Verification batches usually hold many signatures of few keys.  For batches of at least `min_batch` signatures the
  * device entry point therefore decodes every DISTINCT public key of the batch once and builds its window table once, in
- * a pool of up to `keys` tables (4 KiB each) that the lanes share; a key beyond the pool's capacity is handled by its
- * lanes as before, and a batch in which more than half of the signatures bring a key of their own uses no pool at all.
- * Verdicts do not change.  keys = 0 turns the pool off.  Process-wide. */
-#define GOLDILOCKS_AMD_KEY_POOL_DEFAULT 65536
-#define GOLDILOCKS_AMD_KEY_POOL_MIN_BATCH_DEFAULT (1u << 18)
+ * a pool of up to `keys` tables (4 KiB each) that the lanes share; a batch with more distinct keys than that, or in
+ * which more than half of the signatures bring a key of their own, uses no pool (every lane decodes its key and builds
+ * its table itself, as small batches do).  Verdicts do not change.  keys = 0 turns the pool off.  Process-wide. */
+#define GOLDILOCKS_AMD_KEY_POOL_DEFAULT (1u << 18)
+#define GOLDILOCKS_AMD_KEY_POOL_MIN_BATCH_DEFAULT (1u << 16)
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t min_batch);
 /* "gfx950", number of CUs, workspace bytes currently held */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,

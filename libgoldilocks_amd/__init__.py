@@ -442,7 +442,7 @@ def get_wave_batch_max():
     return lib().goldilocks_amd_get_wave_batch_max()
 
 
-KEY_POOL_DEFAULT, KEY_POOL_MIN_BATCH_DEFAULT = 65536, 1 << 18
+KEY_POOL_DEFAULT, KEY_POOL_MIN_BATCH_DEFAULT = 1 << 18, 1 << 16
 
 
 def set_verify_key_pool(keys=KEY_POOL_DEFAULT, min_batch=KEY_POOL_MIN_BATCH_DEFAULT):

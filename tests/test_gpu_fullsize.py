@@ -435,8 +435,8 @@ def test_verification_shares_the_tables_of_repeated_keys(ga, O):
     """For large batches the verification kernel decodes every DISTINCT public key once and builds its window table
     once (goldilocks_amd_set_verify_key_pool; kernels_verify.hip).  Verdicts must not depend on it: the same batch
     -- signatures of 37 keys, rejects of every kind, an undecodable key that many signatures share -- with the pool
-    off, with the default pool, with a pool of 5 keys (most keys do not get a table: lanes of both kinds in every
-    wave) and with a batch of all-distinct keys (no pool is used: more than half of the signatures bring their own)."""
+    off, with the default pool, with a pool too small for the batch's keys (then nothing is pooled) and with a batch
+    of all-distinct keys (no pool either: more than half of the signatures bring their own)."""
     import torch
     n, nk = 1 << 17, 37
     sk = np.frombuffer(_gen.stream(b"pool/sk", 57 * nk), np.uint8).reshape(nk, 57)
