@@ -177,3 +177,40 @@ def test_index_independent_scan_on_a_full_residency(ga, O):
     want = _gen.oracle_encode(_gen.oracle_varbase(O, b_h, s_h))
     got = ga.point_encode_batch(out_ct.cpu().numpy().view(np.uint64)[idx])
     assert (got == want).all()
+
+
+def test_ladder_kernels_over_several_launches_of_one_call(ga, O):
+    """A launch of the table-free ladder kernels covers at most 8 operations per resident lane (their shared
+    inversions park per-operation state in a bounded workspace), so a call with more than 2^20 operations is cut into
+    sub-batches: 2^20 + 70 001 variable-base multiplications in place (out aliases base), dual and double
+    multiplications of the same size class, every lane against the digit-addressed kernels on the device and a sample
+    against the oracle."""
+    import torch
+    n = (1 << 20) + 70001
+    k = torch.from_numpy(_gen.stream_scalars(n, b"ta/multi/base").view(np.int64)).cuda()
+    s = torch.from_numpy(_gen.stream_scalars(n, b"ta/multi/scalar").view(np.int64)).cuda()
+    bases = torch.empty((n, 32), dtype=torch.int64, device="cuda")
+    ga.dev("precomputed_scalarmul", bases.data_ptr(), None, k.data_ptr(), n, None)
+    inplace = bases.clone()
+    out_fast = torch.empty_like(bases)
+    ga.dev("point_scalarmul", inplace.data_ptr(), inplace.data_ptr(), s.data_ptr(), n, None, flags=ga.CALL_TABLES_INDEX_INDEPENDENT)
+    ga.dev("point_scalarmul", out_fast.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None, flags=ga.CALL_TABLES_FAST)
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    ga.dev("point_pred", st.data_ptr(), inplace.data_ptr(), out_fast.data_ptr(), 0, n, None)
+    assert int((st == -1).sum()) == n
+    idx = np.unique(np.concatenate([np.arange(0, n, 65537), [0, (1 << 20) - 1, 1 << 20, (1 << 20) + 1, n - 1]]))
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, bases.cpu().numpy().view(np.uint64)[idx], s.cpu().numpy().view(np.uint64)[idx]))
+    assert (ga.point_encode_batch(inplace.cpu().numpy().view(np.uint64)[idx]) == want).all()
+    # s P + k P through the two-ladder kernel == (s + k) P through the digit-addressed one
+    dbl = torch.empty_like(bases)
+    ga.dev("point_double_scalarmul", dbl.data_ptr(), bases.data_ptr(), s.data_ptr(), bases.data_ptr(), k.data_ptr(), n, None,
+           flags=ga.CALL_TABLES_INDEX_INDEPENDENT)
+    o1, o2 = torch.empty_like(bases), torch.empty_like(bases)
+    ga.dev("point_dual_scalarmul", o1.data_ptr(), o2.data_ptr(), bases.data_ptr(), s.data_ptr(), k.data_ptr(), n, None,
+           flags=ga.CALL_TABLES_INDEX_INDEPENDENT)
+    ga.dev("point_pred", st.data_ptr(), o1.data_ptr(), out_fast.data_ptr(), 0, n, None)
+    assert int((st == -1).sum()) == n
+    summed = torch.empty_like(bases)
+    ga.dev("point_op", summed.data_ptr(), o1.data_ptr(), o2.data_ptr(), 0, n, None)          # s P + k P by point_add
+    ga.dev("point_pred", st.data_ptr(), dbl.data_ptr(), summed.data_ptr(), 0, n, None)
+    assert int((st == -1).sum()) == n
