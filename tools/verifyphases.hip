@@ -1,6 +1,7 @@
 // verifyphases.hip -- where does k_ed448_verify spend its time?  
 //
-// The product kernel's body (kernels_verify.hip, eddsa.hpp ed448_verify_lattice) re-stated phase by phase
+// The product kernel's body (kernels_verify.hip, eddsa.hpp ed448_verify_lattice) for a lane that works for itself
+// (no pooled key table: with one, the phases "decode A" and "table A" are not the lane's) re-stated phase by phase
 // with a clock read (s_memtime) between the phases; the same launch shape (256 CUs x 2 blocks x 256 lanes,
 // grid-stride over 2^20 signatures), the same tables and workspace layout.  Inputs are random bytes: every
 // arithmetic phase runs whatever the verdict is (there is no early exit), so timing needs no valid signatures.
@@ -30,11 +31,11 @@ using namespace gd;
     } while (0)
 
 constexpr int NPH = 10;
-static const char *PHASE[NPH] = {"hash + scalar decoding", "short pair (lattice) + tau*S", "decode A and R together", "table A",
-                                 "(reload R)",            "table R",                      "joint ladder (45 windows)",
+static const char *PHASE[NPH] = {"hash + scalar decoding", "short pair (lattice) + tau*S", "decode A", "table A",
+                                 "decode R",              "table R",                      "joint ladder (45 windows)",
                                  "two correcting adds",   "28 base-point adds",           "test + store"};
 // multiply-accumulates per phase (tests/hostsim counters): decode 64.6 K each, table 26.1 K each, ...
-static const double MACS[NPH] = {0, 0, 2 * 64572, 26080, 0, 26080, 225 * 1120.0 + 45 * 192 + 90 * 1728, 2 * 1728, 28 * 1344, 0};
+static const double MACS[NPH] = {0, 0, 64728, 24624, 64728, 24624, 225 * 1120.0 + 45 * 192 + 90 * 1728, 2 * 1728, 28 * 1344, 0};
 
 __device__ __forceinline__ uint64_t now() { return __builtin_readcyclecounter(); }
 
@@ -51,8 +52,8 @@ k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const ui
     LdsStage stage{s_stage + threadIdx.x};
     LdsMkBitsVerify mkbits{s_bits + threadIdx.x};
     __shared__ uint4 s_step[STEP_LDS_U4];
-    LdsStepTable a_tab{VarTable<false>::at(workspace, 0, 2).p, s_step + threadIdx.x},
-                 r_tab{VarTable<false>::at(workspace, 1, 2).p, s_step + threadIdx.x};
+    LdsStepTable<> a_tab{lane_table_at(workspace, 0, 2).p, s_step + threadIdx.x},
+                   r_tab{lane_table_at(workspace, 1, 2).p, s_step + threadIdx.x};
     uint64_t acc[NPH];
     for (int k = 0; k < NPH; k++) acc[k] = 0;
     // experiment: blocks start at different times so that their table-building phases (bursts of stores) do not coincide
@@ -93,32 +94,25 @@ k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const ui
         MARK(1);
         bool ok;
         {
-            uint32_t wa[15], wr[15];
-            load_bytes_as_words(wa, m.b, 57, 15);
-            load_bytes_as_words(wr, m.a, 57, 15);
-            pt A, R;
-            bool oka, okr;
-            pt_decode_eddsa_words2(A, R, oka, okr, wa, wr);
-            ok = oka && okr;
-            pniels park;
-            park.a = R.x; park.b = R.y; park.cn = R.z; park.z = R.t;
-            r_tab.store(0, park);
+            pt A;
+            load_bytes_as_words(w, m.b, 57, 15);
+            ok = pt_decode_eddsa_words(A, w);
             MARK(2);
-            build_window_table(a_tab, pr.tau_pos ? pt_negate(A) : A);
+            build_window_table(a_tab, A);
             MARK(3);
         }
         {
-            const pniels park = r_tab.load(0);
             pt R;
-            R.x = park.a; R.y = park.b; R.z = park.cn; R.t = park.z;
+            load_bytes_as_words(w, m.a, 57, 15);
+            ok = pt_decode_eddsa_words(R, w) && ok;
             MARK(4);
             build_window_table(r_tab, pt_negate(R));
             MARK(5);
         }
-        pt V = ladder_double_var(bits1, a_tab, bits2, r_tab, LATTICE_WINDOWS);
+        pt V = ladder_double_var(bits1, a_tab, pr.tau_pos, bits2, r_tab, LATTICE_WINDOWS);
         MARK(6);
-        lattice_subtract_once(V, a_tab, pr.rho_even);
-        lattice_subtract_once(V, r_tab, pr.tau_even);
+        lattice_subtract_once(V, a_tab, pr.rho_even, pr.tau_pos);
+        lattice_subtract_once(V, r_tab, pr.tau_even, false);
         MARK(7);
         fb.add_to(V, pr.ts, mkbits);
         MARK(8);
