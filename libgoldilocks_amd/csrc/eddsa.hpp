@@ -353,6 +353,18 @@ GD_FN void lattice_subtract_once(pt &V, const AT &tab, bool doit, bool flip) {
     V.z = fe_select(V.z, W.z, doit);
     V.t = fe_select(V.t, W.t, doit);
 }
+// One encoded point (R, or the key) decoded and its window table of odd multiples built; negate: the table of -P.
+// A table type may bring an out-of-line overload of this (kernels.hpp does for the verification kernel's tables:
+// called once for the key and once for R, the two copies of 16 K instructions become one).
+template <class AT>
+GD_FN bool decode_into_table(AT &tab, const uint8_t *enc, bool negate) {
+    uint32_t w[15];
+    pt P;
+    load_bytes_as_words(w, enc, 57, 15);
+    const bool ok = pt_decode_eddsa_words(P, w);
+    build_window_table(tab, negate ? pt_negate(P) : P);
+    return ok;
+}
 // phase 2: decode A and R, walk, add the base point's part, test.
 // The key's table holds the multiples of +A whatever the sign of tau (the digits' signs are flipped at the lookups
 // instead), so that it can be SHARED: a batch's signatures of one key need its decoding and its table once
@@ -361,20 +373,9 @@ GD_FN void lattice_subtract_once(pt &V, const AT &tab, bool doit, bool flip) {
 template <class FB, class AT, class BITS, class MKBITS>
 GD_FN bool ed448_verify_lattice_walk(const Ed448Msg &m, const LatticePair &pr, const BITS &bits1, const BITS &bits2,
                                      const FB &fb, AT &a_tab, AT &r_tab, MKBITS &mkbits, bool shared_key, bool key_ok) {
-    uint32_t w[15];
     bool ok = key_ok;
-    if (!shared_key) {
-        pt A;
-        load_bytes_as_words(w, m.b, 57, 15);                                  // public key
-        ok = pt_decode_eddsa_words(A, w);
-        build_window_table(a_tab, A);
-    }
-    {
-        pt R;
-        load_bytes_as_words(w, m.a, 57, 15);                                  // R = sig[0:57]
-        ok = pt_decode_eddsa_words(R, w) && ok;
-        build_window_table(r_tab, pt_negate(R));                              // PR = -R
-    }
+    if (!shared_key) ok = decode_into_table(a_tab, m.b, false);               // the public key
+    ok = decode_into_table(r_tab, m.a, true) && ok;                           // PR = -R, R = sig[0:57]
     // PA = -+A by the sign of tau: the table of +A with every digit of rho flipped when tau is positive
     pt V = ladder_double_var(bits1, a_tab, pr.tau_pos, bits2, r_tab, LATTICE_WINDOWS);
     lattice_subtract_once(V, a_tab, pr.rho_even, pr.tau_pos);

@@ -243,6 +243,14 @@ struct LdsStepTable {
         return e;
     }
 };
+// eddsa.hpp's decode_into_table for these tables, out of line: k_ed448_verify calls it for the key and for R instead of
+// carrying two inlined copies (62 K -> 49 K instructions), and the register allocation of the decoding's
+// exponentiation no longer shares a function with the hash and the ladder: the kernel's .vgpr_spill_count goes
+// 422 -> 44; the function itself moves 148 registers to scratch and back, once per call, the caller's live state
+// among them.  Same time with pooled keys, 1 % less when every lane decodes its own key (profiles/r03/experiments.md B3).
+__device__ __noinline__ static bool decode_into_table(LdsStepTable<> tab, const uint8_t *enc, bool negate) {
+    return decode_into_table<LdsStepTable<>>(tab, enc, negate);
+}
 // The comb staged in LDS and gathered with wavefront shuffles.  Entry e occupies words
 // [49e, 49e+48) (stride 49 keeps the fill reads below conflict-free).  For comb j every lane
 // first reads 12 words with a LANE-dependent, index-INDEPENDENT address: lane l takes words
