@@ -61,15 +61,22 @@ GD_FN pt ml_scalarmul_u(const pt &b, const fe &x1, const BITS &bits) {
     const fe yz = fe_add(b.y, b.z);                 // Y + Z                  mag 2
     fe x2 = fe_one(), z2 = fe_zero(), x3 = x1, z3 = fe_one();
     bool swap = false;
+    // one read of the scalar per 32 steps: the word's next bit is kept in the sign position
 #pragma unroll 1
-    for (int t = ML_BITS - 1; t >= 0; t--) {
-        const bool k_t = ((bits.word(t >> 5) >> (t & 31)) & 1u) != 0;
-        const bool sw = swap != k_t;
-        swap = k_t;
-        fe a2 = fe_select(x2, x3, sw), a3 = fe_select(x3, x2, sw);
-        fe c2 = fe_select(z2, z3, sw), c3 = fe_select(z3, z2, sw);
-        ml_step(a2, c2, a3, c3, x1);
-        x2 = a2; z2 = c2; x3 = a3; z3 = c3;
+    for (int wi = (ML_BITS - 1) >> 5; wi >= 0; wi--) {
+        const int top = wi == ((ML_BITS - 1) >> 5) ? ((ML_BITS - 1) & 31) : 31;
+        uint32_t w = bits.word(wi) << (31 - top);
+#pragma unroll 1
+        for (int j = top; j >= 0; j--) {
+            const bool k_t = (int32_t)w < 0;
+            w <<= 1;
+            const bool sw = swap != k_t;
+            swap = k_t;
+            fe a2 = fe_select(x2, x3, sw), a3 = fe_select(x3, x2, sw);
+            fe c2 = fe_select(z2, z3, sw), c3 = fe_select(z3, z2, sw);
+            ml_step(a2, c2, a3, c3, x1);
+            x2 = a2; z2 = c2; x3 = a3; z3 = c3;
+        }
     }
     // (X1 : Z1) = u(sP), (X2 : Z2) = u((s+1)P)
     const fe X1 = fe_select(x2, x3, swap), Z1 = fe_select(z2, z3, swap);
