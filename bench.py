@@ -77,11 +77,14 @@ WORKLOADS = {
                  desc="goldilocks_448_precomputed_scalarmul(precomputed_base), 16-bit window table"),
     # half-size scalars (csrc/lattice.hpp): two decodings + two window tables + one 45-window ladder over both
     # points + two correcting additions + 28 base-point additions
-    # macs: every lane decodes its key and builds the key's table itself; macs_shared_keys: the key has a pooled table
-    # (one decoding and one table per DISTINCT key of the batch, kernels_verify.hip) -- what 2^20 signatures of 2^10
-    # keys run at; the per-key work is (64 728 + 24 624) * 2^10 / 2^20 = 87 MACs per signature more
-    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=522_128 + 87, macs_own_key=611_480,
-                   macs_shared_keys=522_128, keys=1024,
+    # macs_own_key: every lane decodes its key and builds the key's table itself (what "verify_distinct" runs);
+    # macs_shared_keys: the key has a pooled window table (one decoding and one table per DISTINCT key of the batch,
+    # kernels_verify.hip); macs_key_comb: the key has a fixed-base comb of its own -- keys that sign at least 32 of
+    # the batch's signatures on average, which is what 2^20 signatures of 2^10 keys run at: no ladder, R's decoding +
+    # the key's comb + the base point's additions; per key 3.46 M more (its decoding, 432 doublings, 256 entries),
+    # 3 377 per signature at 2^10 keys
+    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=204_408 + 3_377, macs_key_comb=204_408, macs_per_key_comb=3_458_392,
+                   macs_pooled_tables=522_128 + 87, macs_own_key=611_480, macs_shared_keys=522_128, keys=1024,
                    desc="goldilocks_ed448_verify, 32-byte messages, 2^10 distinct keys (SURVEY 8d), 1% corrupted"),
     "verify_distinct": dict(metric="Ed448 verifies/sec, every signature under its own key", unit="verifies/s", bytes=207,
                             macs=611_480, keys=None,

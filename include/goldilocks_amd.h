@@ -365,6 +365,14 @@ GOLDILOCKS_AMD_API size_t goldilocks_amd_get_wave_batch_max(void);
 #define GOLDILOCKS_AMD_KEY_POOL_DEFAULT (1u << 18)
 #define GOLDILOCKS_AMD_KEY_POOL_MIN_BATCH_DEFAULT (1u << 16)
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t min_batch);
+/* Keys that sign MANY signatures of a batch get more than a shared window table: a fixed-base comb of their own (4 x 7 x
+ * 16, 48 KiB per key, built on the device per call), with which a verification is src/eddsa.c's equation without a
+ * ladder -- 0.4 of the arithmetic.  Used when the batch averages at least `min_signatures_per_key` signatures per
+ * distinct key and has at most `keys` distinct keys (and is large enough for the pool above); otherwise the pool's
+ * rules apply.  Verdicts do not change.  keys = 0 turns the combs off.  Process-wide. */
+#define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 13)
+#define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 32
+GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t min_signatures_per_key);
 /* "gfx950", number of CUs, workspace bytes currently held */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
         size_t *workspace_bytes);

@@ -87,6 +87,7 @@ FUNCTIONS = {
     "goldilocks_amd_set_wave_batch_max": (None, "z"),
     "goldilocks_amd_get_wave_batch_max": (C.c_size_t, ""),
     "goldilocks_amd_set_verify_key_pool": (None, "zz"),
+    "goldilocks_amd_set_verify_key_combs": (None, "zz"),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -449,6 +450,15 @@ def set_verify_key_pool(keys=KEY_POOL_DEFAULT, min_batch=KEY_POOL_MIN_BATCH_DEFA
     """Verification shares one decoding and one window table between the signatures of a key: a pool of `keys`
     tables for batches of at least `min_batch` signatures (0 keys turns it off)."""
     lib().goldilocks_amd_set_verify_key_pool(int(keys), int(min_batch))
+
+
+KEY_COMBS_DEFAULT, KEY_COMBS_MIN_PER_KEY_DEFAULT = 1 << 13, 32
+
+
+def set_verify_key_combs(keys=KEY_COMBS_DEFAULT, min_signatures_per_key=KEY_COMBS_MIN_PER_KEY_DEFAULT):
+    """Keys that sign at least `min_signatures_per_key` signatures of a batch on average get a fixed-base comb each
+    (at most `keys` of them; 0 turns the combs off)."""
+    lib().goldilocks_amd_set_verify_key_combs(int(keys), int(min_signatures_per_key))
 
 
 def get_table_access():

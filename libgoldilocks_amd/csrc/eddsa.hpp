@@ -393,6 +393,26 @@ GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &
     return ed448_verify_lattice_walk(m, pr, bits1, bits2, fb, a_tab, r_tab, mkbits, shared_key, key_ok);
 }
 
+// Verification against a key that has a fixed-base comb (kernels_verify.hip: keys that sign many of a batch's
+// signatures): src/eddsa.c:253-306 as it stands -- P = (-h)*A + S*B, accept iff P equals the decoded R up to
+// 2-torsion (goldilocks_448_point_eq, src/goldilocks.c:644-653) -- with (-h)*A from the key's comb instead of a
+// ladder.  COMB: comb.load(j, idx) -> niels, COMB::plan its geometry.  The caller ANDs the key's own decoding in.
+template <class FB, class COMB, class STAGE, class MKBITS>
+GD_FN bool ed448_verify_keycomb(const Ed448Msg &m, const FB &fb, const COMB &comb, STAGE &stage, MKBITS &mkbits) {
+    uint32_t w[29];
+    shake256_114(w, m, m.total(), stage);
+    const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));     // -h mod q
+    load_bytes_as_words(w, m.a + 57, 57, 15);
+    const sc response = sc_decode_long_words<57>(w);                          // S mod q, no range check
+    pt R;
+    load_bytes_as_words(w, m.a, 57, 15);                                      // R = sig[0:57]
+    const bool ok = pt_decode_eddsa_words(R, w);
+    auto bits = mkbits(COMB::plan::recode(challenge), 0);
+    pt P = ladder_comb_ahead(bits, comb);                                     // -h*A, T included
+    fb.add_to(P, response, mkbits);                                           // + S*B
+    return ok && fe_eq(fe_mul(P.y, R.x), fe_mul(R.y, P.x));
+}
+
 // ------------------------------------------------------------------ key derivation and signing
 // ("next" row f1 of SURVEY.md section 8; restates src/eddsa.c:34-48, 98-230)
 

@@ -190,6 +190,17 @@ __device__ __forceinline__ pniels pniels_load(const uint4 *q) {
     e.z = fe_load(q + 12);
     return e;
 }
+__device__ __forceinline__ void niels_store(uint4 *q, const niels &e) {   // 12 uint4: an affine entry of a comb
+    fe_store(q, e.a);
+    fe_store(q + 4, e.b);
+    fe_store(q + 8, e.cn);
+}
+// The 28 teeth of a 4 x 7 x 16 comb as pniels, 16 uint4 each, in LDS or in global memory (scalarmul.hpp comb_big_entry)
+struct TeethAt {
+    const uint4 *p;
+    __device__ __forceinline__ pniels load(uint32_t m) const { return pniels_load(p + 16 * m); }
+};
+using LdsTeeth = TeethAt;
 struct LaneTable {  // this lane's window table in the HBM workspace, lane-contiguous; the digit picks the address
     static constexpr bool direct = true;   // lookup = one entry's loads (a two-table ladder may issue both entries' at once)
     uint4 *p;
@@ -336,6 +347,22 @@ struct GlobalBwt {
         return e;
     }
 };
+// A 4 x 7 x 16 comb in global memory, read by the digit (public scalars only): the comb of a verification key that
+// signed many of a batch's signatures (kernels_verify.hip), 256 affine niels = 48 KiB per key.
+constexpr int KEY_TEETH_U4 = comb_big::TEETH * comb_big::COMBS * 16;   // 28 pniels per key while its comb is built
+constexpr int KEY_COMB_U4 = comb_big::ENTRIES * 12;
+struct GlobalCombBig {
+    using plan = comb_big;
+    const uint4 *p;
+    __device__ __forceinline__ niels load(int j, uint32_t idx) const {
+        const uint4 *q = p + 12 * (comb_big::PER_COMB * j + idx);
+        niels e;
+        e.a = fe_load(q);
+        e.b = fe_load(q + 4);
+        e.cn = fe_load(q + 8);
+        return e;
+    }
+};
 
 struct LdsStage {  // 136-byte sponge block per lane, word-interleaved across lanes
     uint32_t *p;   // &stage[threadIdx.x]
@@ -454,9 +481,22 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
 GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slot_of, uint32_t *__restrict__ key_list,
                           uint32_t *__restrict__ hash_slots, uint32_t hash_mask, uint32_t *__restrict__ ctrl,
                           const uint8_t *__restrict__ pk, uint32_t n);
-GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, uint32_t *__restrict__ ctrl,
-                              const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk, uint32_t n,
-                              uint32_t capacity);
+GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t pool_capacity, uint32_t comb_capacity,
+                            uint32_t comb_min_per_key);
+GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
+                              const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk);
+extern "C" __global__ void k_verify_key_teeth(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok,
+                                              const uint32_t *__restrict__ ctrl, const uint32_t *__restrict__ key_list,
+                                              const uint8_t *__restrict__ pk);
+GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
+                             uint4 *__restrict__ chain);
+GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
+                                 const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
+                                 const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
+                                 const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
+                                 const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
+                                 const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
+                                 const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl);
 GD_KERNEL k_ed448_derive_public_key(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
                                     const uint4 *__restrict__ bwt, uint4 *__restrict__ workspace);
 GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,

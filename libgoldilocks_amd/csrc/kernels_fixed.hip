@@ -172,16 +172,7 @@ GD_KERNEL k_recomb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) 
         pniels_store(s_teeth + 16 * e, pt_to_pniels(t));
     }
     __syncthreads();
-    const uint32_t j = e / comb_big::PER_COMB, idx = e % comb_big::PER_COMB;
-    pt p = pniels_to_pt(pniels_load(s_teeth + 16 * (comb_big::TEETH - 1 + comb_big::TEETH * j)), false);
-#pragma unroll 1
-    for (uint32_t k = 0; k + 1 < (uint32_t)comb_big::TEETH; k++)
-        pt_add_pniels(p, pniels_load(s_teeth + 16 * (k + comb_big::TEETH * j)), ((idx >> k) & 1u) == 0, true);
-    fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
-    uint4 *q = dst + 12 * (size_t)e;
-    fe_store(q, fe_mul(fe_weak(fe_sub<2>(p.y, p.x)), zi));
-    fe_store(q + 4, fe_mul(fe_weak(fe_add(p.x, p.y)), zi));
-    fe_store(q + 8, fe_mul(fe_mulw(p.t, TWO_EFF_D), zi));
+    niels_store(dst + 12 * (size_t)e, comb_big_entry(LdsTeeth{s_teeth}, e));
 }
 
 // enc[i] = RFC 8032 encoding of 4 * pts[i]   (ref: goldilocks_448_point_mul_by_ratio_and_encode_like_eddsa,

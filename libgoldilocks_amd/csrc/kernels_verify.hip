@@ -39,7 +39,8 @@ GD_KERNEL k_half_size_pair(uint32_t *__restrict__ rho, uint32_t *__restrict__ ta
 // signatures bring a key of their own, gains too little (lanes with and without a pooled key in one wave run both
 // paths: + 4 % measured with a quarter of the keys pooled), so then no table is pooled (ctrl[1] = 0) and every lane
 // decodes its key and builds its table itself, as before.
-// ctrl: [0] distinct keys seen, [1] pooled keys (written by k_verify_key_tables' first block), both zeroed by the host
+// ctrl: [0] distinct keys seen, [1] keys with a pooled window table, [2] keys with a comb (k_verify_key_mode: at most
+// one of the two is non-zero); zeroed by the host
 __device__ __forceinline__ uint32_t key_hash(const uint32_t (&w)[15]) {
     uint32_t h = 0x9e3779b9u;
 #pragma unroll
@@ -76,13 +77,21 @@ GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slo
         }
     }
 }
-GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, uint32_t *__restrict__ ctrl,
-                              const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk, uint32_t n,
-                              uint32_t capacity) {
-    __shared__ uint4 s_step[STEP_LDS_U4];
+// ctrl[1], ctrl[2]: how this batch's keys are served (one thread, after the dedupe)
+GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t pool_capacity, uint32_t comb_capacity,
+                            uint32_t comb_min_per_key) {
+    if (blockIdx.x || threadIdx.x) return;
     const uint32_t distinct = ctrl[0];
-    const uint32_t pooled = 2 * (uint64_t)distinct > n || distinct > capacity ? 0u : distinct;
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[1] = pooled;
+    uint32_t pooled = 0, combed = 0;
+    if (distinct <= comb_capacity && (uint64_t)distinct * comb_min_per_key <= n) combed = distinct;
+    else if (2 * (uint64_t)distinct <= n && distinct <= pool_capacity) pooled = distinct;
+    ctrl[1] = pooled;
+    ctrl[2] = combed;
+}
+GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
+                              const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk) {
+    __shared__ uint4 s_step[STEP_LDS_U4];
+    const uint32_t pooled = ctrl[1];
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < pooled; k += stride) {
         uint32_t w[15];
@@ -91,6 +100,89 @@ GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ ke
         key_ok[k] = pt_decode_eddsa_words(A, w) ? 1 : 0;
         LdsStepTable<> tab{pool + (size_t)KEY_TABLE_U4 * k, s_step + threadIdx.x};
         build_window_table(tab, A);
+    }
+}
+
+// ---- a fixed-base COMB per key, when a batch's keys sign many signatures each.
+// With a comb of the key the challenge's multiple needs no ladder at all: P = (-h)*A from the key's 4 x 7 x 16 comb
+// (15 doublings + 63 mixed additions, scalarmul.hpp comb_big: what the library's own base point gets), S*B added
+// from the base point's window table, and P is compared with the decoded R as the reference's
+// goldilocks_448_point_eq does (src/eddsa.c:299-305, src/goldilocks.c:644-653): the equation of src/eddsa.c as it
+// stands, no short pair, no table per signature -- 207 K multiply-accumulates instead of 522 K.  What it costs is
+// the comb: 432 successive doublings and 256 entries per key, about 1.2 M multiply-accumulates = six such
+// verifications, and a latency of 432 doublings; so only keys' worth it: ctrl[2] != 0 iff the batch averages at least
+// comb_min_per_key signatures per distinct key (goldilocks_amd_set_verify_key_combs; 32 by default) and the keys fit.
+//   k_verify_key_teeth   (kernels_wave.hip) wave k: decode key k, teeth 2^(16 m) * A_k, m < 28, by row arithmetic
+//   k_verify_key_combs   block: lane e computes entry e of a key's comb = a signed sum of 7 teeth, for up to 8 keys,
+//                        and normalises them with one shared inversion
+//   k_ed448_verify_keycomb   the verification itself
+// chain: 8 uint4 per (block, round, lane) -- the shared inversion's parking slots (InvChain), 8 rounds
+GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
+                             uint4 *__restrict__ chain) {
+    static_assert(comb_big::ENTRIES == BLOCK, "one lane per entry");
+    constexpr uint32_t ROUNDS = 8;
+    __shared__ uint4 s_teeth[KEY_TEETH_U4];
+    const uint32_t combed = ctrl[2], e = threadIdx.x;
+    uint4 *const my_chain = chain + ((size_t)blockIdx.x * ROUNDS * BLOCK + e) * 8;
+    // the keys of a block: blockIdx.x, + gridDim.x, ...; a lane computes ITS entry of up to 8 of them unnormalised,
+    // shares one inversion between them (Montgomery's trick along the lane, fixed_bodies.hpp) and walks back
+    for (uint32_t first = blockIdx.x; first < combed; first += ROUNDS * gridDim.x) {
+        InvChain ch;
+        ch.begin();
+        uint32_t r = 0;
+#pragma unroll 1
+        for (uint32_t k = first; r < ROUNDS && k < combed; r++, k += gridDim.x) {   // block-uniform
+            __syncthreads();
+            for (uint32_t i = threadIdx.x; i < (uint32_t)KEY_TEETH_U4; i += BLOCK) s_teeth[i] = teeth[(size_t)KEY_TEETH_U4 * k + i];
+            __syncthreads();
+            const pt p = comb_big_entry_projective(LdsTeeth{s_teeth}, e);
+            uint4 *q = combs + (size_t)KEY_COMB_U4 * k + 12 * e;
+            fe_store(q, fe_weak(fe_sub<2>(p.y, p.x)));
+            fe_store(q + 4, fe_weak(fe_add(p.x, p.y)));
+            fe_store(q + 8, fe_mulw(p.t, TWO_EFF_D));
+            ch.push(my_chain + 8 * BLOCK * r, fe_add(p.z, p.z), true);
+        }
+        ch.invert();
+#pragma unroll 1
+        while (r--) {
+            const uint32_t k = first + r * gridDim.x;
+            const fe zi = ch.pop(my_chain + 8 * BLOCK * r);
+            uint4 *q = combs + (size_t)KEY_COMB_U4 * k + 12 * e;
+            fe_store(q, fe_mul(fe_load(q), zi));
+            fe_store(q + 4, fe_mul(fe_load(q + 4), zi));
+            fe_store(q + 8, fe_mul(fe_load(q + 8), zi));
+        }
+    }
+}
+GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
+                                 const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
+                                 const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
+                                 const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
+                                 const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
+                                 const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
+                                 const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl) {
+    __shared__ uint32_t s_bits[16 * BLOCK];
+    if (!ctrl[2]) return;                       // this batch's keys are served otherwise (k_ed448_verify)
+    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t stride = gridDim.x * BLOCK;
+    GlobalBwt bwt_tab{bwt};
+    FixedBwt<GlobalBwt> b_tab{bwt_tab};
+    LdsStage stage{s_bits + threadIdx.x};       // (unused by the word-granular absorb)
+    LdsMkBitsVerify mk{s_bits + threadIdx.x};
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {     // wave-uniform, as in k_ed448_verify
+        const uint32_t slot = lane + r * stride;
+        const bool live = slot < n;
+        const uint32_t i = live ? slot : n - 1;
+        const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
+        const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
+        const bool fits = len64 < MAX_MESSAGE_BYTES;
+        const Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg,
+                                                  fits ? (uint32_t)len64 : 0u, prehashed, ctx, ctx_len);
+        const uint32_t k = slot_of[rep[i]];
+        const GlobalCombBig comb{combs + (size_t)KEY_COMB_U4 * k};
+        const bool ok = ed448_verify_keycomb(m, b_tab, comb, stage, mk) && key_ok[k] != 0;
+        if (live) status[i] = ok && fits ? -1 : 0;
     }
 }
 
@@ -106,6 +198,7 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
     __shared__ uint32_t s_bits[16 * BLOCK];
     __shared__ uint32_t s_stage[34 * BLOCK];
     __shared__ uint4 s_step[STEP_LDS_U4];   // the table builds' step (LdsStepTable)
+    if (ctrl && ctrl[2]) return;                // this batch's keys have combs (k_ed448_verify_keycomb)
     const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
     const uint32_t stride = gridDim.x * BLOCK;
     GlobalBwt bwt_tab{bwt};

@@ -91,6 +91,33 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_precompute_wave(uint64_t *
         wc::precompute(L, s_work[w], tables + (size_t)op * (80 * 24), wc::load_point(L, base + 32 * (size_t)op));
 }
 
+// Verification keys that get a comb of their own (kernels_verify.hip): key k decoded and its 28 teeth 2^(16 m) * A_k
+// written as pniels, ONE KEY PER WAVE -- the chain of 432 doublings is pure latency, and a wave's doubling is two row
+// multiplications (0.25 ms for the chain instead of the 1.7 ms of a lane's).  A pniels' 64 words are the wave's 64
+// lanes (rows a, b, cn, z): every tooth is one coalesced 256-byte store.
+extern "C" __global__ void __launch_bounds__(BLOCK) k_verify_key_teeth(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok,
+                                                                       const uint32_t *__restrict__ ctrl,
+                                                                       const uint32_t *__restrict__ key_list,
+                                                                       const uint8_t *__restrict__ pk) {
+    const wc::Lane L = wc::make_lane();
+    const uint32_t combed = ctrl[2], me = threadIdx.x & 63u, swap_row = L.row ^ 1u;
+    const uint32_t nwaves = gridDim.x * (BLOCK / 64);
+    for (uint32_t k = blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6); k < combed; k += nwaves) {   // wave-uniform
+        wc::wfe X, Y, Z, T;
+        const bool ok = wc::decode_eddsa_rows(L, pk + 57 * (size_t)key_list[k], X, Y, Z, T);
+        if (me == 0) key_ok[k] = ok ? 1 : 0;
+        wc::wfe P = wc::pack_point<0>(L, X, Y, Z, T);
+        uint32_t *out = reinterpret_cast<uint32_t *>(teeth + (size_t)KEY_TEETH_U4 * k);
+#pragma unroll 1
+        for (int m = 0; m < comb_big::TEETH * comb_big::COMBS; m++) {
+            out[64 * m + me] = wc::to_pniels(L, P, swap_row);
+            if (m + 1 == comb_big::TEETH * comb_big::COMBS) break;
+#pragma unroll 1
+            for (int d = 0; d < comb_big::SPACING; d++) P = wc::dbl(L, P);
+        }
+    }
+}
+
 // scaled[i] = encode(scalar[i] * decode(base[i])), one operation per wave; an encoding that does not decode gives
 // status 0 and (unless short_circuit) the base point is multiplied instead   (ref: goldilocks_448_direct_scalarmul,
 // src/goldilocks.c:888-903)

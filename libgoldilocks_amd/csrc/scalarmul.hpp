@@ -166,6 +166,58 @@ GD_FN pt ladder_comb(const BITS &bits, const COMB &comb) {
     return acc;
 }
 
+// ---- the 4 x 7 x 16 comb of an ARBITRARY point P (a caller's table re-combed, kernels_fixed.hip; a verification
+// key that signed many of a batch's signatures, kernels_verify.hip).  Tooth m (m < 28) is 2^(16 m) * P; entry
+// e = 64 j + idx is T_(6+7j) + sum_{k<6} (+-) T_(k+7j), + iff bit k of idx, as an affine niels in our form.
+// TEETH: teeth.load(m) -> pniels.
+template <class TEETH>
+GD_FN pt comb_big_entry_projective(const TEETH &teeth, uint32_t e) {
+    const uint32_t j = e / comb_big::PER_COMB, idx = e % comb_big::PER_COMB;
+    pt p = pniels_to_pt(teeth.load(comb_big::TEETH - 1 + comb_big::TEETH * j), false);
+#pragma unroll 1
+    for (uint32_t k = 0; k + 1 < (uint32_t)comb_big::TEETH; k++)
+        pt_add_pniels(p, teeth.load(k + comb_big::TEETH * j), ((idx >> k) & 1u) == 0, true);
+    return p;
+}
+GD_FN niels comb_big_normalise(const pt &p) {
+    const fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
+    niels n;
+    n.a = fe_mul(fe_weak(fe_sub<2>(p.y, p.x)), zi);
+    n.b = fe_mul(fe_weak(fe_add(p.x, p.y)), zi);
+    n.cn = fe_mul(fe_mulw(p.t, TWO_EFF_D), zi);
+    return n;
+}
+template <class TEETH>
+GD_FN niels comb_big_entry(const TEETH &teeth, uint32_t e) { return comb_big_normalise(comb_big_entry_projective(teeth, e)); }
+
+// The same walk for a comb in global memory read by the digit (public scalars: a verification key's own comb): the
+// entry of the NEXT addition is requested before the current one, as in ladder_bwt_onto below.
+template <class BITS, class COMB>
+GD_FN pt ladder_comb_ahead(const BITS &bits, const COMB &comb) {
+    using PLAN = typename COMB::plan;
+    constexpr int S = PLAN::SPACING, N = PLAN::COMBS, T = PLAN::TEETH;
+    uint32_t idx;
+    bool neg;
+    signed_digit_w<T>(comb_teeth_of<PLAN>(bits, S - 1, 0), idx, neg);
+    pt acc = niels_to_pt(comb.load(0, idx), neg);
+    signed_digit_w<T>(comb_teeth_of<PLAN>(bits, S - 1, 1 % N), idx, neg);
+    niels next = comb.load(1 % N, idx);
+#pragma unroll 1
+    for (int s = 1; s < S * N; s++) {              // step s: spacing position S - 1 - s / N, comb s % N
+        const int j = s % N;
+        if (j == 0) pt_double(acc, true);
+        const niels e = next;
+        const bool neg_e = neg;
+        if (s + 1 < S * N) {
+            const int jn = (s + 1) % N;
+            signed_digit_w<T>(comb_teeth_of<PLAN>(bits, S - 1 - (s + 1) / N, jn), idx, neg);
+            next = comb.load(jn, idx);
+        }
+        pt_add_niels(acc, e, neg_e, !(j == N - 1 && s + 1 < S * N));
+    }
+    return acc;
+}
+
 // Fixed-base, no doublings: s*B = sum_i (+-) T_i[idx_i] over the signed BWT_BITS-bit digits of the
 // recoded scalar W = (s + 2^(BWT_BITS*BWT_WINDOWS) - 1)/2 mod q, with T_i[k] = (2k+1) * 2^(BWT_BITS*i) * B
 // as affine niels, built once per device.  With 8-bit digits: 56 x 128 entries (1.3 MiB), 55 mixed

@@ -377,6 +377,61 @@ int hs_ed448_verify_lattice_shared_key(const uint8_t *sig, const uint8_t *pk, co
     Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
     return ed448_verify_lattice(m, fb, ta, tr, stage, mk, true, key_ok) ? -1 : 0;
 }
+// ... and against a key that has a fixed-base comb of its own (eddsa.hpp ed448_verify_keycomb; kernels_verify.hip
+// builds one per key when a batch's keys sign many signatures each).  The comb is built the way the device builds it:
+// teeth 2^(16 m) * A by doubling, every entry a signed sum of 7 teeth (scalarmul.hpp comb_big_entry_projective), one
+// inversion for the key's 256 entries (Montgomery's trick); kept for the next call with the same key.
+struct HostTeeth {
+    pniels t[comb_big::TEETH * comb_big::COMBS];
+    pniels load(uint32_t m) const { return t[m]; }
+};
+int hs_ed448_verify_keycomb(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen, uint8_t prehashed,
+                            const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    FixedComb<HostComb> fb{comb};
+    static HostCombBig kc;
+    static uint8_t have_pk[57];
+    static bool have = false, key_ok = false;
+    if (!have || memcmp(have_pk, pk, 57) != 0) {
+        uint32_t w[15];
+        bytes_to_words(w, pk, 57, 15);
+        pt A;
+        key_ok = pt_decode_eddsa_words(A, w);
+        static HostTeeth teeth;
+        pt tooth = A;
+        for (int m = 0; m < comb_big::TEETH * comb_big::COMBS; m++) {
+            teeth.t[m] = pt_to_pniels(tooth);
+            if (m + 1 < comb_big::TEETH * comb_big::COMBS)
+                for (int d = 0; d < comb_big::SPACING; d++) pt_double(tooth, d + 1 == comb_big::SPACING);
+        }
+        static pt proj[comb_big::ENTRIES];
+        static fe prefix[comb_big::ENTRIES];
+        fe acc = fe_one();
+        for (int e = 0; e < comb_big::ENTRIES; e++) {
+            proj[e] = comb_big_entry_projective(teeth, (uint32_t)e);
+            prefix[e] = acc;
+            const fe z2 = fe_weak(fe_add(proj[e].z, proj[e].z));
+            acc = fe_mul(acc, fe_is_zero(z2) ? fe_one() : z2);
+        }
+        fe inv = fe_invert(acc);
+        for (int e = comb_big::ENTRIES - 1; e >= 0; e--) {
+            const fe z2 = fe_weak(fe_add(proj[e].z, proj[e].z));
+            const bool zero = fe_is_zero(z2);
+            const fe zi = zero ? fe_zero() : fe_mul(inv, prefix[e]);
+            inv = fe_mul(inv, zero ? fe_one() : z2);
+            kc.e[e].a = fe_mul(fe_weak(fe_sub<2>(proj[e].y, proj[e].x)), zi);
+            kc.e[e].b = fe_mul(fe_weak(fe_add(proj[e].x, proj[e].y)), zi);
+            kc.e[e].cn = fe_mul(fe_mulw(proj[e].t, TWO_EFF_D), zi);
+        }
+        memcpy(have_pk, pk, 57);
+        have = true;
+    }
+    HostStage stage;
+    HostMkBits mk;
+    Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
+    return ed448_verify_keycomb(m, fb, kc, stage, mk) && key_ok ? -1 : 0;
+}
 // the short pair of a challenge: rho (15 words), tau (8 words, two's complement)
 void hs_half_size_pair(uint32_t *rho, uint32_t *tau, const uint64_t *h) {
     wide15 r;

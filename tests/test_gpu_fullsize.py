@@ -433,7 +433,8 @@ def test_config5_share_of_one_gpu_in_one_launch(ga, O, log2n):
 
 def test_verification_shares_the_tables_of_repeated_keys(ga, O):
     """For large batches the verification kernel decodes every DISTINCT public key once and builds its window table
-    once (goldilocks_amd_set_verify_key_pool; kernels_verify.hip).  Verdicts must not depend on it: the same batch
+    once (goldilocks_amd_set_verify_key_pool; kernels_verify.hip), or -- keys that sign many signatures each -- a
+    fixed-base comb per key (goldilocks_amd_set_verify_key_combs).  Verdicts must not depend on it: the same batch
     -- signatures of 37 keys, rejects of every kind, an undecodable key that many signatures share -- with the pool
     off, with the default pool, with a pool too small for the batch's keys (then nothing is pooled) and with a batch
     of all-distinct keys (no pool either: more than half of the signatures bring their own)."""
@@ -464,9 +465,22 @@ def test_verification_shares_the_tables_of_repeated_keys(ga, O):
         return st.cpu().numpy()
     try:
         got = {}
-        for name, (keys, min_batch) in dict(off=(0, 0), default=(ga.KEY_POOL_DEFAULT, 1 << 16), tiny=(5, 1 << 16)).items():
+        # (pool keys, min batch, comb keys, min signatures per key): the batch has 37 + 1 + 8 192 distinct keys
+        modes = dict(off=(0, 0, 0, 1), tables=(ga.KEY_POOL_DEFAULT, 1 << 16, 0, 1), tiny=(5, 1 << 16, 0, 1),
+                     combs=(ga.KEY_POOL_DEFAULT, 1 << 16, 1 << 14, 8), default=(ga.KEY_POOL_DEFAULT, 1 << 16, ga.KEY_COMBS_DEFAULT, ga.KEY_COMBS_MIN_PER_KEY_DEFAULT))
+        for name, (keys, min_batch, comb_keys, per_key) in modes.items():
             ga.set_verify_key_pool(keys, min_batch)
+            ga.set_verify_key_combs(comb_keys, per_key)
             got[name] = run(d_sig, d_pk, d_msg, n)
+        # few keys only (the lanes whose key is one of a kind left out): 2^16 signatures of 38 keys -> combs by default
+        few = np.flatnonzero(kind != 9)[: 1 << 16]
+        d_few = torch.from_numpy(few).cuda()
+        ga.set_verify_key_pool()
+        ga.set_verify_key_combs()
+        st_few = run(d_sig[d_few].contiguous(), d_pk[d_few].contiguous(), d_msg[d_few].contiguous(), len(few))
+        ga.set_verify_key_combs(0, 1)
+        assert (run(d_sig[d_few].contiguous(), d_pk[d_few].contiguous(), d_msg[d_few].contiguous(), len(few)) == st_few).all()
+        assert (st_few == got["off"][few]).all()
         for name, st in got.items():
             assert set(np.unique(st)) <= {-1, 0}, name
             assert ((st == 0) >= want_bad).all(), name           # every corrupted lane is rejected
@@ -485,8 +499,10 @@ def test_verification_shares_the_tables_of_repeated_keys(ga, O):
         ga.dev("ed448_sign", d_sig2.data_ptr(), d_sk2.data_ptr(), d_pk2.data_ptr(), d_msg.data_ptr(), None, 24, 0, None, 0, m, None)
         d_sig2[::9, 70] ^= 4
         ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT, 1 << 15)
+        ga.set_verify_key_combs()
         st2 = run(d_sig2, d_pk2, d_msg, m)
         bad2 = (np.arange(m) % 9) == 0
         assert ((st2 == -1) == ~bad2).all()
     finally:
         ga.set_verify_key_pool()
+        ga.set_verify_key_combs()

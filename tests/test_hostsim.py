@@ -219,7 +219,28 @@ def test_mac_counts_match_bench(H, O):
     # a key with a pooled table (shared by the signatures of a batch): its decoding and its table are not the lane's,
     # but one lane's per distinct key: (decoding + table) * 2^10 keys / 2^20 signatures more per signature
     assert W["verify"]["macs_shared_keys"] == own - c["decode_eddsa"] - c["table16"]
-    assert W["verify"]["macs"] == W["verify"]["macs_shared_keys"] + (c["decode_eddsa"] + c["table16"]) * W["verify"]["keys"] // 2**20
+    assert W["verify"]["macs_pooled_tables"] == W["verify"]["macs_shared_keys"] + (c["decode_eddsa"] + c["table16"]) * W["verify"]["keys"] // 2**20
+    # a key with a comb of its own (keys that sign many of a batch's signatures: BASELINE config 4): R's decoding, the
+    # comb ladder, the base point's additions, the comparison; per key: its decoding, 432 doublings, 256 entries of
+    # 6 additions each and their normalisation (counted with ONE inversion per key; the device shares one between the
+    # keys a lane serves)
+    H.hs_ed448_verify_keycomb.restype = C.c_int
+    seen = set()
+    for i in range(3):
+        m = (C.c_uint8 * 32).from_buffer_copy(msgs[i])
+        counts = []
+        for _ in range(2):                                    # the first call with a key builds its comb
+            H.hs_mac_counter_reset()
+            assert H.hs_ed448_verify_keycomb(p(sigs[i]), p(pks[i]), m, C.c_size_t(32), C.c_uint8(0), None, C.c_uint8(0), p(comb)) == -1
+            counts.append(H.hs_mac_counter_get())
+        seen.add((counts[0] - counts[1], counts[1]))
+    assert len(seen) == 1
+    per_key, per_sig = seen.pop()
+    per_sig += 28 * c["add_niels_t"] - (c["comb"] + c["pt_add"])
+    assert per_sig == c["decode_eddsa"] + c["comb_big"] + 28 * c["add_niels_t"] + 2 * c["fe_mul"]
+    assert (W["verify"]["macs_key_comb"], W["verify"]["macs_per_key_comb"]) == (per_sig, per_key)
+    assert W["verify"]["macs"] == per_sig + per_key * W["verify"]["keys"] // 2**20
+    assert per_sig < 0.42 * W["verify"]["macs_shared_keys"]
 
 
 def test_big_comb_of_the_base_point_matches_oracle(H, O):
@@ -300,6 +321,7 @@ def test_verification_with_half_size_scalars(H, O):
     f7 = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "f7_verify_torsion.json")))["cases"]
     H.hs_ed448_verify_lattice.restype = C.c_int
     H.hs_ed448_verify_lattice_shared_key.restype = C.c_int
+    H.hs_ed448_verify_keycomb.restype = C.c_int
     want = _gen.oracle_verify(O, sigs, pks, mlist)
     for i in range(n):
         m = (C.c_uint8 * len(mlist[i])).from_buffer_copy(mlist[i])
@@ -311,6 +333,11 @@ def test_verification_with_half_size_scalars(H, O):
         got = H.hs_ed448_verify_lattice_shared_key(sigs[i].ctypes.data_as(C.c_void_p), pks[i].ctypes.data_as(C.c_void_p), m,
                                                    C.c_size_t(len(mlist[i])), C.c_uint8(0), None, C.c_uint8(0), tab)
         assert got == want[i], ("shared key", i)
+        # ... and with a fixed-base comb of the key (a key that signs many of a batch's signatures): the reference's
+        # equation without a ladder
+        got = H.hs_ed448_verify_keycomb(sigs[i].ctypes.data_as(C.c_void_p), pks[i].ctypes.data_as(C.c_void_p), m,
+                                        C.c_size_t(len(mlist[i])), C.c_uint8(0), None, C.c_uint8(0), tab)
+        assert got == want[i], ("key comb", i)
     assert (want == -1).sum() >= 10 and (want == 0).sum() >= 10
     accepted = rejected = 0
     for c in f7:
@@ -321,6 +348,8 @@ def test_verification_with_half_size_scalars(H, O):
         assert got == c["verdict"], c["kind"]
         assert H.hs_ed448_verify_lattice_shared_key(sig, pk, mb, C.c_size_t(len(msg)), C.c_uint8(c["prehashed"]), cb,
                                                     C.c_uint8(len(ctx)), tab) == c["verdict"], ("shared key", c["kind"])
+        assert H.hs_ed448_verify_keycomb(sig, pk, mb, C.c_size_t(len(msg)), C.c_uint8(c["prehashed"]), cb,
+                                         C.c_uint8(len(ctx)), tab) == c["verdict"], ("key comb", c["kind"])
         accepted += got == -1; rejected += got == 0
     assert accepted >= 4 and rejected >= 4
 
