@@ -287,7 +287,8 @@ def make_workload(name, cx, access):
         m = min(n, SAMPLE)
         return dict(kind="verify", sigs=v["sig"][:m], pks=v["pk"][:m], msgs=[x.tobytes() for x in v["msg"][:m]],
                     got=host(status[:m]))
-    return dict(step=step, kernel="k_ed448_verify", check=check, sample=sample)
+    # 2^10 keys: every key gets a fixed-base comb (kernels_verify.hip); all-distinct keys: every lane for itself
+    return dict(step=step, kernel="k_ed448_verify" if name == "verify_distinct" else "k_ed448_verify_keycomb", check=check, sample=sample)
 
 
 def verify_inputs(cx, distinct=False):

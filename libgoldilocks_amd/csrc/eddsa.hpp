@@ -408,7 +408,7 @@ GD_FN bool ed448_verify_keycomb(const Ed448Msg &m, const FB &fb, const COMB &com
     load_bytes_as_words(w, m.a, 57, 15);                                      // R = sig[0:57]
     const bool ok = pt_decode_eddsa_words(R, w);
     auto bits = mkbits(COMB::plan::recode(challenge), 0);
-    pt P = ladder_comb_ahead(bits, comb);                                     // -h*A, T included
+    pt P = ladder_comb(bits, comb);                                           // -h*A, T included
     fb.add_to(P, response, mkbits);                                           // + S*B
     return ok && fe_eq(fe_mul(P.y, R.x), fe_mul(R.y, P.x));
 }

@@ -190,34 +190,6 @@ GD_FN niels comb_big_normalise(const pt &p) {
 template <class TEETH>
 GD_FN niels comb_big_entry(const TEETH &teeth, uint32_t e) { return comb_big_normalise(comb_big_entry_projective(teeth, e)); }
 
-// The same walk for a comb in global memory read by the digit (public scalars: a verification key's own comb): the
-// entry of the NEXT addition is requested before the current one, as in ladder_bwt_onto below.
-template <class BITS, class COMB>
-GD_FN pt ladder_comb_ahead(const BITS &bits, const COMB &comb) {
-    using PLAN = typename COMB::plan;
-    constexpr int S = PLAN::SPACING, N = PLAN::COMBS, T = PLAN::TEETH;
-    uint32_t idx;
-    bool neg;
-    signed_digit_w<T>(comb_teeth_of<PLAN>(bits, S - 1, 0), idx, neg);
-    pt acc = niels_to_pt(comb.load(0, idx), neg);
-    signed_digit_w<T>(comb_teeth_of<PLAN>(bits, S - 1, 1 % N), idx, neg);
-    niels next = comb.load(1 % N, idx);
-#pragma unroll 1
-    for (int s = 1; s < S * N; s++) {              // step s: spacing position S - 1 - s / N, comb s % N
-        const int j = s % N;
-        if (j == 0) pt_double(acc, true);
-        const niels e = next;
-        const bool neg_e = neg;
-        if (s + 1 < S * N) {
-            const int jn = (s + 1) % N;
-            signed_digit_w<T>(comb_teeth_of<PLAN>(bits, S - 1 - (s + 1) / N, jn), idx, neg);
-            next = comb.load(jn, idx);
-        }
-        pt_add_niels(acc, e, neg_e, !(j == N - 1 && s + 1 < S * N));
-    }
-    return acc;
-}
-
 // Fixed-base, no doublings: s*B = sum_i (+-) T_i[idx_i] over the signed BWT_BITS-bit digits of the
 // recoded scalar W = (s + 2^(BWT_BITS*BWT_WINDOWS) - 1)/2 mod q, with T_i[k] = (2k+1) * 2^(BWT_BITS*i) * B
 // as affine niels, built once per device.  With 8-bit digits: 56 x 128 entries (1.3 MiB), 55 mixed

@@ -27,7 +27,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_default" -- 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_defaultresident" -- \
     python3 "$BENCH" --steps 5 --warmup 1 --no-end-to-end > "$OUT/stats_defaultresident.log" 2>&1
 
-for wl in varbase fixed base verify sign x448 direct; do
+for wl in varbase fixed base verify verify_distinct sign x448 direct; do
     python3 "$BENCH" --workload $wl $Q > "$DST/bench_$wl.json" 2> "$OUT/bench_$wl.err"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- \
         python3 "$BENCH" --workload $wl --steps 5 --warmup 1 $Q > "$OUT/stats_$wl.log" 2>&1
@@ -46,7 +46,7 @@ pmc() {   # pmc <tag> <workload> <extra bench args...> -- <counters...>
     rocprofv3 --pmc "$@" --output-format csv -d "$OUT/pmc_${tag}_$wl" -- \
         python3 "$BENCH" --workload $wl "${extra[@]}" --steps 2 --warmup 1 $Q > "$OUT/pmc_${tag}_$wl.log" 2>&1
 }
-for wl in varbase fixed base verify; do
+for wl in varbase fixed base verify verify_distinct; do
     pmc FETCH $wl -- FETCH_SIZE
     pmc WRITE $wl -- WRITE_SIZE
 done
@@ -54,7 +54,7 @@ pmc FETCHFAST varbase $FAST -- FETCH_SIZE
 pmc WRITEFAST varbase $FAST -- WRITE_SIZE
 pmc FETCHFAST base $FAST -- FETCH_SIZE
 pmc WRITEFAST base $FAST -- WRITE_SIZE
-for wl in varbase verify; do
+for wl in varbase verify verify_distinct; do
     pmc SQ1 $wl -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES
     pmc SQ2 $wl -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 done

@@ -46,7 +46,7 @@ def main(raw, out):
     for d in sorted(glob.glob(os.path.join(raw, "pmc_*"))):
         if not os.path.isdir(d):
             continue
-        wl = os.path.basename(d).rsplit("_", 1)[1]
+        wl = "_".join(os.path.basename(d).split("_")[2:])
         tag = os.path.basename(d).split("_")[1]
         if tag.endswith("II"):
             wl += "_index_independent"
