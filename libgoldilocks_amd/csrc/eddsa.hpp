@@ -396,21 +396,66 @@ GD_FN bool ed448_verify_lattice(const Ed448Msg &m, const FB &fb, AT &a_tab, AT &
 // Verification against a key that has a fixed-base comb (kernels_verify.hip: keys that sign many of a batch's
 // signatures): src/eddsa.c:253-306 as it stands -- P = (-h)*A + S*B, accept iff P equals the decoded R up to
 // 2-torsion (goldilocks_448_point_eq, src/goldilocks.c:644-653) -- with (-h)*A from the key's comb instead of a
-// ladder.  COMB: comb.load(j, idx) -> niels, COMB::plan its geometry.  The caller ANDs the key's own decoding in.
+// ladder, and WITHOUT decoding R: that exponentiation would be a third of what is left.  With u = 1 - y^2,
+// v = 1 - d y^2 (so that x_R^2 = u / v), the reference's test "P == isogeny(R) up to 2-torsion", X_P Y' == Y_P X'
+// (src/goldilocks.c:644-653 after :949-1004), multiplied through by v^2 reads
+//       L == K * x_R,     L = X_P (y^2 v - u)(u + y^2 v),     K = 2 Y_P (2 v - u - y^2 v) v y.
+// So (K != 0, u v != 0):  L^2 v == K^2 u  says that L / K is a square root of u / v (if u / v has none the reference
+// rejects R, and the equation cannot hold); and then x_R == L / K iff the low bit of L / K is R's sign bit, because
+// the decoder picks the root with that low bit.  The one division left, 1 / K, is an INVERSION, which the signatures
+// a lane handles share (Montgomery's trick along the lane, as key derivation and signing share theirs): begin()
+// returns what waits for 1 / K, finish() the verdict.  u v == 0 is the reference's isr(0) failure; K == 0 (y = 0,
+// Y_P = 0 or 2 - x^2 - y^2 = 0) decodes R after all and compares points (decided = true).  Round 2 verified
+// full-length ladders this way (the derivation and its tests: profiles/r02/experiments.md C); fixtures F3 and F7
+// (torsion-shifted R, which the reference accepts) and RFC 8032 pass through it on the host checker and on the device.
+// COMB: comb.load(j, idx) -> niels, COMB::plan its geometry.  The caller ANDs the key's own decoding in.
+struct KeycombPending {
+    fe K, L;          // R's x-coordinate is L / K
+    bool ok;          // everything else about the signature held (or, decided: the verdict)
+    bool sign;        // R's sign bit
+    bool decided;     // the slow path ran: ok is final, K is 1
+};
 template <class FB, class COMB, class STAGE, class MKBITS>
-GD_FN bool ed448_verify_keycomb(const Ed448Msg &m, const FB &fb, const COMB &comb, STAGE &stage, MKBITS &mkbits) {
+GD_FN KeycombPending ed448_verify_keycomb_begin(const Ed448Msg &m, const FB &fb, const COMB &comb, STAGE &stage, MKBITS &mkbits) {
     uint32_t w[29];
     shake256_114(w, m, m.total(), stage);
     const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));     // -h mod q
     load_bytes_as_words(w, m.a + 57, 57, 15);
     const sc response = sc_decode_long_words<57>(w);                          // S mod q, no range check
-    pt R;
-    load_bytes_as_words(w, m.a, 57, 15);                                      // R = sig[0:57]
-    const bool ok = pt_decode_eddsa_words(R, w);
     auto bits = mkbits(COMB::plan::recode(challenge), 0);
     pt P = ladder_comb(bits, comb);                                           // -h*A, T included
     fb.add_to(P, response, mkbits);                                           // + S*B
-    return ok && fe_eq(fe_mul(P.y, R.x), fe_mul(R.y, P.x));
+    KeycombPending pend;
+    load_bytes_as_words(w, m.a, 57, 15);                                      // R = sig[0:57]: only what the equation needs
+    const uint32_t last = w[14] & 0xff;
+    pend.sign = (last & 0x80) != 0;
+    bool ok = (last & 0x7f) == 0;
+    fe y;
+    ok = fe_deserialize_words(y, w) && ok;
+    const fe y2 = fe_sqr(y);
+    const fe u = fe_weak(fe_sub<2>(fe_one(), y2));                            // 1 - y^2
+    const fe v = fe_weak(fe_add(fe_one(), fe_mulw(y2, NEG_EDWARDS_D)));       // 1 - d y^2
+    ok = ok && !fe_is_zero(u) && !fe_is_zero(v);                              // the reference's isr(0) failure
+    const fe w1 = fe_mul(y2, v);                                              // y^2 v
+    const fe lf = fe_mul(fe_weak(fe_sub<2>(w1, u)), fe_add(u, w1));           // (y^2 v - u)(u + y^2 v)
+    pend.L = fe_mul(P.x, lf);
+    const fe ef = fe_weak(fe_sub<4>(fe_add(v, v), fe_add(u, w1)));            // 2 v - u - y^2 v
+    fe K = fe_mul(P.y, fe_mul(fe_mul(ef, v), y));
+    K = fe_weak(fe_add(K, K));
+    const bool poly = fe_eq(fe_mul(fe_sqr(pend.L), v), fe_mul(fe_sqr(K), u)); // L^2 v == K^2 u
+    pend.decided = fe_is_zero(K);
+    pend.ok = ok && poly;
+    if (pend.decided) {   // rare: decode R after all and compare points
+        pt R;
+        const bool okr = pt_decode_eddsa_words(R, w);
+        pend.ok = ok && okr && fe_eq(fe_mul(P.y, R.x), fe_mul(R.y, P.x));
+        K = fe_one();
+    }
+    pend.K = K;
+    return pend;
+}
+GD_FN bool ed448_verify_keycomb_finish(const KeycombPending &pend, const fe &inv_k) {
+    return pend.ok && (pend.decided || fe_lobit(fe_mul(pend.L, inv_k)) == pend.sign);
 }
 
 // ------------------------------------------------------------------ key derivation and signing

@@ -154,26 +154,26 @@ GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict_
         }
     }
 }
+// park: KEYCOMB_SLOT_U4 uint4 per signature of the launch (K | the chain's prefix | L | flags); at most
+// SHARED_INV_OPS_PER_LANE signatures per resident lane per launch (the host splits larger batches)
 GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
                                  const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
                                  const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
                                  const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
-                                 const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl) {
+                                 const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
+                                 uint4 *__restrict__ park) {
     __shared__ uint32_t s_bits[16 * BLOCK];
     if (!ctrl[2]) return;                       // this batch's keys are served otherwise (k_ed448_verify)
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> b_tab{bwt_tab};
     LdsStage stage{s_bits + threadIdx.x};       // (unused by the word-granular absorb)
     LdsMkBitsVerify mk{s_bits + threadIdx.x};
-    const uint32_t rounds = (n + stride - 1) / stride;
-    for (uint32_t r = 0; r < rounds; r++) {     // wave-uniform, as in k_ed448_verify
-        const uint32_t slot = lane + r * stride;
-        const bool live = slot < n;
-        const uint32_t i = live ? slot : n - 1;
+    // first pass: everything but the sign test of R's x = L / K, whose inversion the lane's signatures share
+    InvChain ch;
+    ch.begin();
+    for_each_op<true>(n, [&](uint32_t i, bool live) {   // wave-uniform, as in k_ed448_verify
         const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
         const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
         const bool fits = len64 < MAX_MESSAGE_BYTES;
@@ -181,9 +181,26 @@ GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__
                                                   fits ? (uint32_t)len64 : 0u, prehashed, ctx, ctx_len);
         const uint32_t k = slot_of[rep[i]];
         const GlobalCombBig comb{combs + (size_t)KEY_COMB_U4 * k};
-        const bool ok = ed448_verify_keycomb(m, b_tab, comb, stage, mk) && key_ok[k] != 0;
-        if (live) status[i] = ok && fits ? -1 : 0;
-    }
+        const KeycombPending pend = ed448_verify_keycomb_begin(m, b_tab, comb, stage, mk);
+        uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * i;
+        if (live) {
+            fe_store(slot + 8, pend.L);
+            slot[12] = make_uint4(pend.ok && fits && key_ok[k] != 0 ? 1u : 0u, pend.sign ? 1u : 0u, pend.decided ? 1u : 0u, 0u);
+        }
+        ch.push(slot, pend.K, live);
+    });
+    ch.invert();
+    for_each_op_reverse(n, [&](uint32_t i) {
+        const uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * i;
+        const fe inv_k = ch.pop(slot);
+        const uint4 flags = slot[12];
+        KeycombPending pend;
+        pend.L = fe_load(slot + 8);
+        pend.ok = flags.x != 0;
+        pend.sign = flags.y != 0;
+        pend.decided = flags.z != 0;
+        status[i] = ed448_verify_keycomb_finish(pend, inv_k) ? -1 : 0;
+    });
 }
 
 // config 4: status[i] = ed448_verify(sig[i], pk[i], msg[i])   (ref: goldilocks_ed448_verify)

@@ -430,7 +430,8 @@ int hs_ed448_verify_keycomb(const uint8_t *sig, const uint8_t *pk, const uint8_t
     HostStage stage;
     HostMkBits mk;
     Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
-    return ed448_verify_keycomb(m, fb, kc, stage, mk) && key_ok ? -1 : 0;
+    const KeycombPending pend = ed448_verify_keycomb_begin(m, fb, kc, stage, mk);
+    return ed448_verify_keycomb_finish(pend, fe_invert(pend.K)) && key_ok ? -1 : 0;   // (the device shares the inversion along a lane)
 }
 // the short pair of a challenge: rho (15 words), tau (8 words, two's complement)
 void hs_half_size_pair(uint32_t *rho, uint32_t *tau, const uint64_t *h) {

@@ -236,11 +236,13 @@ def test_mac_counts_match_bench(H, O):
         seen.add((counts[0] - counts[1], counts[1]))
     assert len(seen) == 1
     per_key, per_sig = seen.pop()
-    per_sig += 28 * c["add_niels_t"] - (c["comb"] + c["pt_add"])
-    assert per_sig == c["decode_eddsa"] + c["comb_big"] + 28 * c["add_niels_t"] + 2 * c["fe_mul"]
+    # (the host hook inverts K per signature; the device shares one inversion between the 8 signatures a lane owns
+    # at batch 2^20: 3 more multiplications for the chain)
+    per_sig += 28 * c["add_niels_t"] - (c["comb"] + c["pt_add"]) - inv + 3 * c["fe_mul"] + inv // 8
+    assert per_sig == c["comb_big"] + 28 * c["add_niels_t"] + 12 * c["fe_mul"] + 3 * c["fe_sqr"] + c["fe_mulw"] + inv // 8
     assert (W["verify"]["macs_key_comb"], W["verify"]["macs_per_key_comb"]) == (per_sig, per_key)
     assert W["verify"]["macs"] == per_sig + per_key * W["verify"]["keys"] // 2**20
-    assert per_sig < 0.42 * W["verify"]["macs_shared_keys"]
+    assert per_sig < 0.30 * W["verify"]["macs_shared_keys"]
 
 
 def test_big_comb_of_the_base_point_matches_oracle(H, O):
