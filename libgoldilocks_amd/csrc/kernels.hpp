@@ -351,6 +351,7 @@ struct GlobalBwt {
 // signed many of a batch's signatures (kernels_verify.hip), 256 affine niels = 48 KiB per key.
 constexpr int KEY_TEETH_U4 = comb_big::TEETH * comb_big::COMBS * 16;   // 28 pniels per key while its comb is built
 constexpr int KEY_COMB_U4 = comb_big::ENTRIES * 12;
+constexpr int KEY_COMBS_MAX = 8192;   // the most keys of a batch that can have combs (per-block bins in LDS)
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)
 struct GlobalCombBig {
     using plan = comb_big;
@@ -498,7 +499,12 @@ GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__
                                  const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
                                  const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
-                                 uint4 *__restrict__ park);
+                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order);
+GD_KERNEL k_verify_key_count(uint32_t *__restrict__ count, const uint32_t *__restrict__ rep,
+                             const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n);
+GD_KERNEL k_verify_key_scan(uint32_t *__restrict__ count, const uint32_t *__restrict__ ctrl);
+GD_KERNEL k_verify_key_scatter(uint32_t *__restrict__ order, uint32_t *__restrict__ count, const uint32_t *__restrict__ rep,
+                               const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n);
 GD_KERNEL k_ed448_derive_public_key(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
                                     const uint4 *__restrict__ bwt, uint4 *__restrict__ workspace);
 GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,
