@@ -84,6 +84,7 @@ FUNCTIONS = {
     "goldilocks_amd_set_table_access": (C.c_int, "i"),
     "goldilocks_amd_get_table_access": (C.c_int, ""),
     "goldilocks_amd_thread_mode_counts": (None, "p"),
+    "goldilocks_amd_last_verify_key_counts": (C.c_int, "p"),
     "goldilocks_amd_set_wave_batch_max": (None, "z"),
     "goldilocks_amd_get_wave_batch_max": (C.c_size_t, ""),
     "goldilocks_amd_set_verify_key_pool": (None, "zz"),
@@ -470,6 +471,14 @@ def thread_mode_counts():
     c = (C.c_uint64 * 2)()
     lib().goldilocks_amd_thread_mode_counts(C.addressof(c))
     return int(c[0]), int(c[1])
+
+
+def last_verify_key_counts():
+    """(distinct keys, keys with a pooled window table, keys with a comb) of the last large verification batch on this
+    device (test hook)."""
+    c = (C.c_uint32 * 3)()
+    _check(lib().goldilocks_amd_last_verify_key_counts(C.addressof(c)))
+    return int(c[0]), int(c[1]), int(c[2])
 
 
 def device_info():

@@ -452,7 +452,9 @@ def test_verification_shares_the_tables_of_repeated_keys(ga, O):
     sigs[kind == 5, 9] ^= 0x40                  # R
     msg_h[kind == 7, 0] ^= 1                    # message
     own = (idx % 32) == 9
-    pks[own, 11] ^= 2                           # a key of its own, most likely undecodable or wrong
+    pks[own, 11] ^= 2                           # a key of its own (4 096 of them), most likely undecodable or wrong
+    for b in range(3):
+        pks[own, 20 + b] ^= ((idx[own] >> (8 * b)) & 0xff).astype(np.uint8)
     bad_key = pk_k[0].copy(); bad_key[56] = 0x01   # byte 56 neither 0 nor 0x80: the reference rejects the key
     pks[kind == 11] = bad_key                   # ... shared by n/16 signatures
     want_bad = (kind == 3) | (kind == 5) | (kind == 7) | own | (kind == 11)
@@ -465,7 +467,7 @@ def test_verification_shares_the_tables_of_repeated_keys(ga, O):
         torch.cuda.synchronize()
         return st.cpu().numpy()
     try:
-        got = {}
+        got, served = {}, {}
         # (pool keys, min batch, comb keys, min signatures per key): the batch has 37 + 1 + 4 096 distinct keys
         modes = dict(off=(0, 0, 0, 1), tables=(ga.KEY_POOL_DEFAULT, 1 << 16, 0, 1), tiny=(5, 1 << 16, 0, 1),
                      combs=(ga.KEY_POOL_DEFAULT, 1 << 16, 1 << 13, 8), default=(ga.KEY_POOL_DEFAULT, 1 << 16, ga.KEY_COMBS_DEFAULT, ga.KEY_COMBS_MIN_PER_KEY_DEFAULT))
@@ -473,12 +475,17 @@ def test_verification_shares_the_tables_of_repeated_keys(ga, O):
             ga.set_verify_key_pool(keys, min_batch)
             ga.set_verify_key_combs(comb_keys, per_key)
             got[name] = run(d_sig, d_pk, d_msg, n)
+            served[name] = ga.last_verify_key_counts()
+        nkeys = len({bytes(k) for k in pks})
+        assert served == dict(off=(0, 0, 0), tables=(nkeys, nkeys, 0), tiny=(nkeys, 0, 0), combs=(nkeys, 0, nkeys),
+                              default=(nkeys, nkeys, 0)), served          # (default: 32 signatures per key are the rule, this batch has 31.7)
         # few keys only (the lanes whose key is one of a kind left out): 2^16 signatures of 38 keys -> combs by default
         few = np.flatnonzero(~own)[: 1 << 16]
         d_few = torch.from_numpy(few).cuda()
         ga.set_verify_key_pool()
         ga.set_verify_key_combs()
         st_few = run(d_sig[d_few].contiguous(), d_pk[d_few].contiguous(), d_msg[d_few].contiguous(), len(few))
+        assert ga.last_verify_key_counts() == (38, 0, 38)
         ga.set_verify_key_combs(0, 1)
         assert (run(d_sig[d_few].contiguous(), d_pk[d_few].contiguous(), d_msg[d_few].contiguous(), len(few)) == st_few).all()
         assert (st_few == got["off"][few]).all()

@@ -385,6 +385,42 @@ def test_golden_f7_verify_torsion(ga):
     assert sum(len(v) for v in groups.values()) == 48
 
 
+@pytest.mark.parametrize("keys", ["combs", "pooled tables", "every lane for itself"])
+def test_golden_f3_f7_through_the_large_batch_kernels(ga, keys):
+    """Large batches verify through other kernels than small ones, and how a batch's keys repeat decides which
+    (kernels_verify.hip: a fixed-base comb per key without R's decoding / a pooled window table per key / every lane
+    for itself).  The reference's fixtures F3 (256 cases: malformed encodings, S >= q, byte-56 rules) and F7 (48
+    torsion-malleable / small-order cases, which only pass if R is compared as a point up to torsion) replicated
+    into batches of 8 192 .. 16 384 signatures per (context, prehash) group, each through all three."""
+    f3 = json.load(open(os.path.join(GOLD, "f3_verify.json")))["cases"]
+    f7 = json.load(open(os.path.join(GOLD, "f7_verify_torsion.json")))["cases"]
+    groups = {}
+    for c in f3 + [dict(c, prehashed=c.get("prehashed", 0)) for c in f7]:
+        groups.setdefault((c["ctx"], c["prehashed"]), []).append(c)
+    try:
+        ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT if keys != "every lane for itself" else 0, 4097)
+        ga.set_verify_key_combs(ga.KEY_COMBS_DEFAULT if keys == "combs" else 0, 8)
+        checked = 0
+        for (ctx, ph), cs in groups.items():
+            reps = -(-8192 // len(cs))
+            order = np.random.default_rng(len(cs)).permutation(len(cs) * reps) % len(cs)
+            sigs = np.array([np.frombuffer(bytes.fromhex(c["sig"]), np.uint8) for c in cs])[order]
+            pks = np.array([np.frombuffer(bytes.fromhex(c["pk"]), np.uint8) for c in cs])[order]
+            msgs = [bytes.fromhex(cs[i]["msg"]) for i in order]
+            got = np.asarray(ga.ed448_verify_batch(sigs, pks, msgs, prehashed=bool(ph), context=bytes.fromhex(ctx)))
+            want = np.array([cs[i]["verdict"] for i in order])
+            assert (got == want).all(), sorted({cs[i]["kind"] for i in order[got != want]})
+            distinct, pooled, combed = ga.last_verify_key_counts()      # ... and the batch went the way it was meant to
+            nkeys = len({c["pk"] for c in cs})
+            assert (distinct, pooled, combed) == dict(combs=(nkeys, 0, nkeys), **{"pooled tables": (nkeys, nkeys, 0),
+                                                      "every lane for itself": (0, 0, 0)})[keys]
+            checked += len(cs)
+        assert checked == 256 + 48
+    finally:
+        ga.set_verify_key_pool()
+        ga.set_verify_key_combs()
+
+
 def test_rfc8032_vectors_through_the_abi(ga):
     kats = json.load(open(os.path.join(GOLD, "kats.json")))
     for c in kats["rfc8032_ed448"]:
