@@ -72,6 +72,40 @@ def test_soak_sign_verify(ga, O):
     assert (st == want_st).all() and (st[~bad] == -1).all()
 
 
+@pytest.mark.parametrize("keys", ["combs", "pooled tables"])
+def test_soak_verify_repeated_keys(ga, O, keys):
+    """The verification kernels for keys that repeat in a batch (kernels_verify.hip: a comb per key and R not decoded /
+    a pooled window table per key): 32 768 signatures of 64 keys, a bit flipped anywhere in a quarter of the
+    signatures, in an eighth of the keys used and in a few messages, every lane against the oracle."""
+    nk = 64
+    sk = np.frombuffer(_gen.stream(SEED + b"soak/rk-sk", 57 * nk), np.uint8).reshape(nk, 57).copy()
+    pk_k = ga.ed448_derive_public_key_batch(sk)
+    rng = np.random.default_rng(11)
+    key_of = rng.integers(0, nk, N)
+    msg = np.frombuffer(_gen.stream(SEED + b"soak/rk-msg", 40 * N), np.uint8).reshape(N, 40).copy()
+    sig = ga.ed448_sign_batch(sk[key_of], pk_k[key_of], [m.tobytes() for m in msg], context=b"rk")
+    pk = pk_k[key_of].copy()
+    bad = rng.random(N) < 0.25
+    sig[bad, rng.integers(0, 114, bad.sum())] ^= (1 << rng.integers(0, 8, bad.sum())).astype(np.uint8)
+    badk = rng.random(N) < 0.125
+    pk[badk, rng.integers(0, 57, badk.sum())] ^= (1 << rng.integers(0, 8, badk.sum())).astype(np.uint8)
+    badm = rng.random(N) < 0.03
+    msg[badm, 7] ^= 0x10
+    try:
+        ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT, 4097)
+        ga.set_verify_key_combs(ga.KEY_COMBS_DEFAULT if keys == "combs" else 0, 2)
+        st = ga.ed448_verify_batch(sig, pk, [m.tobytes() for m in msg], context=b"rk")
+        distinct, pooled, combed = ga.last_verify_key_counts()
+        assert distinct > nk and (combed if keys == "combs" else pooled) == distinct
+    finally:
+        ga.set_verify_key_pool()
+        ga.set_verify_key_combs()
+    want = np.empty(N, np.int32)
+    ctx = (C.c_uint8 * 2).from_buffer_copy(b"rk")
+    O.orc_ed448_verify_batch(_p(want), _p(sig), _p(pk), _p(msg), 40, 0, ctx, 2, N, _gen.NTHREADS)
+    assert (st == want).all() and (want == -1).sum() > N // 2 and (want == 0).sum() > N // 4
+
+
 def test_soak_x448_and_elligator(ga, O):
     from _libs import Point
     n = N // 4
