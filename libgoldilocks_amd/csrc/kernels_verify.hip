@@ -106,16 +106,19 @@ GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ ke
 // ---- a fixed-base COMB per key, when a batch's keys sign many signatures each.
 // With a comb of the key the challenge's multiple needs no ladder at all: P = (-h)*A from the key's 4 x 7 x 16 comb
 // (15 doublings + 63 mixed additions, scalarmul.hpp comb_big: what the library's own base point gets), S*B added
-// from the base point's window table, and P is compared with the decoded R as the reference's
-// goldilocks_448_point_eq does (src/eddsa.c:299-305, src/goldilocks.c:644-653): the equation of src/eddsa.c as it
-// stands, no short pair, no table per signature -- 207 K multiply-accumulates instead of 522 K.  What it costs is
-// the comb: 432 successive doublings and 256 entries per key, about 1.2 M multiply-accumulates = six such
-// verifications, and a latency of 432 doublings; so only keys' worth it: ctrl[2] != 0 iff the batch averages at least
-// comb_min_per_key signatures per distinct key (goldilocks_amd_set_verify_key_combs; 32 by default) and the keys fit.
-//   k_verify_key_teeth   (kernels_wave.hip) wave k: decode key k, teeth 2^(16 m) * A_k, m < 28, by row arithmetic
-//   k_verify_key_combs   block: lane e computes entry e of a key's comb = a signed sum of 7 teeth, for up to 8 keys,
-//                        and normalises them with one shared inversion
-//   k_ed448_verify_keycomb   the verification itself
+// from the base point's window table, and P is compared with R as the reference's goldilocks_448_point_eq compares
+// it with the decoded R (src/eddsa.c:299-305, src/goldilocks.c:644-653) -- WITHOUT decoding R: the comparison is
+// turned into a polynomial identity plus one sign test whose division the lane's signatures share
+// (eddsa.hpp ed448_verify_keycomb_begin / _finish).  The equation of src/eddsa.c as it stands, no short pair, no table
+// per signature: 150 K multiply-accumulates instead of 522 K.  What it costs is the comb: 432 successive doublings
+// and 256 entries per key, 3.5 M multiply-accumulates and, as built here, the time of 14 verifications; so only for
+// keys worth it: ctrl[2] != 0 iff the batch averages at least comb_min_per_key signatures per distinct key
+// (goldilocks_amd_set_verify_key_combs; 32 by default) and has at most KEY_COMBS_MAX of them.
+//   k_verify_key_teeth     (kernels_wave.hip) wave k: decode key k, teeth 2^(16 m) * A_k, m < 28, by row arithmetic
+//   k_verify_key_combs     block: lane e computes entry e of a key's comb = a signed sum of 7 teeth, for up to 8 keys,
+//                          and normalises them with one shared inversion
+//   k_verify_key_count / _scan / _scatter   the signatures in the order of their keys (below)
+//   k_ed448_verify_keycomb the verification itself, two passes around the lane's shared inversion
 // chain: 8 uint4 per (block, round, lane) -- the shared inversion's parking slots (InvChain), 8 rounds
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain) {
