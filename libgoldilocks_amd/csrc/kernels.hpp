@@ -349,7 +349,7 @@ struct GlobalBwt {
 };
 // A 4 x 7 x 16 comb in global memory, read by the digit (public scalars only): the comb of a verification key that
 // signed many of a batch's signatures (kernels_verify.hip), 256 affine niels = 48 KiB per key.
-constexpr int KEY_TEETH_U4 = comb_big::TEETH * comb_big::COMBS * 16;   // 28 pniels per key while its comb is built
+constexpr int KEY_TEETH_U4 = 2 * comb_big::TEETH * comb_big::COMBS * 16;   // 28 teeth + their doubles (pniels) per key while its comb is built
 constexpr int KEY_COMB_U4 = comb_big::ENTRIES * 12;
 constexpr int KEY_COMBS_MAX = 8192;   // the most keys of a batch that can have combs (per-block bins in LDS)
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)

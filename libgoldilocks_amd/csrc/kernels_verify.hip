@@ -115,45 +115,52 @@ GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ ke
 // keys worth it: ctrl[2] != 0 iff the batch averages at least comb_min_per_key signatures per distinct key
 // (goldilocks_amd_set_verify_key_combs; 32 by default) and has at most KEY_COMBS_MAX of them.
 //   k_verify_key_teeth     (kernels_wave.hip) wave k: decode key k, teeth 2^(16 m) * A_k, m < 28, by row arithmetic
-//   k_verify_key_combs     block: lane e computes entry e of a key's comb = a signed sum of 7 teeth, for up to 8 keys,
-//                          and normalises them with one shared inversion
+//   k_verify_key_combs     16 lanes per key: a lane walks 16 entries of one comb in Gray-code order (one addition of a
+//                          doubled tooth per entry) and normalises them with one shared inversion
 //   k_verify_key_count / _scan / _scatter   the signatures in the order of their keys (below)
 //   k_ed448_verify_keycomb the verification itself, two passes around the lane's shared inversion
-// chain: 8 uint4 per (block, round, lane) -- the shared inversion's parking slots (InvChain), 8 rounds
+// Entry 64 j + idx of a key's comb is T_(6+7j) + sum_{k<6} (+-) T_(k+7j), + iff bit k of idx.  A lane owns a SEGMENT of
+// 16 consecutive Gray codes of one comb of one key (16 lanes per key): its first entry is the signed sum of 7 teeth
+// (6 additions), each further one differs from its predecessor in one sign, i.e. by (+-) 2 T_k (1 addition) -- 21
+// additions for 16 entries instead of 96 -- and the 16 share one inversion (Montgomery's trick along the lane).
+// The entries wait unnormalised in their own slots of the comb; chain: 8 uint4 per (key, entry) for the trick.
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain) {
-    static_assert(comb_big::ENTRIES == BLOCK, "one lane per entry");
-    constexpr uint32_t ROUNDS = 8;
-    __shared__ uint4 s_teeth[KEY_TEETH_U4];
-    const uint32_t combed = ctrl[2], e = threadIdx.x;
-    uint4 *const my_chain = chain + ((size_t)blockIdx.x * ROUNDS * BLOCK + e) * 8;
-    // the keys of a block: blockIdx.x, + gridDim.x, ...; a lane computes ITS entry of up to 8 of them unnormalised,
-    // shares one inversion between them (Montgomery's trick along the lane, fixed_bodies.hpp) and walks back
-    for (uint32_t first = blockIdx.x; first < combed; first += ROUNDS * gridDim.x) {
+    constexpr uint32_t SEG = 16, PER_KEY = comb_big::ENTRIES / SEG, NT = comb_big::TEETH * comb_big::COMBS;
+    const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK, total = combed * PER_KEY;
+    for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < total; t += stride) {
+        const uint32_t k = t / PER_KEY, j = (t % PER_KEY) / (comb_big::PER_COMB / SEG), g0 = (t % (comb_big::PER_COMB / SEG)) * SEG;
+        const TeethAt tooth{teeth + (size_t)KEY_TEETH_U4 * k}, twice{teeth + (size_t)KEY_TEETH_U4 * k + 16 * NT};
+        uint4 *const comb = combs + (size_t)KEY_COMB_U4 * k + 12 * comb_big::PER_COMB * j;
+        uint4 *const slots = chain + ((size_t)comb_big::ENTRIES * k + comb_big::PER_COMB * j) * 8;
+        uint32_t idx = g0 ^ (g0 >> 1);
+        pt p = pniels_to_pt(tooth.load(comb_big::TEETH - 1 + comb_big::TEETH * j), false);
+#pragma unroll 1
+        for (uint32_t b = 0; b + 1 < (uint32_t)comb_big::TEETH; b++)
+            pt_add_pniels(p, tooth.load(b + comb_big::TEETH * j), ((idx >> b) & 1u) == 0, true);
         InvChain ch;
         ch.begin();
-        uint32_t r = 0;
 #pragma unroll 1
-        for (uint32_t k = first; r < ROUNDS && k < combed; r++, k += gridDim.x) {   // block-uniform
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < (uint32_t)KEY_TEETH_U4; i += BLOCK) s_teeth[i] = teeth[(size_t)KEY_TEETH_U4 * k + i];
-            __syncthreads();
-            const pt p = comb_big_entry_projective(LdsTeeth{s_teeth}, e);
-            uint4 *q = combs + (size_t)KEY_COMB_U4 * k + 12 * e;
+        for (uint32_t s = 0;; s++) {
+            uint4 *q = comb + 12 * idx;
             fe_store(q, fe_weak(fe_sub<2>(p.y, p.x)));
             fe_store(q + 4, fe_weak(fe_add(p.x, p.y)));
             fe_store(q + 8, fe_mulw(p.t, TWO_EFF_D));
-            ch.push(my_chain + 8 * BLOCK * r, fe_add(p.z, p.z), true);
+            ch.push(slots + 8 * idx, fe_add(p.z, p.z), true);
+            if (s + 1 == SEG) break;
+            const uint32_t g = g0 + s + 1, b = (uint32_t)__builtin_ctz(g);     // the Gray bit that flips
+            idx ^= 1u << b;
+            pt_add_pniels(p, twice.load(b + comb_big::TEETH * j), ((idx >> b) & 1u) == 0, true);
         }
         ch.invert();
 #pragma unroll 1
-        while (r--) {
-            const uint32_t k = first + r * gridDim.x;
-            const fe zi = ch.pop(my_chain + 8 * BLOCK * r);
-            uint4 *q = combs + (size_t)KEY_COMB_U4 * k + 12 * e;
+        for (uint32_t s = SEG; s-- > 0;) {
+            const fe zi = ch.pop(slots + 8 * idx);
+            uint4 *q = comb + 12 * idx;
             fe_store(q, fe_mul(fe_load(q), zi));
             fe_store(q + 4, fe_mul(fe_load(q + 4), zi));
             fe_store(q + 8, fe_mul(fe_load(q + 8), zi));
+            if (s) idx ^= 1u << (uint32_t)__builtin_ctz(g0 + s);               // back to the predecessor's pattern
         }
     }
 }

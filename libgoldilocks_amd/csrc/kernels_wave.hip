@@ -92,7 +92,7 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_precompute_wave(uint64_t *
 }
 
 // Verification keys that get a comb of their own (kernels_verify.hip): key k decoded and its 28 teeth 2^(16 m) * A_k
-// written as pniels, ONE KEY PER WAVE -- the chain of 432 doublings is pure latency, and a wave's doubling is two row
+// (and their doubles, which the comb's entries are walked with) written as pniels, ONE KEY PER WAVE -- the chain of 432 doublings is pure latency, and a wave's doubling is two row
 // multiplications (0.25 ms for the chain instead of the 1.7 ms of a lane's).  A pniels' 64 words are the wave's 64
 // lanes (rows a, b, cn, z): every tooth is one coalesced 256-byte store.
 extern "C" __global__ void __launch_bounds__(BLOCK) k_verify_key_teeth(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok,
@@ -108,12 +108,15 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_verify_key_teeth(uint4 *__
         if (me == 0) key_ok[k] = ok ? 1 : 0;
         wc::wfe P = wc::pack_point<0>(L, X, Y, Z, T);
         uint32_t *out = reinterpret_cast<uint32_t *>(teeth + (size_t)KEY_TEETH_U4 * k);
+        constexpr int NT = comb_big::TEETH * comb_big::COMBS;
 #pragma unroll 1
-        for (int m = 0; m < comb_big::TEETH * comb_big::COMBS; m++) {
+        for (int m = 0; m < NT; m++) {          // T_m, and 2 T_m (the first doubling towards T_(m+1)) behind the 28 teeth
             out[64 * m + me] = wc::to_pniels(L, P, swap_row);
-            if (m + 1 == comb_big::TEETH * comb_big::COMBS) break;
+            P = wc::dbl(L, P);
+            out[64 * (NT + m) + me] = wc::to_pniels(L, P, swap_row);
+            if (m + 1 == NT) break;
 #pragma unroll 1
-            for (int d = 0; d < comb_big::SPACING; d++) P = wc::dbl(L, P);
+            for (int d = 1; d < comb_big::SPACING; d++) P = wc::dbl(L, P);
         }
     }
 }
