@@ -22,7 +22,7 @@ def timeit(fn, reps=5):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 for n in (1 << 16, 1 << 17, 1 << 18, 1 << 20):
-    for nk in (16, 1024, n // 128, n // 32, n // 8, n // 4, n):
+    for nk in (16, 1024, n // 128, n // 32, n // 16, n // 8, n // 4, n):
         sig, pk, msg = make(n, nk)
         st = torch.empty(n, dtype=torch.int32, device="cuda")
         f = lambda: ga.dev("ed448_verify", st.data_ptr(), sig.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0, None, 0, n, None)
