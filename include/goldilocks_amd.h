@@ -369,7 +369,8 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
  * 16, 48 KiB per key, built on the device per call), with which a verification is src/eddsa.c's equation without a
  * ladder -- 0.4 of the arithmetic.  Used when the batch averages at least `min_signatures_per_key` signatures per
  * distinct key and has at most `keys` distinct keys (and is large enough for the pool above); otherwise the pool's
- * rules apply.  Verdicts do not change.  keys = 0 turns the combs off, 8192 is the most.  Process-wide. */
+ * rules apply.  Verdicts do not change.  keys = 0 turns the combs off, 8192 is the most; turning the pool off
+ * (goldilocks_amd_set_verify_key_pool(0, ..)) turns the combs off with it.  Process-wide. */
 #define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 13)
 #define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 32
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t min_signatures_per_key);
