@@ -31,10 +31,14 @@
 #if defined(__HIPCC__)
 #define GD_FN __device__ __forceinline__
 #define GD_MFN __device__ __forceinline__
+// on a lambda handed to a loop helper: hipcc otherwise leaves a large body out of line -- a call per operation, the
+// captured state through scratch (k_ed448_verify_keycomb: 4 % of the kernel)
+#define GD_LAMBDA_INLINE __attribute__((always_inline))
 #define GD_CONST __device__ const
 #else
 #define GD_FN static inline   // the host checker build lets g++ decide (forced inlining costs minutes of compile time)
 #define GD_MFN inline
+#define GD_LAMBDA_INLINE
 #define GD_CONST static const
 #endif
 

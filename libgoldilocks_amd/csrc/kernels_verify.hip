@@ -251,7 +251,7 @@ GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__
     // first pass: everything but the sign test of R's x = L / K, whose inversion the lane's signatures share
     InvChain ch;
     ch.begin();
-    for_each_op<true>(n, [&](uint32_t t, bool live) {   // wave-uniform, as in k_ed448_verify; position t: signature i
+    for_each_op<true>(n, [&](uint32_t t, bool live) GD_LAMBDA_INLINE {   // wave-uniform, as in k_ed448_verify; position t: signature i
         const uint32_t i = order[t];
         const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
         const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;

@@ -233,11 +233,11 @@ __device__ __forceinline__ void point_dual_scalarmul_ladder_body(uint64_t *out1,
     __shared__ uint32_t s_bits[15 * BLOCK];
     InvChain ch;
     ch.begin();
-    for_each_op<true>(n, [&](uint32_t i, bool live) {
+    for_each_op<true>(n, [&](uint32_t i, bool live) GD_LAMBDA_INLINE {
         ch.push(workspace + (size_t)ML_SLOT_U4 * i, ml_denominator(pt_load_abi(base + 32 * (size_t)i)), live);
     });
     ch.invert();
-    for_each_op_reverse(n, [&](uint32_t i) {
+    for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
         const pt b = pt_load_abi(base + 32 * (size_t)i);
         const fe u = fe_mul(fe_add(b.y, b.z), ch.pop(workspace + (size_t)ML_SLOT_U4 * i));
         LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s1 + 7 * (size_t)i)));
@@ -259,13 +259,13 @@ __device__ __forceinline__ void double_scalarmul_ladder_body(uint64_t *out, cons
     __shared__ uint32_t s_bits[15 * BLOCK];
     InvChain ch;
     ch.begin();
-    for_each_op<true>(n, [&](uint32_t i, bool live) {
+    for_each_op<true>(n, [&](uint32_t i, bool live) GD_LAMBDA_INLINE {
         uint4 *slot = workspace + (size_t)(2 * ML_SLOT_U4) * i;
         ch.push(slot, ml_denominator(pt_load_abi(b1 + 32 * (size_t)i)), live);
         ch.push(slot + ML_SLOT_U4, ml_denominator(pt_load_abi(b2 + 32 * (size_t)i)), live);
     });
     ch.invert();
-    for_each_op_reverse(n, [&](uint32_t i) {
+    for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
         const uint4 *slot = workspace + (size_t)(2 * ML_SLOT_U4) * i;
         const pt q = pt_load_abi(b2 + 32 * (size_t)i);           // popped in the reverse order of the pushes
         const fe uq = fe_mul(fe_add(q.y, q.z), ch.pop(slot + ML_SLOT_U4));
