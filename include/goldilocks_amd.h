@@ -367,12 +367,14 @@ GOLDILOCKS_AMD_API size_t goldilocks_amd_get_wave_batch_max(void);
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t min_batch);
 /* Keys that sign MANY signatures of a batch get more than a shared window table: a fixed-base comb of their own (4 x 7 x
  * 16, 48 KiB per key, built on the device per call), with which a verification is src/eddsa.c's equation without a
- * ladder -- 0.4 of the arithmetic.  Used when the batch averages at least `min_signatures_per_key` signatures per
- * distinct key and has at most `keys` distinct keys (and is large enough for the pool above); otherwise the pool's
- * rules apply.  Verdicts do not change.  keys = 0 turns the combs off, 8192 is the most; turning the pool off
+ * ladder and without R's decoding -- 0.3 of the arithmetic.  Used when the batch averages at least
+ * `min_signatures_per_key` signatures per distinct key (twice that for batches below 2^18 signatures, where the fixed
+ * latency of building the combs weighs more) and has at most `keys` distinct keys (and is large enough for the pool
+ * above); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the combs off, 2^17 is the most
+ * (62 KiB of device memory per key the batch may have); turning the pool off
  * (goldilocks_amd_set_verify_key_pool(0, ..)) turns the combs off with it.  Process-wide. */
-#define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 13)
-#define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 32
+#define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 15)
+#define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 16
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t min_signatures_per_key);
 /* Test hook: how the last large verification batch on the calling thread's device served its keys --
  * counts[0] distinct keys seen, counts[1] keys with a pooled window table, counts[2] keys with a comb (at most one of the

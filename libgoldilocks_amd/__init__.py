@@ -453,12 +453,12 @@ def set_verify_key_pool(keys=KEY_POOL_DEFAULT, min_batch=KEY_POOL_MIN_BATCH_DEFA
     lib().goldilocks_amd_set_verify_key_pool(int(keys), int(min_batch))
 
 
-KEY_COMBS_DEFAULT, KEY_COMBS_MIN_PER_KEY_DEFAULT = 1 << 13, 32
+KEY_COMBS_DEFAULT, KEY_COMBS_MIN_PER_KEY_DEFAULT = 1 << 15, 16
 
 
 def set_verify_key_combs(keys=KEY_COMBS_DEFAULT, min_signatures_per_key=KEY_COMBS_MIN_PER_KEY_DEFAULT):
-    """Keys that sign at least `min_signatures_per_key` signatures of a batch on average get a fixed-base comb each
-    (at most `keys` of them; 0 turns the combs off)."""
+    """Keys that sign at least `min_signatures_per_key` signatures of a batch on average (twice that below 2^18
+    signatures) get a fixed-base comb each (at most `keys` of them; 0 turns the combs off)."""
     lib().goldilocks_amd_set_verify_key_combs(int(keys), int(min_signatures_per_key))
 
 

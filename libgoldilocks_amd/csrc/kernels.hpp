@@ -351,7 +351,9 @@ struct GlobalBwt {
 // signed many of a batch's signatures (kernels_verify.hip), 256 affine niels = 48 KiB per key.
 constexpr int KEY_TEETH_U4 = 2 * comb_big::TEETH * comb_big::COMBS * 16;   // 28 teeth + their doubles (pniels) per key while its comb is built
 constexpr int KEY_COMB_U4 = comb_big::ENTRIES * 12;
-constexpr int KEY_COMBS_MAX = 8192;   // the most keys of a batch that can have combs (per-block bins in LDS)
+constexpr int KEY_COMBS_MAX = 1 << 17;     // the most keys of a batch that can have combs (62 KiB of workspace each)
+constexpr int KEY_SORT_BINS = 8192;        // up to so many keys the counting sort goes through per-block bins in LDS
+constexpr int KEY_TEETH_BY_WAVE_MAX = 4096;   // up to so many keys a WAVE computes a key's teeth (latency), beyond a lane (throughput)
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)
 struct GlobalCombBig {
     using plan = comb_big;
@@ -490,6 +492,8 @@ GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ ke
 extern "C" __global__ void k_verify_key_teeth(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok,
                                               const uint32_t *__restrict__ ctrl, const uint32_t *__restrict__ key_list,
                                               const uint8_t *__restrict__ pk);
+GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
+                                   const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk);
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain);
 GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,

@@ -113,12 +113,39 @@ GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ ke
 // per signature: 150 K multiply-accumulates instead of 522 K.  What it costs is the comb: 432 successive doublings
 // and 256 entries per key, 3.5 M multiply-accumulates and, as built here, the time of 14 verifications; so only for
 // keys worth it: ctrl[2] != 0 iff the batch averages at least comb_min_per_key signatures per distinct key
-// (goldilocks_amd_set_verify_key_combs; 32 by default) and has at most KEY_COMBS_MAX of them.
-//   k_verify_key_teeth     (kernels_wave.hip) wave k: decode key k, teeth 2^(16 m) * A_k, m < 28, by row arithmetic
+// (goldilocks_amd_set_verify_key_combs; 16 by default, 32 below 2^18 signatures) and has no more of them than the
+// call's capacity (2^15 by default, KEY_COMBS_MAX at most).
+//   k_verify_key_teeth     (kernels_wave.hip) wave k: decode key k, teeth 2^(16 m) * A_k, m < 28, by row arithmetic;
+//                          k_verify_key_teeth_lanes: a lane per key instead, when the keys are many
 //   k_verify_key_combs     16 lanes per key: a lane walks 16 entries of one comb in Gray-code order (one addition of a
 //                          doubled tooth per entry) and normalises them with one shared inversion
 //   k_verify_key_count / _scan / _scatter   the signatures in the order of their keys (below)
 //   k_ed448_verify_keycomb the verification itself, two passes around the lane's shared inversion
+// The teeth of MANY keys (more than KEY_TEETH_BY_WAVE_MAX): a lane per key.  One lane's chain of 432 doublings takes
+// 1.7 ms however few keys there are, but it costs a sixth of a wave's instructions: 2^15 keys 1.8 ms against 6.4 ms.
+GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
+                                   const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk) {
+    constexpr int NT = comb_big::TEETH * comb_big::COMBS;
+    const uint32_t combed = ctrl[2];
+    if (combed <= (uint32_t)KEY_TEETH_BY_WAVE_MAX) return;
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < combed; k += stride) {
+        uint32_t w[15];
+        load_bytes_as_words(w, pk + 57 * (size_t)key_list[k], 57, 15);
+        pt P;
+        key_ok[k] = pt_decode_eddsa_words(P, w) ? 1 : 0;
+        uint4 *out = teeth + (size_t)KEY_TEETH_U4 * k;
+#pragma unroll 1
+        for (int m = 0; m < NT; m++) {          // T_m, and 2 T_m behind the 28 teeth (as k_verify_key_teeth)
+            pniels_store(out + 16 * m, pt_to_pniels(P));
+            pt_double(P, true);
+            pniels_store(out + 16 * (NT + m), pt_to_pniels(P));
+            if (m + 1 == NT) break;
+#pragma unroll 1
+            for (int d = 1; d < comb_big::SPACING; d++) pt_double(P, d + 1 == comb_big::SPACING);
+        }
+    }
+}
 // Entry 64 j + idx of a key's comb is T_(6+7j) + sum_{k<6} (+-) T_(k+7j), + iff bit k of idx.  A lane owns a SEGMENT of
 // 16 consecutive Gray codes of one comb of one key (16 lanes per key): its first entry is the signed sum of 7 teeth
 // (6 additions), each further one differs from its predecessor in one sign, i.e. by (+-) 2 T_k (1 addition) -- 21
@@ -169,15 +196,19 @@ GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict_
 // 48 MiB: Infinity Cache).  2^20 signatures whose keys arrive in random order: 10.0 -> 9.3 ms when they come sorted.
 // Counting and scattering go through per-block bins in LDS, so that a global counter sees one atomic per block and
 // key instead of one per signature (16 keys in 2^20 signatures would otherwise queue 65 536 atomics on each of 16
-// addresses, twice: + 5 ms).  KEY_COMBS_MAX bins: the most keys that can have combs.
+// addresses, twice: + 5 ms).  Beyond KEY_SORT_BINS keys a counter sees few signatures and plain atomics do.
 GD_KERNEL k_verify_key_count(uint32_t *__restrict__ count, const uint32_t *__restrict__ rep,
                              const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n) {
-    __shared__ uint32_t s_bin[KEY_COMBS_MAX];
+    __shared__ uint32_t s_bin[KEY_SORT_BINS];
     const uint32_t keys = ctrl[2];
     if (!keys) return;
+    const uint32_t stride = gridDim.x * BLOCK;
+    if (keys > (uint32_t)KEY_SORT_BINS) {   // many keys: few signatures per counter, plain atomics do
+        for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) atomicAdd(count + slot_of[rep[i]], 1u);
+        return;
+    }
     for (uint32_t k = threadIdx.x; k < keys; k += BLOCK) s_bin[k] = 0;
     __syncthreads();
-    const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) atomicAdd(s_bin + slot_of[rep[i]], 1u);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < keys; k += BLOCK)
@@ -213,12 +244,16 @@ GD_KERNEL k_verify_key_scan(uint32_t *__restrict__ count, const uint32_t *__rest
 // atomic on the key's cursor (count[k], left by the scan), and hands them out from LDS
 GD_KERNEL k_verify_key_scatter(uint32_t *__restrict__ order, uint32_t *__restrict__ count, const uint32_t *__restrict__ rep,
                                const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n) {
-    __shared__ uint32_t s_bin[KEY_COMBS_MAX], s_base[KEY_COMBS_MAX];
+    __shared__ uint32_t s_bin[KEY_SORT_BINS], s_base[KEY_SORT_BINS];
     const uint32_t keys = ctrl[2];
     if (!keys) return;
+    const uint32_t stride = gridDim.x * BLOCK;
+    if (keys > (uint32_t)KEY_SORT_BINS) {
+        for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) order[atomicAdd(count + slot_of[rep[i]], 1u)] = i;
+        return;
+    }
     for (uint32_t k = threadIdx.x; k < keys; k += BLOCK) s_bin[k] = 0;
     __syncthreads();
-    const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) atomicAdd(s_bin + slot_of[rep[i]], 1u);
     __syncthreads();
     for (uint32_t k = threadIdx.x; k < keys; k += BLOCK) {

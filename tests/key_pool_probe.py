@@ -29,7 +29,7 @@ for n in (1 << 16, 1 << 17, 1 << 18, 1 << 20):
         ga.set_verify_key_combs(0, 1)
         ga.set_verify_key_pool(0, 0); a = timeit(f)
         ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT, 0); b = timeit(f); assert int((st == -1).sum()) == n
-        ga.set_verify_key_combs(1 << 13, 1); c = timeit(f) if nk <= 1 << 13 else float("nan"); assert int((st == -1).sum()) == n
+        ga.set_verify_key_combs(1 << 17, 1); c = timeit(f) if nk <= 1 << 17 and nk * 4 <= n else float("nan"); assert int((st == -1).sum()) == n
         ga.set_verify_key_combs(); d = timeit(f); assert int((st == -1).sum()) == n
         print("n=2^%d keys=%-7d (%6.1f per key)  every lane for itself %7.3f ms   pooled tables %7.3f ms   combs forced %7.3f ms   library default %7.3f ms"
               % (n.bit_length() - 1, nk, n / nk, a, b, c, d), flush=True)

@@ -514,3 +514,42 @@ def test_verification_shares_the_tables_of_repeated_keys(ga, O):
     finally:
         ga.set_verify_key_pool()
         ga.set_verify_key_combs()
+
+
+def test_verification_with_combs_for_ten_thousand_keys(ga, O):
+    """More keys than a wave each can serve (kernels_verify.hip: beyond 4 096 keys a LANE computes a key's teeth, beyond
+    8 192 the counting sort uses plain atomics): 2^18 signatures of 10 000 keys, a tenth corrupted, through the combs (the
+    library's choice at 26 signatures per key), against the same batch with every lane for itself and the oracle."""
+    import torch
+    n, nk = 1 << 18, 10_000
+    sk = torch.from_numpy(np.frombuffer(_gen.stream(b"tenk/sk", 57 * nk), np.uint8).reshape(nk, 57).copy()).cuda()
+    pk_k = torch.empty((nk, 57), dtype=torch.uint8, device="cuda")
+    ga.dev("ed448_derive_public_key", pk_k.data_ptr(), sk.data_ptr(), nk, None)
+    key_of = torch.from_numpy(np.random.default_rng(8).integers(0, nk, n)).cuda()
+    d_sk, d_pk = sk[key_of].contiguous(), pk_k[key_of].contiguous()
+    d_msg = torch.from_numpy(np.frombuffer(_gen.stream(b"tenk/msg", 32 * n), np.uint8).reshape(n, 32).copy()).cuda()
+    d_sig = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
+    ga.dev("ed448_sign", d_sig.data_ptr(), d_sk.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(), None, 32, 0, None, 0, n, None)
+    bad = torch.arange(n, device="cuda") % 10 == 3
+    d_sig[bad, 3] ^= 0x10                                # R
+    d_sig[torch.arange(n, device="cuda") % 50 == 7, 80] ^= 1   # S
+    bad |= torch.arange(n, device="cuda") % 50 == 7
+
+    def run():
+        st = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+        ga.dev("ed448_verify", st.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(), None, 32, 0, None, 0, n, None)
+        torch.cuda.synchronize()
+        return st
+    try:
+        st = run()
+        distinct, pooled, combed = ga.last_verify_key_counts()
+        assert distinct == combed == len(np.unique(key_of.cpu().numpy())) > 8192 and pooled == 0
+        ga.set_verify_key_pool(0, 0)
+        assert bool((run() == st).all())
+    finally:
+        ga.set_verify_key_pool()
+    assert bool(((st == -1) == ~bad).all())
+    pick = np.random.default_rng(9).integers(0, n, 256)
+    pick_d = torch.from_numpy(pick).cuda()
+    want = _gen.oracle_verify(O, d_sig[pick_d].cpu().numpy(), d_pk[pick_d].cpu().numpy(), [m.tobytes() for m in d_msg[pick_d].cpu().numpy()])
+    assert (st[pick_d].cpu().numpy() == want).all() and (want == 0).sum() >= 10
