@@ -1,0 +1,170 @@
+// keycombphases.hip -- where does k_ed448_verify_keycomb spend its time?
+//
+// The product kernel's first pass (kernels_verify.hip, eddsa.hpp ed448_verify_keycomb_begin) re-stated phase by phase
+// with a clock read (s_memtime) between the phases, then the shared inversion and the second pass as one phase each;
+// the same launch shape (256 CUs x 2 blocks x 256 lanes, 8 signatures per lane at 2^20), 2^10 combs of random limbs,
+// the signatures already in the order of their keys (position t uses comb (t / 1024) % 1024 -- what the counting sort
+// produces).  Inputs are random bytes: every arithmetic phase runs whatever the verdict is.  Printed: each phase's
+// share of the lanes' total, next to its multiply-accumulate count, i.e. clocks per MAC by phase (tools/verifyphases
+// does the same for k_ed448_verify).
+//
+//   hipcc -std=c++17 -O3 --offload-arch=gfx950 -Ilibgoldilocks_amd/csrc -o tools/keycombphases tools/keycombphases.hip
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "varbase_bodies.hpp"
+
+using namespace gd;
+
+#define CHECK(x)                                                       \
+    do {                                                               \
+        hipError_t e = (x);                                            \
+        if (e != hipSuccess) {                                         \
+            fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e));     \
+            exit(1);                                                   \
+        }                                                              \
+    } while (0)
+
+constexpr int NPH = 7;
+static const char *PHASE[NPH] = {"hash + scalar decoding", "the key's comb: 15 doublings + 63 adds", "28 base-point adds",
+                                 "R's test (L, K, L^2 v == K^2 u)", "park + chain", "the lane's inversion", "second pass"};
+static const double MACS[NPH] = {0, 15 * 1312.0 + 63 * 1344 + 576, 28 * 1344.0, 3 * 136 + 8 * 192.0 + 16, 192, 63616.0 / 8, 3 * 192};
+
+__device__ __forceinline__ uint64_t now() { return __builtin_readcyclecounter(); }
+
+extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
+k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ pk,
+         const uint8_t *__restrict__ msgs, uint32_t msg_len, uint32_t n, const uint4 *__restrict__ bwt,
+         const uint4 *__restrict__ combs, uint4 *__restrict__ park, unsigned long long *__restrict__ totals) {
+    __shared__ uint32_t s_bits[16 * BLOCK];
+    GlobalBwt bwt_tab{bwt};
+    FixedBwt<GlobalBwt> fb{bwt_tab};
+    LdsStage stage{s_bits + threadIdx.x};
+    LdsMkBitsVerify mkbits{s_bits + threadIdx.x};
+    uint64_t acc[NPH];
+    for (int k = 0; k < NPH; k++) acc[k] = 0;
+    uint64_t t0, t1;
+#define MARK(k) t1 = now(); acc[k] += t1 - t0; t0 = t1
+    InvChain ch;
+    ch.begin();
+    for_each_op<true>(n, [&](uint32_t i, bool live) GD_LAMBDA_INLINE {
+        t0 = now();
+        const Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msgs + (size_t)msg_len * i,
+                                                  msg_len, 0, nullptr, 0);
+        const GlobalCombBig comb{combs + (size_t)KEY_COMB_U4 * ((i >> 10) & 1023u)};
+        uint32_t w[29];
+        shake256_114(w, m, m.total(), stage);
+        const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));
+        load_bytes_as_words(w, m.a + 57, 57, 15);
+        const sc response = sc_decode_long_words<57>(w);
+        auto bits = mkbits(comb_big::recode(challenge), 0);
+        MARK(0);
+        pt P = ladder_comb(bits, comb);
+        MARK(1);
+        fb.add_to(P, response, mkbits);
+        MARK(2);
+        load_bytes_as_words(w, m.a, 57, 15);
+        const uint32_t last = w[14] & 0xff;
+        const bool sign = (last & 0x80) != 0;
+        bool ok = (last & 0x7f) == 0;
+        fe y;
+        ok = fe_deserialize_words(y, w) && ok;
+        const fe y2 = fe_sqr(y);
+        const fe u = fe_weak(fe_sub<2>(fe_one(), y2));
+        const fe v = fe_weak(fe_add(fe_one(), fe_mulw(y2, NEG_EDWARDS_D)));
+        ok = ok && !fe_is_zero(u) && !fe_is_zero(v);
+        const fe w1 = fe_mul(y2, v);
+        const fe lf = fe_mul(fe_weak(fe_sub<2>(w1, u)), fe_add(u, w1));
+        const fe L = fe_mul(P.x, lf);
+        const fe ef = fe_weak(fe_sub<4>(fe_add(v, v), fe_add(u, w1)));
+        fe K = fe_mul(P.y, fe_mul(fe_mul(ef, v), y));
+        K = fe_weak(fe_add(K, K));
+        const bool poly = fe_eq(fe_mul(fe_sqr(L), v), fe_mul(fe_sqr(K), u));
+        MARK(3);
+        uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * i;
+        if (live) {
+            fe_store(slot + 8, L);
+            slot[12] = make_uint4(ok && poly ? 1u : 0u, sign ? 1u : 0u, 0u, 0u);
+        }
+        ch.push(slot, K, live);
+        MARK(4);
+    });
+    t0 = now();
+    ch.invert();
+    MARK(5);
+    for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
+        const uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * i;
+        const fe inv_k = ch.pop(slot);
+        const uint4 flags = slot[12];
+        status[i] = flags.x && (fe_lobit(fe_mul(fe_load(slot + 8), inv_k)) == (flags.y != 0)) ? -1 : 0;
+    });
+    MARK(6);
+    for (int k = 0; k < NPH; k++) atomicAdd(totals + k, (unsigned long long)acc[k]);
+}
+
+int main() {
+    const uint32_t n = 1u << 20, msg_len = 32, nkeys = 1024;
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int grid = prop.multiProcessorCount * WAVES_PER_SIMD;
+    uint8_t *sig, *pk, *msg;
+    int32_t *status;
+    uint4 *bwt, *combs, *park;
+    unsigned long long *totals;
+    const size_t bwt_bytes = (size_t)BWT_ENTRIES * 12 * sizeof(uint4), comb_bytes = (size_t)nkeys * KEY_COMB_U4 * sizeof(uint4);
+    CHECK(hipMalloc(&sig, 114 * (size_t)n));
+    CHECK(hipMalloc(&pk, 57 * (size_t)n));
+    CHECK(hipMalloc(&msg, msg_len * (size_t)n));
+    CHECK(hipMalloc(&status, 4 * (size_t)n));
+    CHECK(hipMalloc(&bwt, bwt_bytes));
+    CHECK(hipMalloc(&combs, comb_bytes));
+    CHECK(hipMalloc(&park, (size_t)n * KEYCOMB_SLOT_U4 * sizeof(uint4)));
+    CHECK(hipMalloc(&totals, NPH * sizeof(unsigned long long)));
+    {   // random bytes everywhere (table entries: limbs below 2^28)
+        const size_t nb = bwt_bytes > comb_bytes ? bwt_bytes : comb_bytes;
+        uint32_t *h = (uint32_t *)malloc(nb);
+        uint64_t x = 0x9e3779b97f4a7c15ull;
+        for (size_t i = 0; i < nb / 4; i++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            h[i] = (uint32_t)x & 0x0fffffffu;
+        }
+        CHECK(hipMemcpy(bwt, h, bwt_bytes, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(combs, h + 12345, comb_bytes - 4 * 12345, hipMemcpyHostToDevice));
+        for (size_t i = 0; i < 114 * (size_t)n / 4; i++) {
+            x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+            h[i] = (uint32_t)x;
+        }
+        CHECK(hipMemcpy(sig, h, 114 * (size_t)n, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(pk, h + 1000, 57 * (size_t)n, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(msg, h + 5000, msg_len * (size_t)n, hipMemcpyHostToDevice));
+        free(h);
+    }
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0));
+    CHECK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 3; rep++) {
+        CHECK(hipMemset(totals, 0, NPH * sizeof(unsigned long long)));
+        CHECK(hipEventRecord(e0));
+        hipLaunchKernelGGL(k_phases, dim3(grid), dim3(BLOCK), 0, 0, status, sig, pk, msg, msg_len, n, bwt, combs, park, totals);
+        CHECK(hipEventRecord(e1));
+        CHECK(hipDeviceSynchronize());
+        float ms;
+        CHECK(hipEventElapsedTime(&ms, e0, e1));
+        unsigned long long t[NPH];
+        CHECK(hipMemcpy(t, totals, sizeof(t), hipMemcpyDeviceToHost));
+        double sum = 0;
+        for (int k = 0; k < NPH; k++) sum += (double)t[k];
+        printf("run %d: %.3f ms per 2^20 (instrumented)\n", rep, ms);
+        if (rep < 2) continue;
+        printf("%-42s %8s %12s %10s %14s\n", "phase", "share", "ms of total", "MACs", "clocks / MAC");
+        for (int k = 0; k < NPH; k++) {
+            char b[32] = "-";
+            if (MACS[k] > 0) snprintf(b, sizeof b, "%.3f", (double)t[k] / n / MACS[k]);
+            printf("%-42s %7.2f%% %12.3f %10.0f %14s\n", PHASE[k], 100.0 * t[k] / sum, ms * t[k] / sum, MACS[k], b);
+        }
+    }
+    return 0;
+}

@@ -67,6 +67,7 @@ for probe in gpu_probe wave_probe key_pool_probe ct_varbase_probe base_double_pr
 done
 "$ROOT/tools/fieldbench" > "$DST/fieldbench.txt" 2>&1
 "$ROOT/tools/verifyphases" > "$DST/verifyphases.txt" 2>&1
+"$ROOT/tools/keycombphases" > "$DST/keycombphases.txt" 2>&1
 python3 "$ROOT/tests/batch_sweep.py" > "$DST/batch_sweep.txt" 2>&1
 python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$DST"
 ls -la "$DST"
