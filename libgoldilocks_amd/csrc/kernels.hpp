@@ -484,7 +484,7 @@ GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict
 // one decoding and one window table per distinct public key of a verification batch (kernels_verify.hip)
 GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slot_of, uint32_t *__restrict__ key_list,
                           uint32_t *__restrict__ hash_slots, uint32_t hash_mask, uint32_t *__restrict__ ctrl,
-                          const uint8_t *__restrict__ pk, uint32_t n);
+                          const uint8_t *__restrict__ pk, uint32_t n, uint32_t seed);
 GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t pool_capacity, uint32_t comb_capacity,
                             uint32_t comb_min_per_key);
 GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,

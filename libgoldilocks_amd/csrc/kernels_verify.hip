@@ -41,20 +41,21 @@ GD_KERNEL k_half_size_pair(uint32_t *__restrict__ rho, uint32_t *__restrict__ ta
 // decodes its key and builds its table itself, as before.
 // ctrl: [0] distinct keys seen, [1] keys with a pooled window table, [2] keys with a comb (k_verify_key_mode: at most
 // one of the two is non-zero); zeroed by the host
-__device__ __forceinline__ uint32_t key_hash(const uint32_t (&w)[15]) {
-    uint32_t h = 0x9e3779b9u;
+// (seed: drawn per call by the host, so that which keys collide in the set is not a property of the batch alone)
+__device__ __forceinline__ uint32_t key_hash(const uint32_t (&w)[15], uint32_t seed) {
+    uint32_t h = 0x9e3779b9u ^ seed;
 #pragma unroll
     for (int k = 0; k < 15; k++) h = (h ^ w[k]) * 0x85ebca6bu + (h >> 15);
     return h ^ h >> 13;
 }
 GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slot_of, uint32_t *__restrict__ key_list,
                           uint32_t *__restrict__ hash_slots, uint32_t hash_mask, uint32_t *__restrict__ ctrl,
-                          const uint8_t *__restrict__ pk, uint32_t n) {
+                          const uint8_t *__restrict__ pk, uint32_t n, uint32_t seed) {
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         uint32_t w[15];
         load_bytes_as_words(w, pk + 57 * (size_t)i, 57, 15);
-        uint32_t h = key_hash(w) & hash_mask, owner;
+        uint32_t h = key_hash(w, seed) & hash_mask, owner;
         for (;;) {
             owner = atomicCAS(hash_slots + h, 0xffffffffu, i);
             if (owner == 0xffffffffu) {
