@@ -421,6 +421,41 @@ def test_golden_f3_f7_through_the_large_batch_kernels(ga, keys):
         ga.set_verify_key_combs()
 
 
+@pytest.mark.parametrize("keys", ["combs", "pooled tables", "every lane for itself"])
+def test_degenerate_r_and_keys_through_the_large_batch_kernels(ga, O, keys):
+    """The key-comb kernel tests R without decoding it (eddsa.hpp ed448_verify_keycomb_begin): x_R = L / K with
+    K = 2 Y_P (2v - u - y^2 v) v y.  The encodings where that degenerates -- y_R = 0 (K = 0: the slow path decodes R after
+    all), y_R = +-1 (u = 0: the reference's isr(0) failure), y_R >= p, the sign bit flipped, byte 56 not 0 / 0x80 -- and
+    the same for the keys, spliced into valid signatures of 6 keys and replicated to 12 288 signatures: every lane
+    against the oracle, through all three large-batch paths."""
+    P_ = 2**448 - 2**224 - 1
+    enc = lambda y, s=0: np.frombuffer(int(y).to_bytes(56, "little") + bytes([0x80 * s]), np.uint8)
+    sigs, pks, msgs = _gen.signatures(O, 48, msglen=20, seed=b"degenerate", nkeys=6)
+    msgs = np.array([np.frombuffer(m, np.uint8) for m in msgs])
+    special = [enc(0), enc(0, 1), enc(1), enc(1, 1), enc(P_ - 1), enc(P_ - 1, 1), enc(P_), enc(2**448 - 1), enc(5), enc(5, 1), enc(2), enc(P_ - 2)]
+    for i, r in enumerate(special):
+        sigs[2 * i, :57] = r                     # R
+    sigs[25, 56] ^= 0x80                         # R's sign
+    sigs[27, 56] |= 0x01                         # byte 56 of R
+    sigs[29, 57:] = 0xff                         # S >= q: reduced, not rejected
+    for i, r in enumerate(special[:6]):
+        pks[30 + 2 * i] = r                      # the key
+    pks[43, 56] ^= 0x80
+    want48 = _gen.oracle_verify(O, sigs, pks, [m.tobytes() for m in msgs])
+    assert (want48 == -1).sum() >= 12 and (want48 == 0).sum() >= 20
+    order = np.random.default_rng(3).permutation(48 * 256) % 48
+    try:
+        ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT if keys != "every lane for itself" else 0, 4097)
+        ga.set_verify_key_combs(ga.KEY_COMBS_DEFAULT if keys == "combs" else 0, 8)
+        got = np.asarray(ga.ed448_verify_batch(sigs[order], pks[order], [m.tobytes() for m in msgs[order]]))
+        assert (got == want48[order]).all(), sorted(set(order[got != want48[order]]))
+        distinct, pooled, combed = ga.last_verify_key_counts()
+        assert (pooled, combed) == dict(combs=(0, distinct), **{"pooled tables": (distinct, 0), "every lane for itself": (0, 0)})[keys]
+    finally:
+        ga.set_verify_key_pool()
+        ga.set_verify_key_combs()
+
+
 def test_rfc8032_vectors_through_the_abi(ga):
     kats = json.load(open(os.path.join(GOLD, "kats.json")))
     for c in kats["rfc8032_ed448"]:
