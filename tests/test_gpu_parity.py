@@ -456,6 +456,19 @@ def test_degenerate_r_and_keys_through_the_large_batch_kernels(ga, O, keys):
         ga.set_verify_key_combs()
 
 
+def test_small_batches_of_few_keys_get_combs_by_default(ga, O):
+    """From 2^13 signatures on (the smallest batches the lane kernels see) keys that repeat enough get combs with the
+    library's defaults: 12 000 signatures of 16 keys, a few corrupted, every lane against the oracle."""
+    n = 12_000
+    sigs, pks, msgs = _gen.signatures(O, n, msglen=24, seed=b"small-combs", nkeys=16)
+    sigs[::7, 60] ^= 2
+    sigs[3::11, 5] ^= 1
+    got = np.asarray(ga.ed448_verify_batch(sigs, pks, msgs))
+    assert ga.last_verify_key_counts() == (16, 0, 16)
+    want = _gen.oracle_verify(O, sigs, pks, msgs)
+    assert (got == want).all() and (want == 0).sum() > n // 8 and (want == -1).sum() > n // 2
+
+
 def test_rfc8032_vectors_through_the_abi(ga):
     kats = json.load(open(os.path.join(GOLD, "kats.json")))
     for c in kats["rfc8032_ed448"]:
