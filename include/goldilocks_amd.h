@@ -369,8 +369,8 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
  * 16, 48 KiB per key, built on the device per call), with which a verification is src/eddsa.c's equation without a
  * ladder and without R's decoding -- 0.3 of the arithmetic.  Used when the batch averages at least
  * `min_signatures_per_key` signatures per distinct key (twice that for batches below 2^18 signatures, where the fixed
- * latency of building the combs weighs more) and has at most `keys` distinct keys, in batches of 2^13 signatures or
- * more (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the combs off, 2^17 is the most
+ * latency of building the combs weighs more) and has at most `keys` distinct keys, in batches of more than 2^12
+ * signatures (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the combs off, 2^17 is the most
  * (62 KiB of device memory per key the batch may have); turning the pool off
  * (goldilocks_amd_set_verify_key_pool(0, ..)) turns the combs off with it.  Process-wide. */
 #define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 15)

@@ -352,7 +352,7 @@ struct GlobalBwt {
 constexpr int KEY_TEETH_U4 = 2 * comb_big::TEETH * comb_big::COMBS * 16;   // 28 teeth + their doubles (pniels) per key while its comb is built
 constexpr int KEY_COMB_U4 = comb_big::ENTRIES * 12;
 constexpr int KEY_COMBS_MAX = 1 << 17;     // the most keys of a batch that can have combs (62 KiB of workspace each)
-constexpr int KEY_COMBS_MIN_BATCH = 8192;   // combs are considered from so many signatures on (smaller batches: one verification per wave, or too few per key)
+constexpr int KEY_COMBS_MIN_BATCH = 4096;   // combs are considered from so many signatures on (up to there a wave verifies each signature, section 7a)
 constexpr int KEY_SORT_BINS = 8192;        // up to so many keys the counting sort goes through per-block bins in LDS
 constexpr int KEY_TEETH_BY_WAVE_MAX = 4096;   // up to so many keys a WAVE computes a key's teeth (latency), beyond a lane (throughput)
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)

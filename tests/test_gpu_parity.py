@@ -457,9 +457,9 @@ def test_degenerate_r_and_keys_through_the_large_batch_kernels(ga, O, keys):
 
 
 def test_small_batches_of_few_keys_get_combs_by_default(ga, O):
-    """From 2^13 signatures on (the smallest batches the lane kernels see) keys that repeat enough get combs with the
-    library's defaults: 12 000 signatures of 16 keys, a few corrupted, every lane against the oracle."""
-    n = 12_000
+    """From the smallest batches the lane kernels see (more than 2^12 signatures) keys that repeat enough get combs
+    with the library's defaults: 5 000 signatures of 16 keys, a few corrupted, every lane against the oracle."""
+    n = 5_000
     sigs, pks, msgs = _gen.signatures(O, n, msglen=24, seed=b"small-combs", nkeys=16)
     sigs[::7, 60] ^= 2
     sigs[3::11, 5] ^= 1
