@@ -79,11 +79,14 @@ WORKLOADS = {
     # points + two correcting additions + 28 base-point additions
     # macs_own_key: every lane decodes its key and builds the key's table itself (what "verify_distinct" runs);
     # macs_shared_keys: the key has a pooled window table (one decoding and one table per DISTINCT key of the batch,
-    # kernels_verify.hip); macs_key_comb: the key has a fixed-base comb of its own -- keys that sign at least 32 of
-    # the batch's signatures on average, which is what 2^20 signatures of 2^10 keys run at: no ladder, R's decoding +
-    # the key's comb + the base point's additions; per key 3.46 M more (its decoding, 432 doublings, 256 entries),
-    # 3 377 per signature at 2^10 keys
-    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=149_976 + 3_377, macs_key_comb=149_976, macs_per_key_comb=3_458_392,
+    # kernels_verify.hip); macs_key_comb: the key has a fixed-base comb of its own (keys that sign at least 16 of the
+    # batch's signatures on average): no ladder, no decoding of R -- the key's 4 x 7 x 16 comb, the base point's
+    # additions, R's test with a shared inversion; per key 3.46 M more (its decoding, 432 doublings, 256 entries);
+    # macs_key_comb_wide: keys with 256 signatures or more get 4 x 8 x 14 combs -- what 2^20 signatures of 2^10 keys
+    # run at: 13 doublings + 55 additions, 7.09 M per key (512 entries) = 6 922 per signature at 2^10 keys
+    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=136_984 + 6_922,
+                   macs_key_comb=149_976, macs_per_key_comb=3_458_392,
+                   macs_key_comb_wide=136_984, macs_per_key_comb_wide=7_088_472,
                    macs_pooled_tables=522_128 + 87, macs_own_key=611_480, macs_shared_keys=522_128, keys=1024,
                    desc="goldilocks_ed448_verify, 32-byte messages, 2^10 distinct keys (SURVEY 8d), 1% corrupted"),
     "verify_distinct": dict(metric="Ed448 verifies/sec, every signature under its own key", unit="verifies/s", bytes=207,
@@ -287,8 +290,9 @@ def make_workload(name, cx, access):
         m = min(n, SAMPLE)
         return dict(kind="verify", sigs=v["sig"][:m], pks=v["pk"][:m], msgs=[x.tobytes() for x in v["msg"][:m]],
                     got=host(status[:m]))
-    # 2^10 keys: every key gets a fixed-base comb (kernels_verify.hip); all-distinct keys: every lane for itself
-    return dict(step=step, kernel="k_ed448_verify" if name == "verify_distinct" else "k_ed448_verify_keycomb", check=check, sample=sample)
+    # 2^10 keys: every key gets a fixed-base comb, the wide one at 2^10 signatures per key (kernels_verify.hip);
+    # all-distinct keys: every lane for itself
+    return dict(step=step, kernel="k_ed448_verify" if name == "verify_distinct" else "k_ed448_verify_keycomb_wide", check=check, sample=sample)
 
 
 def verify_inputs(cx, distinct=False):

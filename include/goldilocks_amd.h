@@ -376,10 +376,15 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
 #define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 15)
 #define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 16
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t min_signatures_per_key);
+/* ... and keys that sign at least this many signatures of the batch on average get the wider comb (4 x 8 x 14, 96 KiB:
+ * twice the entries to build, 9 % less to walk per signature).  0: never.  Process-wide. */
+#define GOLDILOCKS_AMD_KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT 256
+GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_wide(size_t min_signatures_per_key);
 /* Test hook: how the last large verification batch on the calling thread's device served its keys --
  * counts[0] distinct keys seen, counts[1] keys with a pooled window table, counts[2] keys with a comb (at most one of the
- * two is non-zero; all zero if the batch was too small for either).  Waits for the device. */
-GOLDILOCKS_AMD_API int goldilocks_amd_last_verify_key_counts(uint32_t counts[3]);
+ * two is non-zero; all zero if the batch was too small for either), counts[3] the combs' teeth (7 or 8; 0 without
+ * combs).  Waits for the device. */
+GOLDILOCKS_AMD_API int goldilocks_amd_last_verify_key_counts(uint32_t counts[4]);
 /* "gfx950", number of CUs, workspace bytes currently held */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
         size_t *workspace_bytes);

@@ -89,6 +89,7 @@ FUNCTIONS = {
     "goldilocks_amd_get_wave_batch_max": (C.c_size_t, ""),
     "goldilocks_amd_set_verify_key_pool": (None, "zz"),
     "goldilocks_amd_set_verify_key_combs": (None, "zz"),
+    "goldilocks_amd_set_verify_key_combs_wide": (None, "z"),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -462,6 +463,14 @@ def set_verify_key_combs(keys=KEY_COMBS_DEFAULT, min_signatures_per_key=KEY_COMB
     lib().goldilocks_amd_set_verify_key_combs(int(keys), int(min_signatures_per_key))
 
 
+KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT = 256
+
+
+def set_verify_key_combs_wide(min_signatures_per_key=KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT):
+    """Keys that sign at least so many signatures of a batch on average get the wider comb (8 teeth); 0: never."""
+    lib().goldilocks_amd_set_verify_key_combs_wide(int(min_signatures_per_key))
+
+
 def get_table_access():
     return lib().goldilocks_amd_get_table_access()
 
@@ -473,12 +482,12 @@ def thread_mode_counts():
     return int(c[0]), int(c[1])
 
 
-def last_verify_key_counts():
+def last_verify_key_counts(teeth=False):
     """(distinct keys, keys with a pooled window table, keys with a comb) of the last large verification batch on this
-    device (test hook)."""
-    c = (C.c_uint32 * 3)()
+    device (test hook); teeth=True: the combs' teeth (7, 8, or 0 without combs) as a fourth number."""
+    c = (C.c_uint32 * 4)()
     _check(lib().goldilocks_amd_last_verify_key_counts(C.addressof(c)))
-    return int(c[0]), int(c[1]), int(c[2])
+    return (int(c[0]), int(c[1]), int(c[2]), int(c[3])) if teeth else (int(c[0]), int(c[1]), int(c[2]))
 
 
 def device_info():

@@ -349,18 +349,23 @@ struct GlobalBwt {
 };
 // A 4 x 7 x 16 comb in global memory, read by the digit (public scalars only): the comb of a verification key that
 // signed many of a batch's signatures (kernels_verify.hip), 256 affine niels = 48 KiB per key.
-constexpr int KEY_TEETH_U4 = 2 * comb_big::TEETH * comb_big::COMBS * 16;   // 28 teeth + their doubles (pniels) per key while its comb is built
+constexpr int KEY_TEETH_U4 = 2 * comb_wide::TEETH * comb_wide::COMBS * 16;   // room for 32 teeth + their doubles (pniels) per key while its comb is built
 constexpr int KEY_COMB_U4 = comb_big::ENTRIES * 12;
+// a key's comb has 7 or 8 teeth per comb (ctrl[3], k_verify_key_mode): entries and uint4 of one key's comb
+__host__ __device__ constexpr uint32_t key_comb_entries(uint32_t teeth) { return 4u << (teeth - 1); }
+__host__ __device__ constexpr uint32_t key_comb_u4(uint32_t teeth) { return 12u * key_comb_entries(teeth); }
+
 constexpr int KEY_COMBS_MAX = 1 << 17;     // the most keys of a batch that can have combs (62 KiB of workspace each)
 constexpr int KEY_COMBS_MIN_BATCH = 4096;   // combs are considered from so many signatures on (up to there a wave verifies each signature, section 7a)
 constexpr int KEY_SORT_BINS = 8192;        // up to so many keys the counting sort goes through per-block bins in LDS
 constexpr int KEY_TEETH_BY_WAVE_MAX = 4096;   // up to so many keys a WAVE computes a key's teeth (latency), beyond a lane (throughput)
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)
-struct GlobalCombBig {
-    using plan = comb_big;
+template <class PLAN>
+struct GlobalCombOf {
+    using plan = PLAN;
     const uint4 *p;
     __device__ __forceinline__ niels load(int j, uint32_t idx) const {
-        const uint4 *q = p + 12 * (comb_big::PER_COMB * j + idx);
+        const uint4 *q = p + 12 * (PLAN::PER_COMB * j + idx);
         niels e;
         e.a = fe_load(q);
         e.b = fe_load(q + 4);
@@ -368,6 +373,7 @@ struct GlobalCombBig {
         return e;
     }
 };
+using GlobalCombBig = GlobalCombOf<comb_big>;
 
 struct LdsStage {  // 136-byte sponge block per lane, word-interleaved across lanes
     uint32_t *p;   // &stage[threadIdx.x]
@@ -487,7 +493,7 @@ GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slo
                           uint32_t *__restrict__ hash_slots, uint32_t hash_mask, uint32_t *__restrict__ ctrl,
                           const uint8_t *__restrict__ pk, uint32_t n, uint32_t seed);
 GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t pool_capacity, uint32_t comb_capacity,
-                            uint32_t comb_min_per_key);
+                            uint32_t comb_min_per_key, uint32_t wide_min_per_key);
 GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                               const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk);
 extern "C" __global__ void k_verify_key_teeth(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok,
@@ -498,6 +504,14 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain);
 GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
+                                 const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
+                                 const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
+                                 const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
+                                 const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
+                                 const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
+                                 const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
+                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order);
+GD_KERNEL k_ed448_verify_keycomb_wide(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
                                  const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,

@@ -80,7 +80,7 @@ GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slo
 }
 // ctrl[1], ctrl[2]: how this batch's keys are served (one thread, after the dedupe)
 GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t pool_capacity, uint32_t comb_capacity,
-                            uint32_t comb_min_per_key) {
+                            uint32_t comb_min_per_key, uint32_t wide_min_per_key) {
     if (blockIdx.x || threadIdx.x) return;
     const uint32_t distinct = ctrl[0];
     uint32_t pooled = 0, combed = 0;
@@ -88,6 +88,8 @@ GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t po
     else if (2 * (uint64_t)distinct <= n && distinct <= pool_capacity) pooled = distinct;
     ctrl[1] = pooled;
     ctrl[2] = combed;
+    // teeth per comb: 8 (scalarmul.hpp comb_wide) for keys that sign hundreds of signatures each, else 7 (comb_big)
+    ctrl[3] = !combed ? 0u : wide_min_per_key && (uint64_t)distinct * wide_min_per_key <= n ? (uint32_t)comb_wide::TEETH : (uint32_t)comb_big::TEETH;
 }
 GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                               const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk) {
@@ -126,9 +128,9 @@ GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ ke
 // 1.7 ms however few keys there are, but it costs a sixth of a wave's instructions: 2^15 keys 1.8 ms against 6.4 ms.
 GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                                    const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk) {
-    constexpr int NT = comb_big::TEETH * comb_big::COMBS;
     const uint32_t combed = ctrl[2];
     if (combed <= (uint32_t)KEY_TEETH_BY_WAVE_MAX) return;
+    const int NT = 4 * (int)ctrl[3], spacing = 448 / NT;
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < combed; k += stride) {
         uint32_t w[15];
@@ -143,7 +145,7 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
             pniels_store(out + 16 * (NT + m), pt_to_pniels(P));
             if (m + 1 == NT) break;
 #pragma unroll 1
-            for (int d = 1; d < comb_big::SPACING; d++) pt_double(P, d + 1 == comb_big::SPACING);
+            for (int d = 1; d < spacing; d++) pt_double(P, d + 1 == spacing);
         }
     }
 }
@@ -154,18 +156,20 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
 // The entries wait unnormalised in their own slots of the comb; chain: 8 uint4 per (key, entry) for the trick.
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain) {
-    constexpr uint32_t SEG = 16, PER_KEY = comb_big::ENTRIES / SEG, NT = comb_big::TEETH * comb_big::COMBS;
-    const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK, total = combed * PER_KEY;
+    constexpr uint32_t SEG = 16;
+    const uint32_t teeth_per = ctrl[3], NT = 4 * teeth_per, per_comb = 1u << (teeth_per - 1), entries = 4 * per_comb,
+                   per_key = entries / SEG;
+    const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK, total = combed * per_key;
     for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < total; t += stride) {
-        const uint32_t k = t / PER_KEY, j = (t % PER_KEY) / (comb_big::PER_COMB / SEG), g0 = (t % (comb_big::PER_COMB / SEG)) * SEG;
+        const uint32_t k = t / per_key, j = (t % per_key) / (per_comb / SEG), g0 = (t % (per_comb / SEG)) * SEG;
         const TeethAt tooth{teeth + (size_t)KEY_TEETH_U4 * k}, twice{teeth + (size_t)KEY_TEETH_U4 * k + 16 * NT};
-        uint4 *const comb = combs + (size_t)KEY_COMB_U4 * k + 12 * comb_big::PER_COMB * j;
-        uint4 *const slots = chain + ((size_t)comb_big::ENTRIES * k + comb_big::PER_COMB * j) * 8;
+        uint4 *const comb = combs + (size_t)key_comb_u4(teeth_per) * k + 12 * per_comb * j;
+        uint4 *const slots = chain + ((size_t)entries * k + per_comb * j) * 8;
         uint32_t idx = g0 ^ (g0 >> 1);
-        pt p = pniels_to_pt(tooth.load(comb_big::TEETH - 1 + comb_big::TEETH * j), false);
+        pt p = pniels_to_pt(tooth.load(teeth_per - 1 + teeth_per * j), false);
 #pragma unroll 1
-        for (uint32_t b = 0; b + 1 < (uint32_t)comb_big::TEETH; b++)
-            pt_add_pniels(p, tooth.load(b + comb_big::TEETH * j), ((idx >> b) & 1u) == 0, true);
+        for (uint32_t b = 0; b + 1 < teeth_per; b++)
+            pt_add_pniels(p, tooth.load(b + teeth_per * j), ((idx >> b) & 1u) == 0, true);
         InvChain ch;
         ch.begin();
 #pragma unroll 1
@@ -178,7 +182,7 @@ GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict_
             if (s + 1 == SEG) break;
             const uint32_t g = g0 + s + 1, b = (uint32_t)__builtin_ctz(g);     // the Gray bit that flips
             idx ^= 1u << b;
-            pt_add_pniels(p, twice.load(b + comb_big::TEETH * j), ((idx >> b) & 1u) == 0, true);
+            pt_add_pniels(p, twice.load(b + teeth_per * j), ((idx >> b) & 1u) == 0, true);
         }
         ch.invert();
 #pragma unroll 1
@@ -270,7 +274,8 @@ GD_KERNEL k_verify_key_scatter(uint32_t *__restrict__ order, uint32_t *__restric
 // park: KEYCOMB_SLOT_U4 uint4 per position of the launch (K | the chain's prefix | L | flags); at most
 // SHARED_INV_OPS_PER_LANE positions per resident lane per launch (the host splits larger batches: n positions of
 // `order`, which indexes the whole batch's arrays)
-GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
+template <class PLAN>
+__device__ __forceinline__ void verify_keycomb_body(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
                                  const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
@@ -279,7 +284,7 @@ GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                                  uint4 *__restrict__ park, const uint32_t *__restrict__ order) {
     __shared__ uint32_t s_bits[16 * BLOCK];
-    if (!ctrl[2]) return;                       // this batch's keys are served otherwise (k_ed448_verify)
+    if (ctrl[3] != (uint32_t)PLAN::TEETH) return;   // this batch's keys are served otherwise (k_ed448_verify, or the other comb)
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> b_tab{bwt_tab};
     LdsStage stage{s_bits + threadIdx.x};       // (unused by the word-granular absorb)
@@ -295,7 +300,7 @@ GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__
         const Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msg,
                                                   fits ? (uint32_t)len64 : 0u, prehashed, ctx, ctx_len);
         const uint32_t k = slot_of[rep[i]];
-        const GlobalCombBig comb{combs + (size_t)KEY_COMB_U4 * k};
+        const GlobalCombOf<PLAN> comb{combs + (size_t)PLAN::ENTRIES * 12 * k};
         const KeycombPending pend = ed448_verify_keycomb_begin(m, b_tab, comb, stage, mk);
         uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * t;
         if (live) {
@@ -318,6 +323,23 @@ GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__
         status[i] = ed448_verify_keycomb_finish(pend, inv_k) ? -1 : 0;
     });
 }
+
+#define KEYCOMB_ARGS                                                                                                      \
+    int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ pk,                        \
+        const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed, \
+        const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n, const uint4 *__restrict__ bwt,                     \
+        const uint32_t *__restrict__ rep, const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,          \
+        const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl, uint4 *__restrict__ park,                  \
+        const uint32_t *__restrict__ order
+GD_KERNEL k_ed448_verify_keycomb(KEYCOMB_ARGS) {        // keys with 7 teeth per comb (4 x 7 x 16)
+    verify_keycomb_body<comb_big>(status, sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
+                                  key_ok, ctrl, park, order);
+}
+GD_KERNEL k_ed448_verify_keycomb_wide(KEYCOMB_ARGS) {   // keys with 8 (4 x 8 x 14): hundreds of signatures per key
+    verify_keycomb_body<comb_wide>(status, sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
+                                   key_ok, ctrl, park, order);
+}
+#undef KEYCOMB_ARGS
 
 // config 4: status[i] = ed448_verify(sig[i], pk[i], msg[i])   (ref: goldilocks_ed448_verify)
 GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,

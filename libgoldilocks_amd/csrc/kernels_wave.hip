@@ -109,15 +109,15 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_verify_key_teeth(uint4 *__
         if (me == 0) key_ok[k] = ok ? 1 : 0;
         wc::wfe P = wc::pack_point<0>(L, X, Y, Z, T);
         uint32_t *out = reinterpret_cast<uint32_t *>(teeth + (size_t)KEY_TEETH_U4 * k);
-        constexpr int NT = comb_big::TEETH * comb_big::COMBS;
+        const int NT = 4 * (int)ctrl[3], spacing = 448 / NT;   // 7 teeth per comb, spacing 16, or 8 and 14 (k_verify_key_mode)
 #pragma unroll 1
-        for (int m = 0; m < NT; m++) {          // T_m, and 2 T_m (the first doubling towards T_(m+1)) behind the 28 teeth
+        for (int m = 0; m < NT; m++) {          // T_m, and 2 T_m (the first doubling towards T_(m+1)) behind the NT teeth
             out[64 * m + me] = wc::to_pniels(L, P, swap_row);
             P = wc::dbl(L, P);
             out[64 * (NT + m) + me] = wc::to_pniels(L, P, swap_row);
             if (m + 1 == NT) break;
 #pragma unroll 1
-            for (int d = 1; d < comb_big::SPACING; d++) P = wc::dbl(L, P);
+            for (int d = 1; d < spacing; d++) P = wc::dbl(L, P);
         }
     }
 }

@@ -119,6 +119,68 @@ static inline bool ed448_verify_lane(const uint8_t *sig, const uint8_t *pk, cons
 
 }  // namespace
 
+// verification against a key's own comb, the comb built as the device builds it (see hs_ed448_verify_keycomb below)
+template <class PLAN>
+struct HostTeethOf {
+    pniels t[PLAN::TEETH * PLAN::COMBS];
+    pniels load(uint32_t m) const { return t[m]; }
+};
+template <class PLAN>
+struct HostCombOf {
+    using plan = PLAN;
+    niels e[PLAN::ENTRIES];
+    niels load(int j, uint32_t idx) const { return e[PLAN::PER_COMB * j + idx]; }
+};
+template <class PLAN>
+static int verify_keycomb_host(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen, uint8_t prehashed,
+                               const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
+    static HostComb comb;
+    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
+    FixedComb<HostComb> fb{comb};
+    static HostCombOf<PLAN> kc;
+    static uint8_t have_pk[57];
+    static bool have = false, key_ok = false;
+    if (!have || memcmp(have_pk, pk, 57) != 0) {
+        uint32_t w[15];
+        bytes_to_words(w, pk, 57, 15);
+        pt A;
+        key_ok = pt_decode_eddsa_words(A, w);
+        static HostTeethOf<PLAN> teeth;
+        pt tooth = A;
+        for (int m = 0; m < PLAN::TEETH * PLAN::COMBS; m++) {
+            teeth.t[m] = pt_to_pniels(tooth);
+            if (m + 1 < PLAN::TEETH * PLAN::COMBS)
+                for (int d = 0; d < PLAN::SPACING; d++) pt_double(tooth, d + 1 == PLAN::SPACING);
+        }
+        static pt proj[PLAN::ENTRIES];
+        static fe prefix[PLAN::ENTRIES];
+        fe acc = fe_one();
+        for (int e = 0; e < PLAN::ENTRIES; e++) {
+            proj[e] = comb_entry_projective<PLAN>(teeth, (uint32_t)e);
+            prefix[e] = acc;
+            const fe z2 = fe_weak(fe_add(proj[e].z, proj[e].z));
+            acc = fe_mul(acc, fe_is_zero(z2) ? fe_one() : z2);
+        }
+        fe inv = fe_invert(acc);
+        for (int e = PLAN::ENTRIES - 1; e >= 0; e--) {
+            const fe z2 = fe_weak(fe_add(proj[e].z, proj[e].z));
+            const bool zero = fe_is_zero(z2);
+            const fe zi = zero ? fe_zero() : fe_mul(inv, prefix[e]);
+            inv = fe_mul(inv, zero ? fe_one() : z2);
+            kc.e[e].a = fe_mul(fe_weak(fe_sub<2>(proj[e].y, proj[e].x)), zi);
+            kc.e[e].b = fe_mul(fe_weak(fe_add(proj[e].x, proj[e].y)), zi);
+            kc.e[e].cn = fe_mul(fe_mulw(proj[e].t, TWO_EFF_D), zi);
+        }
+        memcpy(have_pk, pk, 57);
+        have = true;
+    }
+    HostStage stage;
+    HostMkBits mk;
+    Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
+    const KeycombPending pend = ed448_verify_keycomb_begin(m, fb, kc, stage, mk);
+    return ed448_verify_keycomb_finish(pend, fe_invert(pend.K)) && key_ok ? -1 : 0;   // (the device shares the inversion along a lane)
+}
+
 extern "C" {
 
 void hs_fe_mul(uint64_t *o, const uint64_t *a, const uint64_t *b) {
@@ -381,57 +443,14 @@ int hs_ed448_verify_lattice_shared_key(const uint8_t *sig, const uint8_t *pk, co
 // builds one per key when a batch's keys sign many signatures each).  The comb is built the way the device builds it:
 // teeth 2^(16 m) * A by doubling, every entry a signed sum of 7 teeth (scalarmul.hpp comb_big_entry_projective), one
 // inversion for the key's 256 entries (Montgomery's trick); kept for the next call with the same key.
-struct HostTeeth {
-    pniels t[comb_big::TEETH * comb_big::COMBS];
-    pniels load(uint32_t m) const { return t[m]; }
-};
 int hs_ed448_verify_keycomb(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen, uint8_t prehashed,
                             const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
-    static HostComb comb;
-    for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
-    FixedComb<HostComb> fb{comb};
-    static HostCombBig kc;
-    static uint8_t have_pk[57];
-    static bool have = false, key_ok = false;
-    if (!have || memcmp(have_pk, pk, 57) != 0) {
-        uint32_t w[15];
-        bytes_to_words(w, pk, 57, 15);
-        pt A;
-        key_ok = pt_decode_eddsa_words(A, w);
-        static HostTeeth teeth;
-        pt tooth = A;
-        for (int m = 0; m < comb_big::TEETH * comb_big::COMBS; m++) {
-            teeth.t[m] = pt_to_pniels(tooth);
-            if (m + 1 < comb_big::TEETH * comb_big::COMBS)
-                for (int d = 0; d < comb_big::SPACING; d++) pt_double(tooth, d + 1 == comb_big::SPACING);
-        }
-        static pt proj[comb_big::ENTRIES];
-        static fe prefix[comb_big::ENTRIES];
-        fe acc = fe_one();
-        for (int e = 0; e < comb_big::ENTRIES; e++) {
-            proj[e] = comb_big_entry_projective(teeth, (uint32_t)e);
-            prefix[e] = acc;
-            const fe z2 = fe_weak(fe_add(proj[e].z, proj[e].z));
-            acc = fe_mul(acc, fe_is_zero(z2) ? fe_one() : z2);
-        }
-        fe inv = fe_invert(acc);
-        for (int e = comb_big::ENTRIES - 1; e >= 0; e--) {
-            const fe z2 = fe_weak(fe_add(proj[e].z, proj[e].z));
-            const bool zero = fe_is_zero(z2);
-            const fe zi = zero ? fe_zero() : fe_mul(inv, prefix[e]);
-            inv = fe_mul(inv, zero ? fe_one() : z2);
-            kc.e[e].a = fe_mul(fe_weak(fe_sub<2>(proj[e].y, proj[e].x)), zi);
-            kc.e[e].b = fe_mul(fe_weak(fe_add(proj[e].x, proj[e].y)), zi);
-            kc.e[e].cn = fe_mul(fe_mulw(proj[e].t, TWO_EFF_D), zi);
-        }
-        memcpy(have_pk, pk, 57);
-        have = true;
-    }
-    HostStage stage;
-    HostMkBits mk;
-    Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
-    const KeycombPending pend = ed448_verify_keycomb_begin(m, fb, kc, stage, mk);
-    return ed448_verify_keycomb_finish(pend, fe_invert(pend.K)) && key_ok ? -1 : 0;   // (the device shares the inversion along a lane)
+    return verify_keycomb_host<comb_big>(sig, pk, msg, msglen, prehashed, ctx, ctxlen, comb_table);
+}
+// ... with the wider comb (4 x 8 x 14) of keys that sign hundreds of signatures
+int hs_ed448_verify_keycomb_wide(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen, uint8_t prehashed,
+                                 const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
+    return verify_keycomb_host<comb_wide>(sig, pk, msg, msglen, prehashed, ctx, ctxlen, comb_table);
 }
 // the short pair of a challenge: rho (15 words), tau (8 words, two's complement)
 void hs_half_size_pair(uint32_t *rho, uint32_t *tau, const uint64_t *h) {

@@ -224,25 +224,33 @@ def test_mac_counts_match_bench(H, O):
     # comb ladder, the base point's additions, the comparison; per key: its decoding, 432 doublings, 256 entries of
     # 6 additions each and their normalisation (counted with ONE inversion per key; the device shares one between the
     # keys a lane serves)
-    H.hs_ed448_verify_keycomb.restype = C.c_int
-    seen = set()
-    for i in range(3):
-        m = (C.c_uint8 * 32).from_buffer_copy(msgs[i])
-        counts = []
-        for _ in range(2):                                    # the first call with a key builds its comb
-            H.hs_mac_counter_reset()
-            assert H.hs_ed448_verify_keycomb(p(sigs[i]), p(pks[i]), m, C.c_size_t(32), C.c_uint8(0), None, C.c_uint8(0), p(comb)) == -1
-            counts.append(H.hs_mac_counter_get())
-        seen.add((counts[0] - counts[1], counts[1]))
-    assert len(seen) == 1
-    per_key, per_sig = seen.pop()
+    counts = {}
+    for wide, hook in ((False, H.hs_ed448_verify_keycomb), (True, H.hs_ed448_verify_keycomb_wide)):
+        hook.restype = C.c_int
+        seen = set()
+        for i in range(3):
+            m = (C.c_uint8 * 32).from_buffer_copy(msgs[i])
+            two = []
+            for _ in range(2):                                    # the first call with a key builds its comb
+                H.hs_mac_counter_reset()
+                assert hook(p(sigs[i]), p(pks[i]), m, C.c_size_t(32), C.c_uint8(0), None, C.c_uint8(0), p(comb)) == -1
+                two.append(H.hs_mac_counter_get())
+            seen.add((two[0] - two[1], two[1]))
+        assert len(seen) == 1
+        counts[wide] = seen.pop()
     # (the host hook inverts K per signature; the device shares one inversion between the 8 signatures a lane owns
     # at batch 2^20: 3 more multiplications for the chain)
-    per_sig += 28 * c["add_niels_t"] - (c["comb"] + c["pt_add"]) - inv + 3 * c["fe_mul"] + inv // 8
-    assert per_sig == c["comb_big"] + 28 * c["add_niels_t"] + 12 * c["fe_mul"] + 3 * c["fe_sqr"] + c["fe_mulw"] + inv // 8
+    adjust = 28 * c["add_niels_t"] - (c["comb"] + c["pt_add"]) - inv + 3 * c["fe_mul"] + inv // 8
+    per_key, per_sig = counts[False][0], counts[False][1] + adjust
+    per_key_wide, per_sig_wide = counts[True][0], counts[True][1] + adjust
+    rest = 28 * c["add_niels_t"] + 12 * c["fe_mul"] + 3 * c["fe_sqr"] + c["fe_mulw"] + inv // 8
+    assert per_sig == c["comb_big"] + rest
+    # the wider comb of keys with hundreds of signatures (4 x 8 x 14): 13 doublings + 55 additions instead of 15 + 63
+    assert per_sig_wide == c["niels_to_pt"] + 55 * c["add_niels_t"] - 13 * 192 + 13 * c["dbl_t"] + rest
     assert (W["verify"]["macs_key_comb"], W["verify"]["macs_per_key_comb"]) == (per_sig, per_key)
-    assert W["verify"]["macs"] == per_sig + per_key * W["verify"]["keys"] // 2**20
-    assert per_sig < 0.30 * W["verify"]["macs_shared_keys"]
+    assert (W["verify"]["macs_key_comb_wide"], W["verify"]["macs_per_key_comb_wide"]) == (per_sig_wide, per_key_wide)
+    assert W["verify"]["macs"] == per_sig_wide + per_key_wide * W["verify"]["keys"] // 2**20      # 2^10 keys x 2^10 signatures: wide
+    assert per_sig_wide < per_sig < 0.30 * W["verify"]["macs_shared_keys"]
 
 
 def test_big_comb_of_the_base_point_matches_oracle(H, O):
@@ -324,6 +332,7 @@ def test_verification_with_half_size_scalars(H, O):
     H.hs_ed448_verify_lattice.restype = C.c_int
     H.hs_ed448_verify_lattice_shared_key.restype = C.c_int
     H.hs_ed448_verify_keycomb.restype = C.c_int
+    H.hs_ed448_verify_keycomb_wide.restype = C.c_int
     want = _gen.oracle_verify(O, sigs, pks, mlist)
     for i in range(n):
         m = (C.c_uint8 * len(mlist[i])).from_buffer_copy(mlist[i])
@@ -340,6 +349,9 @@ def test_verification_with_half_size_scalars(H, O):
         got = H.hs_ed448_verify_keycomb(sigs[i].ctypes.data_as(C.c_void_p), pks[i].ctypes.data_as(C.c_void_p), m,
                                         C.c_size_t(len(mlist[i])), C.c_uint8(0), None, C.c_uint8(0), tab)
         assert got == want[i], ("key comb", i)
+        got = H.hs_ed448_verify_keycomb_wide(sigs[i].ctypes.data_as(C.c_void_p), pks[i].ctypes.data_as(C.c_void_p), m,
+                                             C.c_size_t(len(mlist[i])), C.c_uint8(0), None, C.c_uint8(0), tab)
+        assert got == want[i], ("wide key comb", i)
     assert (want == -1).sum() >= 10 and (want == 0).sum() >= 10
     accepted = rejected = 0
     for c in f7:
@@ -352,6 +364,8 @@ def test_verification_with_half_size_scalars(H, O):
                                                     C.c_uint8(len(ctx)), tab) == c["verdict"], ("shared key", c["kind"])
         assert H.hs_ed448_verify_keycomb(sig, pk, mb, C.c_size_t(len(msg)), C.c_uint8(c["prehashed"]), cb,
                                          C.c_uint8(len(ctx)), tab) == c["verdict"], ("key comb", c["kind"])
+        assert H.hs_ed448_verify_keycomb_wide(sig, pk, mb, C.c_size_t(len(msg)), C.c_uint8(c["prehashed"]), cb,
+                                              C.c_uint8(len(ctx)), tab) == c["verdict"], ("wide key comb", c["kind"])
         accepted += got == -1; rejected += got == 0
     assert accepted >= 4 and rejected >= 4
 
