@@ -62,7 +62,7 @@ pmc SQ1FAST varbase $FAST -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_
 pmc SQ2FAST varbase $FAST -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 pmc GRBM varbase -- GRBM_GUI_ACTIVE
 
-for probe in gpu_probe h2d_probe wave_probe key_pool_probe ct_varbase_probe base_double_probe ct_base_probe direct_probe single_call_probe encode_probe crossover_probe; do
+for probe in gpu_probe h2d_probe wave_probe key_pool_probe wide_comb_probe small_batch_probe ct_varbase_probe base_double_probe ct_base_probe direct_probe single_call_probe encode_probe crossover_probe; do
     python3 "$ROOT/tests/$probe.py" > "$DST/$probe.txt" 2>&1
 done
 "$ROOT/tools/fieldbench" > "$DST/fieldbench.txt" 2>&1
