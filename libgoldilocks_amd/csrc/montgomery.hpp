@@ -54,6 +54,28 @@ GD_FN void ml_step(fe &x2, fe &z2, fe &x3, fe &z3, const fe &x1) {
     z2 = fe_mul(fe_add(caa, e), e);                 // z2 = E (39081 AA + E)  (2 x 1)
 }
 
+// The same step with the conditional swap folded in.  Exchanging the two pairs exchanges DA and CB, so DA + CB and
+// (DA - CB)^2 -- the new (x3 : z3) -- do not depend on the swap at all: only the pair that is DOUBLED has to be
+// selected, i.e. one sum and one difference (32 selects per step instead of 64).  The differences are selected
+// unreduced (mag 3: they multiply the other pair's sum, mag 2, as they are) and the selected one is reduced once.
+GD_FN void ml_step_sel(fe &x2, fe &z2, fe &x3, fe &z3, const fe &x1, bool sw) {
+    const fe s2 = fe_add(x2, z2), s3 = fe_add(x3, z3);              // mag 2
+    const fe d2 = fe_sub<2>(x2, z2), d3 = fe_sub<2>(x3, z3);        // mag 3 (times mag 2 only)
+    const fe da = fe_mul(s2, d3);                                   // DA (or CB, swapped: the same pair)
+    const fe cb = fe_mul(s3, d2);
+    const fe t1 = fe_select(s2, s3, sw);                            // A = sum of the pair to double      mag 2
+    const fe t2 = fe_weak(fe_select(d2, d3, sw));                   // B = its difference                 mag 1
+    const fe dm = fe_weak(fe_sub<2>(da, cb));                       // +-(DA - CB)                        mag 1
+    z3 = fe_mul(x1, fe_sqr(dm));                                    // z3 = x1 (DA - CB)^2
+    x3 = fe_sqr(fe_add(da, cb));                                    // x3 = (DA + CB)^2       (input mag 2)
+    const fe aa = fe_sqr(t1);                                       // AA                     (input mag 2)
+    const fe bb = fe_sqr(t2);                                       // BB
+    const fe caa = fe_mulw(aa, ML_C);                               // 39081 AA
+    const fe e = fe_weak(fe_sub<2>(aa, bb));                        // E = AA - BB            mag 1
+    x2 = fe_mul(caa, bb);                                           // x2 = 39081 AA BB
+    z2 = fe_mul(fe_add(caa, e), e);                                 // z2 = E (39081 AA + E)  (2 x 1)
+}
+
 // bits.word(k): k-th 32-bit word of the scalar, already reduced mod q (446 bits).
 // b: the base point; x1 = u(P) = (Y + Z)/(Y - Z) in affine form (anything if P is the identity or (0,-1)).
 template <class BITS>
@@ -72,10 +94,14 @@ GD_FN pt ml_scalarmul_u(const pt &b, const fe &x1, const BITS &bits) {
             w <<= 1;
             const bool sw = swap != k_t;
             swap = k_t;
+#if defined(GD_ML_FULL_SWAP)
             fe a2 = fe_select(x2, x3, sw), a3 = fe_select(x3, x2, sw);
             fe c2 = fe_select(z2, z3, sw), c3 = fe_select(z3, z2, sw);
             ml_step(a2, c2, a3, c3, x1);
             x2 = a2; z2 = c2; x3 = a3; z3 = c3;
+#else
+            ml_step_sel(x2, z2, x3, z3, x1, sw);
+#endif
         }
     }
     // (X1 : Z1) = u(sP), (X2 : Z2) = u((s+1)P)

@@ -237,15 +237,20 @@ __device__ __forceinline__ void point_dual_scalarmul_ladder_body(uint64_t *out1,
         ch.push(workspace + (size_t)ML_SLOT_U4 * i, ml_denominator(pt_load_abi(base + 32 * (size_t)i)), live);
     });
     ch.invert();
+    // ONE copy of the ladder, walked twice (a loop the compiler may not unroll): two inlined copies keep the first
+    // result and both recoveries' temporaries alive across each other -- 1 321 spilled registers, profiles/r03 --
+    // where the single ladder of k_point_scalarmul_ct spills 77.  The second scalar's product goes first: out1 may
+    // alias base, which is read again at the top of each round.
     for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
-        const pt b = pt_load_abi(base + 32 * (size_t)i);
-        const fe u = fe_mul(fe_add(b.y, b.z), ch.pop(workspace + (size_t)ML_SLOT_U4 * i));
-        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s1 + 7 * (size_t)i)));
-        const pt r1 = ml_scalarmul_u(b, u, bits);
-        bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s2 + 7 * (size_t)i)));
-        const pt r2 = ml_scalarmul_u(b, u, bits);
-        pt_store_abi(out1 + 32 * (size_t)i, r1);
-        pt_store_abi(out2 + 32 * (size_t)i, r2);
+        const fe di = ch.pop(workspace + (size_t)ML_SLOT_U4 * i);
+#pragma unroll 1
+        for (int which = 1; which >= 0; which--) {
+            const pt b = pt_load_abi(base + 32 * (size_t)i);
+            const uint64_t *k = (which ? s2 : s1) + 7 * (size_t)i;
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(k)));
+            const pt r = ml_scalarmul(b, di, bits);
+            pt_store_abi((which ? out2 : out1) + 32 * (size_t)i, r);
+        }
     });
     lds_wipe_lane(s_bits + threadIdx.x, 15);
 }
@@ -265,17 +270,20 @@ __device__ __forceinline__ void double_scalarmul_ladder_body(uint64_t *out, cons
         ch.push(slot + ML_SLOT_U4, ml_denominator(pt_load_abi(b2 + 32 * (size_t)i)), live);
     });
     ch.invert();
+    // one copy of the ladder, walked twice (see point_dual_scalarmul_ladder_body): s2*b2 first -- its chain slot is
+    // the one pushed last -- parked in out[i] (which may alias b2[i], read before), then s1*b1 and the addition.
     for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
         const uint4 *slot = workspace + (size_t)(2 * ML_SLOT_U4) * i;
-        const pt q = pt_load_abi(b2 + 32 * (size_t)i);           // popped in the reverse order of the pushes
-        const fe uq = fe_mul(fe_add(q.y, q.z), ch.pop(slot + ML_SLOT_U4));
-        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s2 + 7 * (size_t)i)));
-        const pt rq = ml_scalarmul_u(q, uq, bits);
-        const pt p = pt_load_abi(b1 + 32 * (size_t)i);
-        const fe up = fe_mul(fe_add(p.y, p.z), ch.pop(slot));
-        bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(s1 + 7 * (size_t)i)));
-        const pt rp = ml_scalarmul_u(p, up, bits);
-        pt_store_abi(out + 32 * (size_t)i, pt_add(rp, rq, false));
+#pragma unroll 1
+        for (int which = 1; which >= 0; which--) {
+            const pt b = pt_load_abi((which ? b2 : b1) + 32 * (size_t)i);
+            const fe di = ch.pop(slot + which * ML_SLOT_U4);
+            const uint64_t *k = (which ? s2 : s1) + 7 * (size_t)i;
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(k)));
+            pt r = ml_scalarmul(b, di, bits);
+            if (!which) r = pt_add(r, pt_load_abi(out + 32 * (size_t)i), false);
+            pt_store_abi(out + 32 * (size_t)i, r);
+        }
     });
     lds_wipe_lane(s_bits + threadIdx.x, 15);
 }

@@ -220,17 +220,19 @@ struct WaveTable {
     uint32_t *t;   // this wave's table in LDS
     __device__ __forceinline__ void store(const Lane &L, int k, wfe ev) const { t[k * 64 + (threadIdx.x & 63u)] = ev; }
     __device__ __forceinline__ wfe load(const Lane &L, int k) const { return t[k * 64 + (threadIdx.x & 63u)]; }
-    // entry idx with rows a / b exchanged when neg: every entry is read, one is kept
+    // entry idx with rows a / b exchanged when neg: every entry is read, one is kept.  The digit may be secret: a lane
+    // reads its OWN row whatever the sign (no address depends on the digit, tools/isa_audit.py) and the exchange of rows
+    // 0 and 1 is a register move between lanes (ds_bpermute_b32) kept by a select.
     __device__ __forceinline__ wfe lookup(const Lane &L, uint32_t idx, bool neg) const {
-        const uint32_t frow = (neg && L.row < 2) ? (L.row ^ 1u) : L.row;
-        const uint32_t *q = t + frow * 16 + L.i;
+        const uint32_t *q = t + L.row * 16 + L.i;
         wfe r = q[0];
 #pragma unroll
         for (int k = 1; k < 16; k++) {
             const wfe v = q[k * 64];
             r = idx == (uint32_t)k ? v : r;
         }
-        return r;
+        const wfe exchanged = rows(L, r, L.row < 2 ? (L.row ^ 1u) : L.row);
+        return neg ? exchanged : r;
     }
 };
 
@@ -581,14 +583,16 @@ __device__ __forceinline__ wfe comb_scalarmul(const Lane &L, const uint4 *comb, 
             uint32_t idx;
             bool neg;
             signed_digit(comb_teeth(bits, i, j), idx, neg);
-            const uint32_t frow = (neg && L.row < 2) ? (L.row ^ 1u) : L.row;
-            const uint32_t *q = tab + 48 * 16 * j + (frow < 3 ? frow : 0u) * 16 + L.i;
+            // (a lane reads its own row whatever the digit's sign; rows a / b are exchanged between lanes afterwards)
+            const uint32_t *q = tab + 48 * 16 * j + (L.row < 3 ? L.row : 0u) * 16 + L.i;
             wfe r = q[0];
 #pragma unroll
             for (int k = 1; k < 16; k++) {
                 const wfe v = q[48 * k];
                 r = idx == (uint32_t)k ? v : r;
             }
+            const wfe exchanged = rows(L, r, L.row < 2 ? (L.row ^ 1u) : L.row);
+            r = neg ? exchanged : r;
             const wfe ev = L.row == 3 ? (L.i == 0 ? 1u : 0u) : r;       // affine entries: z = 1
             acc = add_entry(L, acc, ev, neg, swap_row);
         }

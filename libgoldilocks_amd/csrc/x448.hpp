@@ -25,16 +25,17 @@ GD_FN void x448_ladder(fe &rx, fe &rz, const uint32_t base[14], const BITS &bits
         if (t == 447) bit = 1;       // top bit forced
         const bool k_t = bit != 0;
         const bool sw = swap != k_t;
-        fe a2 = fe_select(x2, x3, sw), a3 = fe_select(x3, x2, sw);
-        fe c2 = fe_select(z2, z3, sw), c3 = fe_select(z3, z2, sw);
         swap = k_t;
-        fe t1 = fe_add(a2, c2);                         // A = x2 + z2            mag 2
-        fe t2 = fe_weak(fe_sub<2>(a2, c2));             // B = x2 - z2            mag 1
-        fe d = fe_sub<2>(a3, c3);                       // D = x3 - z3            mag 3 (only multiplied by mag 2)
-        fe da = fe_mul(t1, d);                          // DA
-        fe c = fe_add(c3, a3);                          // C = x3 + z3            mag 2
-        fe cb = fe_mul(c, t2);                          // CB
-        fe dm = fe_weak(fe_sub<2>(da, cb));             // DA - CB                mag 1
+        // Exchanging the two pairs exchanges DA and CB: DA + CB and (DA - CB)^2 do not depend on the swap, only the
+        // pair that is doubled is selected -- one sum and one (unreduced) difference, 32 selects per step, not 64
+        // (montgomery.hpp ml_step_sel).
+        const fe s2 = fe_add(x2, z2), s3 = fe_add(x3, z3);          // mag 2
+        const fe d2 = fe_sub<2>(x2, z2), d3 = fe_sub<2>(x3, z3);    // mag 3 (only multiplied by mag 2)
+        fe da = fe_mul(s2, d3);                         // DA (or CB: the same pair)
+        fe cb = fe_mul(s3, d2);
+        fe t1 = fe_select(s2, s3, sw);                  // A = x2 + z2 of the pair to double      mag 2
+        fe t2 = fe_weak(fe_select(d2, d3, sw));         // B = x2 - z2                            mag 1
+        fe dm = fe_weak(fe_sub<2>(da, cb));             // +-(DA - CB)            mag 1
         z3 = fe_mul(x1, fe_sqr(dm));                    // z3 = x1 (DA-CB)^2
         x3 = fe_sqr(fe_add(da, cb));                    // x3 = (DA+CB)^2   (input mag 2)
         fe aa = fe_sqr(t1);                             // AA   (input mag 2)

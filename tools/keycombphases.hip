@@ -9,6 +9,12 @@
 // does the same for k_ed448_verify).
 //
 //   hipcc -std=c++17 -O3 --offload-arch=gfx950 -Ilibgoldilocks_amd/csrc -o tools/keycombphases tools/keycombphases.hip
+// Diagnostic builds (round 4, profiles/r04/experiments.md):
+//   -DKC_TEETH=8   the 4 x 8 x 14 comb of keys with hundreds of signatures (default 7: 4 x 7 x 16)
+//   -DKC_MODE=1    every lane of a wave reads the SAME entry (lane 0's): what the gathers' divergence costs
+//   -DKC_MODE=2    the block's key's comb staged in LDS (7 teeth, 52-word stride), re-staged every round
+//   -DKC_XCD=1     a block's positions follow its XCD (blocks b, b+8, ... of one XCD take neighbouring positions, so
+//                  that one key's comb is fetched into one L2 instead of four)
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
@@ -28,10 +34,55 @@ using namespace gd;
         }                                                              \
     } while (0)
 
+#ifndef KC_TEETH
+#define KC_TEETH 7
+#endif
+#ifndef KC_MODE
+#define KC_MODE 0
+#endif
+#ifndef KC_XCD
+#define KC_XCD 0
+#endif
+#if KC_TEETH == 8
+using kc_plan = comb_wide;
+#else
+using kc_plan = comb_big;
+#endif
+static_assert(KC_MODE != 2 || KC_TEETH == 7, "only the 48-KiB comb fits LDS twice per CU");
 constexpr int NPH = 7;
-static const char *PHASE[NPH] = {"hash + scalar decoding", "the key's comb: 15 doublings + 63 adds", "28 base-point adds",
+static const char *PHASE[NPH] = {"hash + scalar decoding", "the key's comb: doublings + adds", "28 base-point adds",
                                  "R's test (L, K, L^2 v == K^2 u)", "park + chain", "the lane's inversion", "second pass"};
-static const double MACS[NPH] = {0, 15 * 1312.0 + 63 * 1344 + 576, 28 * 1344.0, 3 * 136 + 8 * 192.0 + 16, 192, 63616.0 / 8, 3 * 192};
+static const double MACS[NPH] = {0, (kc_plan::SPACING - 1) * 1312.0 + (kc_plan::SPACING * kc_plan::COMBS - 1) * 1344 + 576, 28 * 1344.0,
+                                 3 * 136 + 8 * 192.0 + 16, 192, 63616.0 / 8, 3 * 192};
+
+// KC_MODE 1: lane 0's entry for the whole wave
+struct UniformComb {
+    using plan = kc_plan;
+    const uint4 *p;
+    __device__ __forceinline__ niels load(int j, uint32_t idx) const {
+        const uint32_t u = (uint32_t)__builtin_amdgcn_readfirstlane((int)idx);
+        const uint4 *q = p + 12 * (plan::PER_COMB * j + u);
+        niels e;
+        e.a = fe_load(q);
+        e.b = fe_load(q + 4);
+        e.cn = fe_load(q + 8);
+        return e;
+    }
+};
+// KC_MODE 2: the comb in LDS, one entry every KC_LDS_STRIDE uint4 (13: 52 words, so that the entries spread over all banks)
+constexpr int KC_LDS_STRIDE = 13;
+struct LdsKeyComb {
+    using plan = kc_plan;
+    const uint4 *s;
+    __device__ __forceinline__ niels load(int j, uint32_t idx) const {
+        const uint4 *q = s + KC_LDS_STRIDE * (plan::PER_COMB * j + idx);
+        niels e;
+        e.a = fe_load(q);
+        e.b = fe_load(q + 4);
+        e.cn = fe_load(q + 8);
+        return e;
+    }
+};
 
 __device__ __forceinline__ uint64_t now() { return __builtin_readcyclecounter(); }
 
@@ -40,6 +91,9 @@ k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const ui
          const uint8_t *__restrict__ msgs, uint32_t msg_len, uint32_t n, const uint4 *__restrict__ bwt,
          const uint4 *__restrict__ combs, uint4 *__restrict__ park, unsigned long long *__restrict__ totals) {
     __shared__ uint32_t s_bits[16 * BLOCK];
+#if KC_MODE == 2
+    __shared__ uint4 s_comb[KC_LDS_STRIDE * kc_plan::ENTRIES];
+#endif
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> fb{bwt_tab};
     LdsStage stage{s_bits + threadIdx.x};
@@ -50,17 +104,39 @@ k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const ui
 #define MARK(k) t1 = now(); acc[k] += t1 - t0; t0 = t1
     InvChain ch;
     ch.begin();
-    for_each_op<true>(n, [&](uint32_t i, bool live) GD_LAMBDA_INLINE {
+#if KC_XCD
+    // blocks are dealt to the 8 XCDs round robin: block b of XCD b % 8 takes virtual block (b % 8) * (grid / 8) + b / 8
+    const uint32_t vblock = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+#else
+    const uint32_t vblock = blockIdx.x;
+#endif
+    const uint32_t stride_all = gridDim.x * BLOCK, rounds_all = (n + stride_all - 1) / stride_all;
+    for (uint32_t round = 0; round < rounds_all; round++) {
+        const uint32_t pos = vblock * BLOCK + threadIdx.x + round * stride_all;
+        const bool live = pos < n;
+        const uint32_t i = live ? pos : n - 1;
         t0 = now();
         const Ed448Msg m = ed448_challenge_string(sig + 114 * (size_t)i, pk + 57 * (size_t)i, msgs + (size_t)msg_len * i,
                                                   msg_len, 0, nullptr, 0);
-        const GlobalCombBig comb{combs + (size_t)KEY_COMB_U4 * ((i >> 10) & 1023u)};
+        const uint4 *key_comb = combs + (size_t)kc_plan::ENTRIES * 12 * ((i >> 10) & 1023u);
+#if KC_MODE == 0
+        const GlobalCombOf<kc_plan> comb{key_comb};
+#elif KC_MODE == 1
+        const UniformComb comb{key_comb};
+#else
+        __syncthreads();   // (the block's 256 positions are one key's: 1 024 signatures per key, blocks aligned)
+        for (uint32_t e = threadIdx.x; e < (uint32_t)kc_plan::ENTRIES; e += BLOCK)
+#pragma unroll
+            for (int k = 0; k < 12; k++) s_comb[KC_LDS_STRIDE * e + k] = key_comb[12 * e + k];
+        __syncthreads();
+        const LdsKeyComb comb{s_comb};
+#endif
         uint32_t w[29];
         shake256_114(w, m, m.total(), stage);
         const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));
         load_bytes_as_words(w, m.a + 57, 57, 15);
         const sc response = sc_decode_long_words<57>(w);
-        auto bits = mkbits(comb_big::recode(challenge), 0);
+        auto bits = mkbits(kc_plan::recode(challenge), 0);
         MARK(0);
         pt P = ladder_comb(bits, comb);
         MARK(1);
@@ -91,16 +167,18 @@ k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const ui
         }
         ch.push(slot, K, live);
         MARK(4);
-    });
+    }
     t0 = now();
     ch.invert();
     MARK(5);
-    for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
+    for (uint32_t round = rounds_all; round-- > 0;) {
+        const uint32_t i = vblock * BLOCK + threadIdx.x + round * stride_all;
+        if (i >= n) continue;
         const uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * i;
         const fe inv_k = ch.pop(slot);
         const uint4 flags = slot[12];
         status[i] = flags.x && (fe_lobit(fe_mul(fe_load(slot + 8), inv_k)) == (flags.y != 0)) ? -1 : 0;
-    });
+    }
     MARK(6);
     for (int k = 0; k < NPH; k++) atomicAdd(totals + k, (unsigned long long)acc[k]);
 }
@@ -114,7 +192,7 @@ int main() {
     int32_t *status;
     uint4 *bwt, *combs, *park;
     unsigned long long *totals;
-    const size_t bwt_bytes = (size_t)BWT_ENTRIES * 12 * sizeof(uint4), comb_bytes = (size_t)nkeys * KEY_COMB_U4 * sizeof(uint4);
+    const size_t bwt_bytes = (size_t)BWT_ENTRIES * 12 * sizeof(uint4), comb_bytes = (size_t)nkeys * kc_plan::ENTRIES * 12 * sizeof(uint4);
     CHECK(hipMalloc(&sig, 114 * (size_t)n));
     CHECK(hipMalloc(&pk, 57 * (size_t)n));
     CHECK(hipMalloc(&msg, msg_len * (size_t)n));
@@ -157,7 +235,7 @@ int main() {
         CHECK(hipMemcpy(t, totals, sizeof(t), hipMemcpyDeviceToHost));
         double sum = 0;
         for (int k = 0; k < NPH; k++) sum += (double)t[k];
-        printf("run %d: %.3f ms per 2^20 (instrumented)\n", rep, ms);
+        printf("run %d: %.3f ms per 2^20 (instrumented; teeth %d, mode %d, xcd %d)\n", rep, ms, KC_TEETH, KC_MODE, KC_XCD);
         if (rep < 2) continue;
         printf("%-42s %8s %12s %10s %14s\n", "phase", "share", "ms of total", "MACs", "clocks / MAC");
         for (int k = 0; k < NPH; k++) {
