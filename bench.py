@@ -362,7 +362,25 @@ def end_to_end(cx, reps=5):
         "verify": (lambda: L.goldilocks_ed448_verify_batch(ptr(st), ptr(v["sig"]), ptr(v["pk"]), ptr(mptr), ptr(mlen), 0,
                                                            None, 0, n), 207, "goldilocks_ed448_verify_batch"),
     }
-    res = {}
+    # the link, measured here and now: 256 MiB from / to pageable host memory, the kind of memory the calls below get
+    # (best of three; tests/h2d_probe.py has the pinned figures beside them)
+    torch = cx.torch
+    probe_h = torch.from_numpy(np.ones(1 << 28, dtype=np.uint8))
+    probe_d = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")
+    link = {}
+    for direction, (dst, src) in (("h2d", (probe_d, probe_h)), ("d2h", (probe_h, probe_d))):
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            dst.copy_(src)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None or dt < best else best
+        link[direction] = (1 << 28) / best / 1e9
+    del probe_h, probe_d
+    io_bytes = {"varbase": (312, 256), "fixed": (56, 256), "verify": (203 + 8, 4)}   # (in, out) per operation; verify: + the 8-byte offset
+    res = {"link_gbs": {k: round(v, 1) for k, v in link.items()}}
     for name, (call, nbytes, what) in calls.items():
         if call():
             raise RuntimeError(L.goldilocks_amd_last_error().decode())
@@ -374,9 +392,13 @@ def end_to_end(cx, reps=5):
             if rc:
                 raise RuntimeError(L.goldilocks_amd_last_error().decode())
         t = sorted(times)[len(times) // 2]
+        b_in, b_out = io_bytes[name]
+        # the link is full duplex: the busier direction bounds the call.  pcie_frac near 1: the call is PCIe-bound
+        # and no kernel can help it; well below: the device (or the host's packing) is the bound.
+        frac = max(b_in * n / t / 1e9 / link["h2d"], b_out * n / t / 1e9 / link["d2h"])
         res[name] = {"value": n / t, "unit": WORKLOADS[name]["unit"], "ms_per_call": t * 1e3, "entry_point": what,
-                     "pcie_bytes_per_op": nbytes, "host_memory": "pageable", "reps": reps,
-                     "ms_every_call": [round(x * 1e3, 2) for x in times]}
+                     "pcie_bytes_per_op": nbytes, "pcie_bytes_in_out": [b_in, b_out], "pcie_frac": frac,
+                     "host_memory": "pageable", "reps": reps, "ms_every_call": [round(x * 1e3, 2) for x in times]}
     ok = bool(((st == -1) == ~v["bad"]).all())
     res["verify"]["check"] = "accepted lanes == uncorrupted lanes" if ok else "FAILED"
     return res, ok
@@ -513,11 +535,29 @@ def time_workload(torch, shard, w, steps, warmup, dist, backend):
     return mine, worst, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
 
+def kernel_source_sha16():
+    """the kernels' sources of THIS tree (tools/summarize_prof.py stamps the same digest on the counters it condenses)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "libgoldilocks_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(kernel):
+    """HBM bytes per launch from the PMC passes of tools/profile_round.sh (profiles/pmc_traffic.json) -- a measurement of
+    another run, so it says which kernels it was taken on: the figure is only reported as `traffic` when the kernels'
+    sources are still the ones it was measured on; otherwise traffic is null and the stale figure goes to traffic_stale."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(path):
-        return json.load(open(path)).get(kernel)
-    return None
+    if not os.path.exists(path):
+        return None, None
+    d = json.load(open(path))
+    stamp = d.get("_measured_on") or {}
+    current = stamp.get("kernel_source_sha16") == kernel_source_sha16()
+    info = dict(stamp, current=current, file="profiles/pmc_traffic.json")
+    return d.get(kernel), info
 
 
 def roofline(name, kernel, n, avg_ms, table_access):
@@ -527,9 +567,15 @@ def roofline(name, kernel, n, avg_ms, table_access):
     if n < spec.get("recomb_min", 0):
         spec["macs"] = spec["macs_reference_comb"]
     achieved = spec["bytes"] * n / (avg_ms * 1e-3) / 1e9
+    traffic, measured_on = pmc_traffic(kernel)
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-         "traffic": pmc_traffic(kernel), "kernel": kernel, "kernel_ms_avg": avg_ms, "bytes_per_op": spec["bytes"],
+         "traffic": traffic if measured_on and measured_on["current"] else None, "kernel": kernel, "kernel_ms_avg": avg_ms,
+         "bytes_per_op": spec["bytes"],
          "note": "integer-multiply bound by construction (SURVEY 8d); the ceiling that matters is mac"}
+    if measured_on:
+        r["traffic_measured_on"] = measured_on
+        if not measured_on["current"]:
+            r["traffic_stale"] = traffic
     if spec["macs"]:
         macs = spec["macs"] * n / (avg_ms * 1e-3)
         r["mac"] = {"achieved": macs / 1e12, "peak": VALU_MAC_PEAK / 1e12, "unit": "T MAC/s",
@@ -540,17 +586,22 @@ def roofline(name, kernel, n, avg_ms, table_access):
 def run_stub(args, shard, rank, world):
     """Launcher / process-group / timing path without a GPU (tests/test_bench_launcher.py)."""
     dist, backend = shard.init_group(world, rank, 0, use_gpu=False)
-    n = 1 << args.log2_batch
+    if args.global_log2_batch is not None:      # BASELINE config 5's form: contiguous slices of one global batch
+        lo, hi = shard.shard_range(1 << args.global_log2_batch, rank, world)
+        n, scaling = hi - lo, "strong"
+    else:
+        n, scaling, lo = 1 << args.log2_batch, "weak", 0
     step = lambda: time.sleep(args.stub_step_ms * 1e-3 * (1 + rank))
     mine, worst = shard.timed_region(step, args.steps, args.warmup, lambda: None, dist, backend)
-    rows = shard.gather_over_ranks([rank, -1, n * args.steps / mine, mine / args.steps * 1e3], dist, backend)
+    rows = shard.gather_over_ranks([rank, -1, n * args.steps / mine, mine / args.steps * 1e3, n, lo], dist, backend)
     if rank == 0:
         print(json.dumps({
-            "metric": "stub steps", "value": n * args.steps * world / worst, "unit": "ops/s", "n_gpus": world,
+            "metric": "stub steps", "value": sum(int(r[4]) for r in rows) * args.steps / worst, "unit": "ops/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": worst / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "stub",
-            "config": {"workload": "stub", "backend": backend},
-            "per_gpu": [{"rank": int(r[0]), "device": int(r[1]), "value": r[2], "ms_per_step": r[3]} for r in rows]}),
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "none", "data": "stub",
+            "config": {"workload": "stub", "backend": backend, "control_plane": backend},
+            "per_gpu": [dict({"rank": int(r[0]), "device": int(r[1]), "value": r[2], "ms_per_step": r[3], "batch": int(r[4])},
+                             **({"slice": [int(r[5]), int(r[5]) + int(r[4])]} if scaling == "strong" else {})) for r in rows]}),
             flush=True)
     if dist is not None:
         dist.barrier()
@@ -587,14 +638,14 @@ def run_rank(args):
         lo, hi = shard.shard_range(1 << args.global_log2_batch, rank, world)
         n, scaling = hi - lo, "strong"
     else:
-        n, scaling = 1 << args.log2_batch, "weak"
+        n, scaling, lo = 1 << args.log2_batch, "weak", 0
     name = args.workload
     spec = WORKLOADS[name]
     cx = Ctx(ga, np, torch, n, rank)
     w = make_workload(name, cx, args.table_access)
     mine, worst, kernel_ms = time_workload(torch, shard, w, args.steps, args.warmup, dist, backend)
     avg_ms = sum(kernel_ms) / len(kernel_ms)
-    rows = shard.gather_over_ranks([rank, device, n * args.steps / mine, avg_ms, n], dist, backend)
+    rows = shard.gather_over_ranks([rank, device, n * args.steps / mine, avg_ms, n, lo], dist, backend)
     ok, check, extra = w["check"]() if rank == 0 else (True, "n/a", {})
     default_line = rank == 0 and world == 1 and name == "varbase" and args.table_access == "index-independent" \
         and args.global_log2_batch is None
@@ -615,8 +666,9 @@ def run_rank(args):
                                    + ", no data-path collective", "control_plane": backend or "single process",
                        "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],
                        "parity_spot_check": "ok" if ok else "FAILED", "check": check},
-            "per_gpu": [{"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
-                         "kernel_ms_avg": r[3], "batch": int(r[4])} for r in rows],
+            "per_gpu": [dict({"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
+                              "kernel_ms_avg": r[3], "batch": int(r[4])},
+                             **({"slice": [int(r[5]), int(r[5]) + int(r[4])]} if scaling == "strong" else {})) for r in rows],
             "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access),
         }
         line.update(extra)
@@ -635,7 +687,7 @@ def run_rank(args):
             r = roofline(cname, cw["kernel"], n, cavg, access)
             configs[key] = {"value": n * csteps / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
                             "table_access": access, "steps": csteps, "warmup": cwarm, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
-                            "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit")},
+                            "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit", "traffic_measured_on", "traffic_stale") if k in r},
                             "mac_frac": r["mac"]["frac"] if "mac" in r else None, "check": ctext,
                             "parity_spot_check": "ok" if cok else "FAILED"}
             ok = ok and cok

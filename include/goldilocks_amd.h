@@ -310,11 +310,19 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  *       built-in table): a signed comb of the base point staged in LDS (4 combs x 7 teeth x spacing 16,
  *       the structure of the reference's 5x5x18 with fewer additions), every lookup a
  *       wavefront-shuffle gather whose addresses and timing do not depend on the digit;
- *     - goldilocks_448_point_scalarmul: NO table -- a Montgomery ladder on the Montgomery model of the
- *       curve with selects only, then the other coordinate is recovered (csrc/montgomery.hpp);
- *     - the other variable-base multiplications (direct_scalarmul, double_scalarmul, dual_scalarmul):
- *       4-bit signed windows, every lookup reads all 8 entries of the lane's table and keeps the wanted
- *       one with a select.
+ *     - every variable-base multiplication (goldilocks_448_point_scalarmul, direct_scalarmul,
+ *       point_double_scalarmul, point_dual_scalarmul): NO table -- a Montgomery ladder on the Montgomery
+ *       model of the curve with selects only, then the other coordinate is recovered
+ *       (csrc/montgomery.hpp; double_ and dual_scalarmul run two such ladders).  RESULT CONTRACT: this
+ *       mode computes (s mod q) * P, the reference's recoding (s + m q) * P for an m of its own
+ *       (src/goldilocks.c:420-438); on the points the API produces (the subgroup 2E) the two agree up to the
+ *       2-torsion point (0, -1), i.e. results are defined up to goldilocks_448_point_eq and the encodings
+ *       (which is what the reference's own backends guarantee about raw limbs too), not as raw limbs; the
+ *       identity and (0, -1) as base or result come back as the identity's limbs.
+ *     - batches small enough for one operation per wavefront read all 16 entries of an LDS window table for
+ *       every digit and keep one by select.
+ *     tools/isa_audit.py checks the compiled gfx950 code of every kernel of this mode: no branch
+ *     condition and no memory address depends on the scalar (tests/test_isa_audit.py).
  *   GOLDILOCKS_AMD_TABLES_FAST (opt-in, for PUBLIC scalars only)
  *     - each lookup reads only the digit's entry (the address depends on the digit): the base point's
  *       16-bit window table in global memory, 5-bit windows for a variable base.
@@ -370,10 +378,13 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
  * ladder and without R's decoding -- 0.3 of the arithmetic.  Used when the batch averages at least
  * `min_signatures_per_key` signatures per distinct key (twice that for batches below 2^18 signatures, where the fixed
  * latency of building the combs weighs more) and has at most `keys` distinct keys, in batches of more than 2^12
- * signatures (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the combs off, 2^17 is the most
- * (62 KiB of device memory per key the batch may have); turning the pool off
+ * signatures (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the
+ * combs off; 2^17 is the most and the default.  `keys` is a CEILING: a batch can use at most n / min_signatures_per_key
+ * combs, so that is what a call reserves workspace for -- 64 KiB of device memory per such key (2^20 signatures: up to 2^16
+ * keys, 4 GiB), never more than a quarter of the device's free memory, kept until goldilocks_amd_shutdown -- whatever the
+ * batch's keys then turn out to be (the device decides; the call does not wait for it).  Turning the pool off
  * (goldilocks_amd_set_verify_key_pool(0, ..)) turns the combs off with it.  Process-wide. */
-#define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 15)
+#define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 17)
 #define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 16
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t min_signatures_per_key);
 /* ... and keys that sign at least this many signatures of the batch on average get the wider comb (4 x 8 x 14, 96 KiB:

@@ -415,16 +415,35 @@ struct KeycombPending {
     bool sign;        // R's sign bit
     bool decided;     // the slow path ran: ok is final, K is 1
 };
-template <class FB, class COMB, class STAGE, class MKBITS>
-GD_FN KeycombPending ed448_verify_keycomb_begin(const Ed448Msg &m, const FB &fb, const COMB &comb, STAGE &stage, MKBITS &mkbits) {
+// QSRC: S*B may have been computed AHEAD of this call -- it needs nothing but the signature, so a batch's first
+// signatures get theirs from a kernel that runs while the keys' combs are still being built (kernels_verify.hip
+// k_verify_base_part) -- q.have() says so (uniformly for a wave) and q.load() is S*B as a projective niels.
+struct NoParkedBase {
+    GD_MFN bool have() const { return false; }
+    GD_MFN pniels load() const { return pniels(); }
+};
+// S*B for that purpose: what fb.add_to would have added (S = sig[57:114] mod q, no range check)
+template <class FB, class MKBITS>
+GD_FN pniels ed448_verify_base_part(const uint8_t *sig114, const FB &fb, MKBITS &mkbits) {
+    uint32_t w[15];
+    load_bytes_as_words(w, sig114 + 57, 57, 15);
+    return pt_to_pniels(fb.mul(sc_decode_long_words<57>(w), mkbits));
+}
+template <class FB, class COMB, class STAGE, class MKBITS, class QSRC>
+GD_FN KeycombPending ed448_verify_keycomb_begin(const Ed448Msg &m, const FB &fb, const COMB &comb, STAGE &stage, MKBITS &mkbits,
+                                                const QSRC &q) {
     uint32_t w[29];
     shake256_114(w, m, m.total(), stage);
     const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));     // -h mod q
-    load_bytes_as_words(w, m.a + 57, 57, 15);
-    const sc response = sc_decode_long_words<57>(w);                          // S mod q, no range check
     auto bits = mkbits(COMB::plan::recode(challenge), 0);
     pt P = ladder_comb(bits, comb);                                           // -h*A, T included
-    fb.add_to(P, response, mkbits);                                           // + S*B
+    if (q.have()) {
+        pt_add_pniels(P, q.load(), false, true);                              // + S*B, computed ahead
+    } else {
+        load_bytes_as_words(w, m.a + 57, 57, 15);
+        const sc response = sc_decode_long_words<57>(w);                      // S mod q, no range check
+        fb.add_to(P, response, mkbits);                                       // + S*B
+    }
     KeycombPending pend;
     load_bytes_as_words(w, m.a, 57, 15);                                      // R = sig[0:57]: only what the equation needs
     const uint32_t last = w[14] & 0xff;
@@ -453,6 +472,10 @@ GD_FN KeycombPending ed448_verify_keycomb_begin(const Ed448Msg &m, const FB &fb,
     }
     pend.K = K;
     return pend;
+}
+template <class FB, class COMB, class STAGE, class MKBITS>
+GD_FN KeycombPending ed448_verify_keycomb_begin(const Ed448Msg &m, const FB &fb, const COMB &comb, STAGE &stage, MKBITS &mkbits) {
+    return ed448_verify_keycomb_begin(m, fb, comb, stage, mkbits, NoParkedBase());
 }
 GD_FN bool ed448_verify_keycomb_finish(const KeycombPending &pend, const fe &inv_k) {
     return pend.ok && (pend.decided || fe_lobit(fe_mul(pend.L, inv_k)) == pend.sign);

@@ -360,6 +360,13 @@ constexpr int KEY_COMBS_MIN_BATCH = 4096;   // combs are considered from so many
 constexpr int KEY_SORT_BINS = 8192;        // up to so many keys the counting sort goes through per-block bins in LDS
 constexpr int KEY_TEETH_BY_WAVE_MAX = 4096;   // up to so many keys a WAVE computes a key's teeth (latency), beyond a lane (throughput)
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)
+// the launches of one group of key-comb verifications (one shared inversion per lane over all of them): where each
+// launch's positions start, relative to the group's, and how many they are
+constexpr int VERIFY_CHUNKS_MAX = 16;
+struct VerifyChunks {
+    uint32_t count;
+    uint32_t lo[VERIFY_CHUNKS_MAX], m[VERIFY_CHUNKS_MAX];
+};
 template <class PLAN>
 struct GlobalCombOf {
     using plan = PLAN;
@@ -503,27 +510,37 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
                                    const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk);
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain);
-GD_KERNEL k_ed448_verify_keycomb(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
+GD_KERNEL k_ed448_verify_keycomb(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
                                  const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
                                  const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
                                  const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
-                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order);
-GD_KERNEL k_ed448_verify_keycomb_wide(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
+                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order,
+                                 uint4 *__restrict__ chain_state, uint32_t resume,
+                                 const uint4 *__restrict__ qpark, uint32_t q_count);
+GD_KERNEL k_ed448_verify_keycomb_wide(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
                                  const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
                                  const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
                                  const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
-                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order);
+                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order,
+                                 uint4 *__restrict__ chain_state, uint32_t resume,
+                                 const uint4 *__restrict__ qpark, uint32_t q_count);
+GD_KERNEL k_verify_base_part(uint4 *__restrict__ qpark, const uint8_t *__restrict__ sig, const uint32_t *__restrict__ order,
+                             uint32_t q_count, const uint4 *__restrict__ bwt, const uint32_t *__restrict__ ctrl);
+GD_KERNEL k_ed448_verify_keycomb_finish(int32_t *__restrict__ status, const uint32_t *__restrict__ ctrl,
+                                        const uint4 *__restrict__ park, const uint32_t *__restrict__ order,
+                                        const uint4 *__restrict__ chain_state, VerifyChunks chunks);
 GD_KERNEL k_verify_key_count(uint32_t *__restrict__ count, const uint32_t *__restrict__ rep,
                              const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n);
 GD_KERNEL k_verify_key_scan(uint32_t *__restrict__ count, const uint32_t *__restrict__ ctrl);
 GD_KERNEL k_verify_key_scatter(uint32_t *__restrict__ order, uint32_t *__restrict__ count, const uint32_t *__restrict__ rep,
-                               const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n);
+                               const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n,
+                               uint32_t base);
 GD_KERNEL k_ed448_derive_public_key(uint8_t *__restrict__ pk, const uint8_t *__restrict__ sk, uint32_t n,
                                     const uint4 *__restrict__ bwt, uint4 *__restrict__ workspace);
 GD_KERNEL k_ed448_sign(uint8_t *__restrict__ sig, const uint8_t *__restrict__ sk, const uint8_t *__restrict__ pk,

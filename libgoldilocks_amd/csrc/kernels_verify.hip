@@ -157,6 +157,7 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain) {
     constexpr uint32_t SEG = 16;
+    if (!ctrl[2]) return;                           // (ctrl[3] is 0 then: no geometry to derive)
     const uint32_t teeth_per = ctrl[3], NT = 4 * teeth_per, per_comb = 1u << (teeth_per - 1), entries = 4 * per_comb,
                    per_key = entries / SEG;
     const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK, total = combed * per_key;
@@ -247,14 +248,16 @@ GD_KERNEL k_verify_key_scan(uint32_t *__restrict__ count, const uint32_t *__rest
 }
 // order[position] = signature: a block counts its signatures per key, reserves that many positions per key with one
 // atomic on the key's cursor (count[k], left by the scan), and hands them out from LDS
+// (base: what the signature indices written to `order` start at -- `rep` points at the chunk's first signature)
 GD_KERNEL k_verify_key_scatter(uint32_t *__restrict__ order, uint32_t *__restrict__ count, const uint32_t *__restrict__ rep,
-                               const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n) {
+                               const uint32_t *__restrict__ slot_of, const uint32_t *__restrict__ ctrl, uint32_t n,
+                               uint32_t base) {
     __shared__ uint32_t s_bin[KEY_SORT_BINS], s_base[KEY_SORT_BINS];
     const uint32_t keys = ctrl[2];
     if (!keys) return;
     const uint32_t stride = gridDim.x * BLOCK;
     if (keys > (uint32_t)KEY_SORT_BINS) {
-        for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) order[atomicAdd(count + slot_of[rep[i]], 1u)] = i;
+        for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) order[atomicAdd(count + slot_of[rep[i]], 1u)] = base + i;
         return;
     }
     for (uint32_t k = threadIdx.x; k < keys; k += BLOCK) s_bin[k] = 0;
@@ -268,31 +271,72 @@ GD_KERNEL k_verify_key_scatter(uint32_t *__restrict__ order, uint32_t *__restric
     __syncthreads();
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
         const uint32_t k = slot_of[rep[i]];
-        order[s_base[k] + atomicAdd(s_bin + k, 1u)] = i;
+        order[s_base[k] + atomicAdd(s_bin + k, 1u)] = base + i;
     }
 }
-// park: KEYCOMB_SLOT_U4 uint4 per position of the launch (K | the chain's prefix | L | flags); at most
-// SHARED_INV_OPS_PER_LANE positions per resident lane per launch (the host splits larger batches: n positions of
-// `order`, which indexes the whole batch's arrays)
+// ---- the verification itself, in two kernels around the lanes' shared inversions.
+// A lane's positions t (entries of `order`, i.e. signatures in the order of their keys) are verified up to the sign test
+// of R's x = L / K by k_ed448_verify_keycomb(_wide) -- the FIRST pass: it parks K, the running product before it, L and
+// the flags (KEYCOMB_SLOT_U4 uint4 per position) and leaves the lane's running product in chain_state -- and
+// k_ed448_verify_keycomb_finish inverts once per lane and walks the positions back.  Because the running product lives
+// in memory between the two, the first pass may come in SEVERAL launches (`resume`): the host-array pipeline verifies a
+// batch chunk by chunk as the chunks arrive over PCIe and still shares one inversion between all the positions of a
+// lane (goldilocks_amd.hip verify_group); a group of launches covers at most SHARED_INV_OPS_PER_LANE positions per
+// resident lane, which bounds the parking space.  All launches of a group use the same grid.
+// Positions follow the block's XCD: the hardware deals blocks to the 8 XCDs round robin, so blocks b, b + 8, ... share
+// an L2; giving them neighbouring positions -- one key's signatures -- lets one L2 fetch a key's comb instead of four.
+__device__ __forceinline__ uint32_t xcd_block() {
+    const uint32_t g = gridDim.x;
+    return (g & 7u) ? blockIdx.x : (blockIdx.x & 7u) * (g >> 3) + (blockIdx.x >> 3);
+}
+// S*B of the first q_count positions of a launch, AHEAD of it: S*B needs the signature alone, so it can run -- at one
+// block per CU, leaving every CU room for the keys' kernels -- while the combs are being built (the teeth are a chain
+// of 432 doublings per key: latency, on a nearly idle device), which takes it out of the verification's first rounds.
+// qpark: 16 uint4 per position (a projective niels).
+GD_KERNEL k_verify_base_part(uint4 *__restrict__ qpark, const uint8_t *__restrict__ sig, const uint32_t *__restrict__ order,
+                             uint32_t q_count, const uint4 *__restrict__ bwt, const uint32_t *__restrict__ ctrl) {
+    __shared__ uint32_t s_bits[16 * BLOCK];
+    if (!ctrl[2]) return;                           // no combs, no key-comb verification
+    GlobalBwt bwt_tab{bwt};
+    FixedBwt<GlobalBwt> b_tab{bwt_tab};
+    LdsMkBitsVerify mk{s_bits + threadIdx.x};
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < q_count; t += stride)
+        pniels_store(qpark + 16 * (size_t)t, ed448_verify_base_part(sig + 114 * (size_t)order[t], b_tab, mk));
+}
+struct ParkedBase {      // S*B of this position from k_verify_base_part, if its round has it
+    const uint4 *slot;
+    bool parked;
+    __device__ __forceinline__ bool have() const { return parked; }
+    __device__ __forceinline__ pniels load() const { return pniels_load(slot); }
+};
 template <class PLAN>
-__device__ __forceinline__ void verify_keycomb_body(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,
+__device__ __forceinline__ void verify_keycomb_body(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
                                  const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
                                  const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
                                  const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
-                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order) {
+                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order,
+                                 uint4 *__restrict__ chain_state, uint32_t resume,
+                                 const uint4 *__restrict__ qpark, uint32_t q_count) {
     __shared__ uint32_t s_bits[16 * BLOCK];
     if (ctrl[3] != (uint32_t)PLAN::TEETH) return;   // this batch's keys are served otherwise (k_ed448_verify, or the other comb)
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> b_tab{bwt_tab};
     LdsStage stage{s_bits + threadIdx.x};       // (unused by the word-granular absorb)
     LdsMkBitsVerify mk{s_bits + threadIdx.x};
-    // first pass: everything but the sign test of R's x = L / K, whose inversion the lane's signatures share
+    const uint32_t lane = xcd_block() * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    uint4 *const state = chain_state + 4 * (size_t)lane;
     InvChain ch;
     ch.begin();
-    for_each_op<true>(n, [&](uint32_t t, bool live) GD_LAMBDA_INLINE {   // wave-uniform, as in k_ed448_verify; position t: signature i
+    if (resume) ch.acc = fe_load(state);
+    const uint32_t rounds = (n + stride - 1) / stride;
+    for (uint32_t r = 0; r < rounds; r++) {      // wave-uniform, as in k_ed448_verify; position t: signature i
+        const uint32_t pos = lane + r * stride;
+        const bool live = pos < n;
+        const uint32_t t = live ? pos : n - 1;
         const uint32_t i = order[t];
         const uint8_t *msg = msg_offsets ? msgs + msg_offsets[i] : msgs + (size_t)msg_len * i;
         const uint64_t len64 = msg_offsets ? msg_offsets[i + 1] - msg_offsets[i] : (uint64_t)msg_len;
@@ -301,45 +345,64 @@ __device__ __forceinline__ void verify_keycomb_body(int32_t *__restrict__ status
                                                   fits ? (uint32_t)len64 : 0u, prehashed, ctx, ctx_len);
         const uint32_t k = slot_of[rep[i]];
         const GlobalCombOf<PLAN> comb{combs + (size_t)PLAN::ENTRIES * 12 * k};
-        const KeycombPending pend = ed448_verify_keycomb_begin(m, b_tab, comb, stage, mk);
+        // whole rounds only (q_count is a multiple of the launch's lanes): uniform for the block
+        const ParkedBase q{qpark + 16 * (size_t)t, (r + 1) * stride <= q_count};
+        const KeycombPending pend = ed448_verify_keycomb_begin(m, b_tab, comb, stage, mk, q);
         uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * t;
         if (live) {
             fe_store(slot + 8, pend.L);
             slot[12] = make_uint4(pend.ok && fits && key_ok[k] != 0 ? 1u : 0u, pend.sign ? 1u : 0u, pend.decided ? 1u : 0u, 0u);
         }
         ch.push(slot, pend.K, live);
-    });
-    ch.invert();
-    for_each_op_reverse(n, [&](uint32_t t) {
-        const uint32_t i = order[t];
-        const uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * t;
-        const fe inv_k = ch.pop(slot);
-        const uint4 flags = slot[12];
-        KeycombPending pend;
-        pend.L = fe_load(slot + 8);
-        pend.ok = flags.x != 0;
-        pend.sign = flags.y != 0;
-        pend.decided = flags.z != 0;
-        status[i] = ed448_verify_keycomb_finish(pend, inv_k) ? -1 : 0;
-    });
+    }
+    fe_store(state, ch.acc);
 }
 
 #define KEYCOMB_ARGS                                                                                                      \
-    int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ pk,                        \
+    const uint8_t *__restrict__ sig, const uint8_t *__restrict__ pk,                                                      \
         const uint8_t *__restrict__ msgs, const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed, \
         const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n, const uint4 *__restrict__ bwt,                     \
         const uint32_t *__restrict__ rep, const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,          \
         const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl, uint4 *__restrict__ park,                  \
-        const uint32_t *__restrict__ order
+        const uint32_t *__restrict__ order, uint4 *__restrict__ chain_state, uint32_t resume,                            \
+        const uint4 *__restrict__ qpark, uint32_t q_count
 GD_KERNEL k_ed448_verify_keycomb(KEYCOMB_ARGS) {        // keys with 7 teeth per comb (4 x 7 x 16)
-    verify_keycomb_body<comb_big>(status, sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
-                                  key_ok, ctrl, park, order);
+    verify_keycomb_body<comb_big>(sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
+                                  key_ok, ctrl, park, order, chain_state, resume, qpark, q_count);
 }
 GD_KERNEL k_ed448_verify_keycomb_wide(KEYCOMB_ARGS) {   // keys with 8 (4 x 8 x 14): hundreds of signatures per key
-    verify_keycomb_body<comb_wide>(status, sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
-                                   key_ok, ctrl, park, order);
+    verify_keycomb_body<comb_wide>(sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
+                                   key_ok, ctrl, park, order, chain_state, resume, qpark, q_count);
 }
 #undef KEYCOMB_ARGS
+// the lanes' inversions and the second pass over every launch of the group, last launch first: chunks.lo[c] is where
+// launch c's positions start in `park` / `order` (the pointers its launch was given, relative to the group's)
+GD_KERNEL k_ed448_verify_keycomb_finish(int32_t *__restrict__ status, const uint32_t *__restrict__ ctrl,
+                                        const uint4 *__restrict__ park, const uint32_t *__restrict__ order,
+                                        const uint4 *__restrict__ chain_state, VerifyChunks chunks) {
+    if (!ctrl[2]) return;                           // no combs: k_ed448_verify has written the verdicts
+    const uint32_t lane = xcd_block() * BLOCK + threadIdx.x, stride = gridDim.x * BLOCK;
+    InvChain ch;
+    ch.acc = fe_load(chain_state + 4 * (size_t)lane);
+    ch.invert();
+    for (uint32_t c = chunks.count; c-- > 0;) {
+        const uint32_t lo = chunks.lo[c], n = chunks.m[c];
+        if (lane >= n) continue;
+        for (uint32_t p = lane + (n - 1 - lane) / stride * stride;; p -= stride) {
+            const uint32_t t = lo + p, i = order[t];
+            const uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * t;
+            const fe inv_k = ch.pop(slot);
+            const uint4 flags = slot[12];
+            KeycombPending pend;
+            pend.L = fe_load(slot + 8);
+            pend.ok = flags.x != 0;
+            pend.sign = flags.y != 0;
+            pend.decided = flags.z != 0;
+            status[i] = ed448_verify_keycomb_finish(pend, inv_k) ? -1 : 0;
+            if (p < stride) break;
+        }
+    }
+}
 
 // config 4: status[i] = ed448_verify(sig[i], pk[i], msg[i])   (ref: goldilocks_ed448_verify)
 GD_KERNEL k_ed448_verify(int32_t *__restrict__ status, const uint8_t *__restrict__ sig,

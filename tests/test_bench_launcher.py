@@ -99,3 +99,35 @@ def test_the_launch_deadline_is_a_default():
     t0 = time.time()
     assert shard.launch_ranks(["-c", "import time; time.sleep(60)"], 2, timeout=1.0) == 124
     assert time.time() - t0 < 5.0
+
+
+def test_eight_ranks_as_the_scaling_run_launches_them():
+    """The first real 8-GPU run starts eight ranks: rendezvous on a free port, eight gloo processes, barriers, the MAX
+    over ranks and the all-gather of eight rows -- here with the stub step, in both of the driver's forms: independent
+    batches (weak) and BASELINE config 5's contiguous slices of one global batch (strong)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--stub-step-ms", "5",
+                        "--log2-batch", "12"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _check_line(r.stdout, 8, 5, 2)
+    assert [g["batch"] for g in line["per_gpu"]] == [1 << 12] * 8 and line["config"]["control_plane"] == "gloo"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "8", "--steps", "2", "--warmup", "1", "--stub-step-ms", "5",
+                        "--workload", "verify", "--global-log2-batch", "15"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.strip()][0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong"
+    slices = [g["slice"] for g in line["per_gpu"]]
+    assert slices == [[i << 12, (i + 1) << 12] for i in range(8)]           # disjoint, contiguous, the whole batch
+    assert sum(g["batch"] for g in line["per_gpu"]) == 1 << 15
+
+
+def test_host_feed_probe_runs_without_a_device():
+    """tools/hostfeed: the host side of goldilocks_ed448_verify_batch_ex (csrc/host_pack.hpp, the library's own packing
+    code) for 1 / 2 / 4 / 8 shards with the device calls stubbed -- CPU only; here at a small size, as a smoke test."""
+    src, exe = os.path.join(ROOT, "tools", "hostfeed.cpp"), os.path.join(ROOT, "tools", "hostfeed")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(ROOT, "libgoldilocks_amd", "csrc"), "-o", exe, src],
+                   check=True, timeout=300)
+    r = subprocess.run([exe, "--log2n", "17", "--reps", "1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    rows = [l.split() for l in r.stdout.splitlines() if l.split() and l.split()[0].isdigit()]
+    assert [int(x[0]) for x in rows] == [1, 2, 4, 8] and all(float(x[2]) > 1e5 for x in rows), r.stdout
+    assert "cores usable by this process" in r.stdout

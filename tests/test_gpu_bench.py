@@ -59,9 +59,11 @@ def test_default_line_carries_configs_end_to_end_and_cpu_baseline():
     assert "rejects among them" in line["configs"]["verify"]["check"]
     assert line["configs"]["varbase_fast"]["kernel"] == "k_point_scalarmul"
     assert line["configs"]["base"]["kernel"] == "k_base_scalarmul_ct" and line["configs"]["base_fast"]["kernel"] == "k_base_scalarmul"
-    assert set(line["end_to_end"]) == {"varbase", "fixed", "verify"}
-    for e in line["end_to_end"].values():
-        assert e["value"] > 0 and e["host_memory"] == "pageable"
+    assert set(line["end_to_end"]) == {"varbase", "fixed", "verify", "link_gbs"}
+    assert line["end_to_end"]["link_gbs"]["h2d"] > 1 and line["end_to_end"]["link_gbs"]["d2h"] > 1    # the link, measured in the same run
+    for k, e in line["end_to_end"].items():
+        if k != "link_gbs":
+            assert e["value"] > 0 and e["host_memory"] == "pageable" and 0 < e["pcie_frac"] < 1.5
     assert line["end_to_end"]["varbase"]["value"] < line["value"]        # PCIe-inclusive: never the headline
     cb = line["cpu_baseline"]
     assert set(cb["single_thread_by_build"]) <= {"x86_64_generic", "x86_64_v3", "oracle_port"} and cb["build"] in cb["single_thread_by_build"]
@@ -77,4 +79,19 @@ def test_control_plane_over_rccl_on_one_gpu():
     line, _ = _run(["--steps", "2", "--warmup", "1", "--log2-batch", "14", "--no-cpu-baseline", "--no-configs",
                     "--no-end-to-end"], GOLDILOCKS_BENCH_FORCE_DIST="1")
     assert line["config"]["control_plane"] == "nccl" and line["n_gpus"] == 1
+    assert line["config"]["parity_spot_check"] == "ok"
+
+
+def test_eight_ranks_on_one_device_both_forms():
+    """What the first 8-GPU run does, on this box's one device (ranks map to the visible devices modulo their count):
+    eight self-launched ranks, eight library contexts building their tables at once, one agreed control-plane backend,
+    eight per-GPU rows -- independent batches, then BASELINE config 5's form (verify, one global batch cut into eight
+    disjoint slices)."""
+    line, err = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--log2-batch", "12", "--no-cpu-baseline"])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["parity_spot_check"] == "ok"
+    assert [g["rank"] for g in line["per_gpu"]] == list(range(8)) and all(g["value"] > 0 and g["batch"] == 1 << 12 for g in line["per_gpu"])
+    assert line["config"]["control_plane"] in ("gloo", "nccl")            # ONE backend for all ranks (agreed over gloo)
+    line, _ = _run(["--gpus", "8", "--steps", "2", "--warmup", "1", "--workload", "verify", "--global-log2-batch", "15"])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["unit"] == "verifies/s"
+    assert [g["slice"] for g in line["per_gpu"]] == [[i << 12, (i + 1) << 12] for i in range(8)]
     assert line["config"]["parity_spot_check"] == "ok"

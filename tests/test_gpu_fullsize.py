@@ -196,6 +196,56 @@ def test_host_array_pipeline_matches_fixture_and_ragged_tail(ga, O):
     assert (enc(dout.cpu().numpy().view(np.uint64)) == enc(part)).all() and (enc(part) == enc(out[:n])).all()
 
 
+@pytest.mark.parametrize("keys", ["combs", "pooled", "distinct"])
+def test_host_array_verification_pipeline_in_chunks(ga, O, keys):
+    """goldilocks_ed448_verify_batch from host arrays, 2^19 signatures or more: the keys' preparation once for the batch,
+    the signatures chunk by chunk (2^18) through the first pass of the key-comb verification, ONE shared inversion per
+    lane over the chunks of a group (kernels_verify.hip k_ed448_verify_keycomb_finish), or chunk by chunk through
+    k_ed448_verify.  2^20 + 777 signatures of 2^10 keys are two groups, the second a ragged tail; the other key
+    distributions run 2^19 + 5.  Verdicts: exactly the corrupted lanes fail, lane for lane what the single-launch device
+    entry point says, and a sample (rejects among them) what the oracle says (src/eddsa.c:253-306)."""
+    import torch
+    n = (1 << 20) + 777 if keys == "combs" else (1 << 19) + 5
+    nk = {"combs": 1 << 10, "pooled": n // 4, "distinct": n}[keys]
+    sk = np.frombuffer(_gen.stream(b"pipe/sk/" + keys.encode(), 57 * nk), np.uint8).reshape(nk, 57)
+    which = (np.arange(n) * 2654435761 % nk) if keys != "distinct" else np.arange(n)      # keys in scattered order
+    sk_n = np.ascontiguousarray(sk[which])
+    msg = np.frombuffer(_gen.stream(b"pipe/msg", 24 * 4096), np.uint8).reshape(4096, 24)[np.arange(n) % 4096].copy()
+    msg[:, :4] = np.arange(n, dtype=np.uint32).view(np.uint8).reshape(n, 4)                  # every message distinct
+    pk = ga.ed448_derive_public_key_batch(sk_n)
+    msgs = [m.tobytes() for m in msg]
+    sig = ga.ed448_sign_batch(sk_n, pk, msgs)
+    idx = np.arange(n)
+    bad = (idx % 97) == 5
+    kind = (idx // 97) % 4                                  # corrupt S, R, the key or the message, by turns
+    sig[bad & (kind == 0), 60] ^= 1
+    sig[bad & (kind == 1), 5] ^= 0x20
+    pk[bad & (kind == 2), 9] ^= 4
+    msg[bad & (kind == 3), 23] ^= 0x80
+    msgs = [m.tobytes() for m in msg]
+    st = ga.ed448_verify_batch(sig, pk, msgs)
+    assert ((st == -1) | (st == 0)).all()
+    # (a corrupted key is a key of its own: it may fail to decode or verify, never accept)
+    assert ((st == -1) == ~bad).all(), (int((st == -1).sum()), int((~bad).sum()))
+    counts = ga.last_verify_key_counts()
+    if keys == "combs":
+        assert counts[2] > 0 and counts[1] == 0, counts     # the batch's keys got combs (the corrupted ones too)
+    elif keys == "pooled":
+        assert counts[1] > 0 and counts[2] == 0, counts
+    else:
+        assert counts[1] == 0 and counts[2] == 0, counts
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dst = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    dsig, dpk, dmsg = d(sig), d(pk), d(msg)
+    ga.dev("ed448_verify", dst.data_ptr(), dsig.data_ptr(), dpk.data_ptr(), dmsg.data_ptr(), None, 24, 0, None, 0, n, None)
+    torch.cuda.synchronize()
+    assert (dst.cpu().numpy() == st).all()
+    rng = np.random.default_rng(len(keys))
+    pick = np.unique(np.concatenate([rng.integers(0, n, 150), 97 * rng.integers(0, n // 97, 60) + 5, np.arange(n - 40, n)]))
+    want = _gen.oracle_verify(O, sig[pick], pk[pick], [msgs[i] for i in pick])
+    assert (st[pick] == want).all() and (want == 0).sum() >= 50
+
+
 def test_sharded_host_batches_match_single_device(ga, O):
     """goldilocks_amd_use_devices: the contiguous-slice sharding of the host-array batches (one host
     thread per listed device).  A 1-GPU box lists device 0 three times, so the shards run one after

@@ -28,7 +28,11 @@ def table_mode(request, ga):
 
 
 def enc(ga, pts):
-    return ga.point_encode_batch(pts)
+    """canonical bytes of the GPU's raw points -- by the GPU's own encoder AND by the oracle's (orc_point_encode on the
+    raw limbs): a comparison with the oracle's results never rests on the device encoder alone"""
+    got = ga.point_encode_batch(pts)
+    assert (got == _gen.oracle_encode(pts)).all(), "k_point_encode and the oracle's encoder disagree on the GPU's raw points"
+    return got
 
 
 def test_device_is_gfx950(ga):

@@ -33,15 +33,45 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+def enc(ga, pts):
+    """the GPU's raw points encoded by the device AND by the oracle's orc_point_encode: equal, or the device's encoder
+    is what differs"""
+    got = ga.point_encode_batch(pts)
+    assert (got == _gen.oracle_encode(pts)).all()
+    return got
+
+
+def reference_check(bases, scalars, got_enc, k=64):
+    """a sample of lanes against the REAL reference (oracle/_ref/libgoldilocks_ref64.so, arch_ref64 compiled from
+    /root/reference by oracle/Makefile; it travels to the GPU box with the snapshot): goldilocks_448_point_scalarmul
+    (src/goldilocks.c:405-465) + goldilocks_448_point_encode on the same inputs"""
+    from _libs import Point, Scalar, have_ref, ref
+    if not have_ref():
+        return 0
+    R = ref()
+    pick = np.random.default_rng(7).choice(len(bases), k, replace=False)
+    for i in pick:
+        b, s, out = Point(), Scalar(), Point()
+        C.memmove(C.byref(b), bases[i].ctypes.data, 256)
+        C.memmove(C.byref(s), scalars[i].ctypes.data, 56)
+        R.goldilocks_448_point_scalarmul(C.byref(out), C.byref(b), C.byref(s))
+        e = (C.c_uint8 * 56)()
+        R.goldilocks_448_point_encode(e, C.byref(out))
+        assert bytes(e) == got_enc[i].tobytes(), i
+    return k
+
+
 def test_soak_scalarmuls(ga, O):
     k = _gen.stream_scalars(N, SEED + b"soak/base")
     s = _gen.stream_scalars(N, SEED + b"soak/scalar")
     bases = ga.precomputed_scalarmul_batch(k)                                     # 8-bit window table
-    assert (ga.point_encode_batch(bases) == _gen.oracle_encode(_gen.oracle_fixed(O, k))).all()
+    assert (enc(ga, bases) == _gen.oracle_encode(_gen.oracle_fixed(O, k))).all()
     comb = ga.precomputed_scalarmul_batch(k, table=ga.precomputed_base())         # LDS comb
     assert (ga.point_encode_batch(comb) == ga.point_encode_batch(bases)).all()
     got = ga.point_scalarmul_batch(bases, s)
-    assert (ga.point_encode_batch(got) == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all()
+    got_enc = enc(ga, got)
+    assert (got_enc == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all()
+    reference_check(bases, s, got_enc)
     e57 = ga.point_encode_like_eddsa_batch(got)
     dec, st = ga.point_decode_like_eddsa_batch(e57)
     four = ga.point_scalarmul_batch(got, _gen.scalars_from_ints([4] * N))
@@ -127,7 +157,7 @@ def test_soak_x448_and_elligator(ga, O):
     for i in range(0, n, 5):
         O.orc_point_from_hash_uniform(C.cast(_p(w[i]), C.POINTER(Point)), _p(h[i]))
     sel = np.arange(0, n, 5)
-    assert (ga.point_encode_batch(pts[sel]) == _gen.oracle_encode(w[sel])).all()
+    assert (enc(ga, pts[sel]) == _gen.oracle_encode(w[sel])).all()
 
 
 def test_soak_wave_path(ga, O, table_mode):
@@ -141,7 +171,7 @@ def test_soak_wave_path(ga, O, table_mode):
     s = _gen.stream_scalars(n, SEED + b"soak/wave/scalar")
     bases = _gen.oracle_fixed(O, k)
     got = ga.point_scalarmul_batch(bases, s)
-    assert (ga.point_encode_batch(got) == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all()
+    assert (enc(ga, got) == _gen.oracle_encode(_gen.oracle_varbase(O, bases, s))).all()
     m = n // 2
     sigs, pks, msgs = _gen.signatures(O, m, msglen=33, seed=SEED + b"soak/wave/sig", nkeys=97, context=b"w")
     rng = np.random.default_rng(17)
@@ -179,4 +209,4 @@ def test_soak_wave_path(ga, O, table_mode):
                 O.orc_point_from_hash_uniform(C.cast(_p(w[i]), C.POINTER(Point)), _p(h[i]))
             else:
                 O.orc_point_from_hash_nonuniform(C.cast(_p(w[i]), C.POINTER(Point)), _p(np.ascontiguousarray(h[i, :56])))
-        assert (ga.point_encode_batch(hp[sel]) == _gen.oracle_encode(w[sel])).all()
+        assert (enc(ga, hp[sel]) == _gen.oracle_encode(w[sel])).all()

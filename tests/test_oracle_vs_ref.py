@@ -71,6 +71,48 @@ def test_differential(O):
             O.orc_ed448_verify(buf(bad), pk1, m, len(msg), it & 1, c, len(ctx))
 
 
+def test_differential_ten_thousand_scalar_multiplications(O):
+    """The hot path at volume: 10 000 random (point, scalar) pairs through the oracle and the real reference -- variable
+    base, fixed base (raw limbs of both), decaf encoding; every tenth pair also the two-base multiplication and an
+    EdDSA verification of a signature with one flipped bit somewhere.  (The 60 iterations above cover every entry
+    point; this one hunts rare carries in the arithmetic the GPU tests are checked against.)"""
+    R = ref()
+    rnd = random.Random(2024)
+    rb = lambda n: rnd.getrandbits(8 * n).to_bytes(n, "little")
+    p1, p2, s, t, s2, a, b = Point(), Point(), Scalar(), Scalar(), Scalar(), Point(), Point()
+    e1, e2 = (C.c_uint8 * 56)(), (C.c_uint8 * 56)()
+    for it in range(10000):
+        R.goldilocks_448_point_from_hash_uniform(C.byref(p1), buf(rb(112)))
+        raw = rb(72) if it % 50 else bytes([0xff]) * 72            # now and then the largest input
+        R.goldilocks_448_scalar_decode_long(C.byref(s), buf(raw), 72)
+        O.orc_scalar_decode_long(C.byref(s2), buf(raw), 72)
+        assert bytes(s) == bytes(s2), it
+        R.goldilocks_448_point_scalarmul(C.byref(a), C.byref(p1), C.byref(s))
+        O.orc_point_scalarmul(C.byref(b), C.byref(p1), C.byref(s))
+        assert bytes(a) == bytes(b), it
+        R.goldilocks_448_point_encode(e1, C.byref(a)); O.orc_point_encode(e2, C.byref(b))
+        assert bytes(e1) == bytes(e2), it
+        R.goldilocks_448_precomputed_scalarmul(C.byref(a), R.precomputed_base, C.byref(s))
+        O.orc_precomputed_scalarmul(C.byref(b), O.orc_precomputed_base(), C.byref(s))
+        assert bytes(a) == bytes(b), it
+        if it % 10:
+            continue
+        R.goldilocks_448_point_from_hash_uniform(C.byref(p2), buf(rb(112)))
+        R.goldilocks_448_scalar_decode_long(C.byref(t), buf(rb(72)), 72)
+        R.goldilocks_448_point_double_scalarmul(C.byref(a), C.byref(p1), C.byref(s), C.byref(p2), C.byref(t))
+        O.orc_point_double_scalarmul(C.byref(b), C.byref(p1), C.byref(s), C.byref(p2), C.byref(t))
+        assert bytes(a) == bytes(b), it
+        sk, msg = rb(57), rb(it % 200)
+        pk, sg = (C.c_uint8 * 57)(), (C.c_uint8 * 114)()
+        R.goldilocks_ed448_derive_public_key(pk, buf(sk))
+        m = buf(msg) if msg else None
+        R.goldilocks_ed448_sign(sg, buf(sk), pk, m, len(msg), 0, None, 0)
+        assert O.orc_ed448_verify(sg, pk, m, len(msg), 0, None, 0) == -1, it
+        bad = bytearray(sg); bad[rnd.randrange(114)] ^= 1 << rnd.randrange(8)
+        assert R.goldilocks_ed448_verify(buf(bad), pk, m, len(msg), 0, None, 0) == \
+            O.orc_ed448_verify(buf(bad), pk, m, len(msg), 0, None, 0), it
+
+
 def test_decode_special_encodings_differential(O):
     """Decaf and EdDSA decoding of hand-picked encodings (identity, 1, p-1, values >= p, small even and
     odd values, set high bits): status and, when accepted, the raw output limbs match the reference."""

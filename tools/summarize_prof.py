@@ -9,10 +9,24 @@
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
+import subprocess
 import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_sha16():
+    """what bench.py compares with the tree it runs from: the kernels' sources at the time of the measurement"""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "libgoldilocks_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def newest(paths):
@@ -48,8 +62,8 @@ def main(raw, out):
             continue
         wl = "_".join(os.path.basename(d).split("_")[2:])
         tag = os.path.basename(d).split("_")[1]
-        if tag.endswith("II"):
-            wl += "_index_independent"
+        if tag.endswith("FAST"):      # the opt-in mode's passes (tools/profile_round.sh: FETCHFAST, WRITEFAST, SQ1FAST, ...)
+            wl += "_fast"
         # the bench process is the one with the most dispatches
         best = None
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
@@ -82,6 +96,12 @@ def main(raw, out):
         if tgt is not None:
             tgt[r["kernel"]] = max(tgt.get(r["kernel"], 0.0), r["avg_per_dispatch"])
     traffic = {k: 2 * fetch[k] * 1024 + write[k] * 1024 for k in fetch if k in write}
+    try:
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip()
+    except OSError:
+        head = ""
+    traffic["_measured_on"] = {"kernel_source_sha16": kernel_source_sha16(), "git_head": head or None,
+                               "round": os.path.basename(os.path.normpath(out)).replace("profiles_", "")}
     traffic["_note"] = ("HBM bytes per launch (batch 2^20): 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (KiB units; FETCH_SIZE "
                         "doubled per MI355X_MICROARCH.md HBM section), separate --pmc passes, rocprofv3_pmc_summary.json")
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
