@@ -21,7 +21,8 @@ namespace gd_host {
 // built up front; the bytes of lanes [lo, lo+m) are gathered by pack() so that a pipelined caller
 // can pack chunk i+1 while the GPU works on chunk i.
 struct PackedMessages {
-    static constexpr size_t THREADS = 4;
+    static constexpr size_t THREADS = 4;   // at most; `threads` of them are used (a sharded call on a host with few cores asks for fewer)
+    size_t threads = THREADS;
     std::vector<uint64_t> &off;        // the caller's buffers, kept between calls (the device context's)
     std::vector<uint8_t> &store;
     struct Bytes {                     // (what the unique_ptr this replaced offered)
@@ -35,8 +36,9 @@ struct PackedMessages {
     // (construction is free; index() does the work, so that a caller may run it beside something else -- the upload of
     // the public keys, goldilocks_amd.hip verify_pipelined)
     PackedMessages(std::vector<uint64_t> &off_, std::vector<uint8_t> &store_, const uint8_t *const *message_,
-                   const size_t *message_len_, size_t n, bool index_now = true)
-        : off(off_), store(store_), message(message_), message_len(message_len_), count(n) {
+                   const size_t *message_len_, size_t n, bool index_now = true, size_t threads_ = THREADS)
+        : threads(threads_ < 1 ? 1 : threads_ > THREADS ? THREADS : threads_), off(off_), store(store_), message(message_),
+          message_len(message_len_), count(n) {
         if (index_now) index();
     }
     // the n + 1 offsets and room for the packed bytes
@@ -50,15 +52,15 @@ struct PackedMessages {
                 off[i + 1] = off[i] + (too_long ? 0 : message_len[i]);
             }
         } else {   // the offsets of a million messages by four threads: sums of quarters, then the quarters' offsets
-            const size_t per = (n + THREADS - 1) / THREADS;
+            const size_t per = (n + threads - 1) / threads;
             uint64_t sum[THREADS] = {0};
             bool bad[THREADS] = {false};
             const auto range = [&](size_t t, size_t &a, size_t &b) { a = t * per < n ? t * per : n; b = a + per < n ? a + per : n; };
             const auto each = [&](const auto &fn) {
                 std::thread th[THREADS];
-                for (size_t t = 1; t < THREADS; t++) th[t] = std::thread(fn, t);
+                for (size_t t = 1; t < threads; t++) th[t] = std::thread(fn, t);
                 fn((size_t)0);
-                for (size_t t = 1; t < THREADS; t++) th[t].join();
+                for (size_t t = 1; t < threads; t++) th[t].join();
             };
             each([&](size_t t) {
                 size_t a, b;
@@ -70,13 +72,13 @@ struct PackedMessages {
                 }
                 sum[t] = s;
             });
-            for (size_t t = 0; t < THREADS; t++) too_long = too_long || bad[t];
+            for (size_t t = 0; t < threads; t++) too_long = too_long || bad[t];
             if (too_long) {
                 for (size_t i = 0; i < n; i++) off[i + 1] = 0;
             } else {
                 uint64_t start[THREADS];
                 uint64_t acc = 0;
-                for (size_t t = 0; t < THREADS; t++) { start[t] = acc; acc += sum[t]; }
+                for (size_t t = 0; t < threads; t++) { start[t] = acc; acc += sum[t]; }
                 each([&](size_t t) {
                     size_t a, b;
                     range(t, a, b);
@@ -98,8 +100,8 @@ struct PackedMessages {
     size_t nworkers = 0;
     void pack_start(size_t lo, size_t m) {     // ... which work while the caller uploads what needs no packing
         if (m < ((size_t)1 << 16)) return pack_range(lo, lo + m);
-        const size_t per = (m + THREADS - 1) / THREADS, hi = lo + m;
-        for (size_t t = 0; t < THREADS; t++) {
+        const size_t per = (m + threads - 1) / threads, hi = lo + m;
+        for (size_t t = 0; t < threads; t++) {
             const size_t a = lo + t * per < hi ? lo + t * per : hi, b = a + per < hi ? a + per : hi;
             workers[nworkers++] = std::thread([this, a, b] { pack_range(a, b); });
         }

@@ -179,14 +179,18 @@ static int verify_keycomb_host(const uint8_t *sig, const uint8_t *pk, const uint
     Ed448Msg m = ed448_challenge_string(sig, pk, msg, (uint32_t)msglen, prehashed, ctx, ctxlen);
     const KeycombPending pend = ed448_verify_keycomb_begin(m, fb, kc, stage, mk);
     const bool verdict = ed448_verify_keycomb_finish(pend, fe_invert(pend.K)) && key_ok;   // (the device shares the inversion along a lane)
-    // ... and once more with S*B computed ahead and handed in as a projective niels (kernels_verify.hip k_verify_base_part)
+    // ... and once more with S*B computed ahead and handed in as a projective niels (kernels_verify.hip k_verify_base_part);
+    // the multiply-accumulate tally (test_mac_counts_match_bench) stays that of the first evaluation
+    const unsigned long long macs_so_far = gf_mac_counter();
     struct Parked {
         pniels q;
         bool have() const { return true; }
         pniels load() const { return q; }
     } parked{ed448_verify_base_part(sig, fb, mk)};
     const KeycombPending pend2 = ed448_verify_keycomb_begin(m, fb, kc, stage, mk, parked);
-    if ((ed448_verify_keycomb_finish(pend2, fe_invert(pend2.K)) && key_ok) != verdict) return 99;
+    const bool verdict2 = ed448_verify_keycomb_finish(pend2, fe_invert(pend2.K)) && key_ok;
+    gf_mac_counter() = macs_so_far;
+    if (verdict2 != verdict) return 99;
     return verdict ? -1 : 0;
 }
 
