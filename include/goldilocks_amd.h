@@ -376,16 +376,17 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
 /* Keys that sign MANY signatures of a batch get more than a shared window table: a fixed-base comb of their own (4 x 7 x
  * 16, 48 KiB per key, built on the device per call), with which a verification is src/eddsa.c's equation without a
  * ladder and without R's decoding -- 0.3 of the arithmetic.  Used when the batch averages at least
- * `min_signatures_per_key` signatures per distinct key (twice that for batches below 2^18 signatures, where the fixed
- * latency of building the combs weighs more) and has at most `keys` distinct keys, in batches of more than 2^12
+ * `min_signatures_per_key` signatures per distinct key (twice that for batches below 2^18 signatures, four times below 2^17,
+ * where the fixed latency of building the combs weighs more: 8 / 16 / 32 by default, the measured break-evens of
+ * tests/key_pool_probe.py) and has at most `keys` distinct keys, in batches of more than 2^12
  * signatures (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the
  * combs off; 2^17 is the most and the default.  `keys` is a CEILING: a batch can use at most n / min_signatures_per_key
- * combs, so that is what a call reserves workspace for -- 64 KiB of device memory per such key (2^20 signatures: up to 2^16
- * keys, 4 GiB), never more than a quarter of the device's free memory, kept until goldilocks_amd_shutdown -- whatever the
+ * combs, so that is what a call reserves workspace for -- 64 KiB of device memory per such key (2^20 signatures: up to 2^17
+ * keys, 8 GiB), never more than a quarter of the device's free memory, kept until goldilocks_amd_shutdown -- whatever the
  * batch's keys then turn out to be (the device decides; the call does not wait for it).  Turning the pool off
  * (goldilocks_amd_set_verify_key_pool(0, ..)) turns the combs off with it.  Process-wide. */
 #define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 17)
-#define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 16
+#define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 8
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t min_signatures_per_key);
 /* ... and keys that sign at least this many signatures of the batch on average get the wider comb (4 x 8 x 14, 96 KiB:
  * twice the entries to build, 9 % less to walk per signature).  0: never.  Process-wide. */

@@ -454,7 +454,7 @@ def set_verify_key_pool(keys=KEY_POOL_DEFAULT, min_batch=KEY_POOL_MIN_BATCH_DEFA
     lib().goldilocks_amd_set_verify_key_pool(int(keys), int(min_batch))
 
 
-KEY_COMBS_DEFAULT, KEY_COMBS_MIN_PER_KEY_DEFAULT = 1 << 17, 16
+KEY_COMBS_DEFAULT, KEY_COMBS_MIN_PER_KEY_DEFAULT = 1 << 17, 8
 
 
 def set_verify_key_combs(keys=KEY_COMBS_DEFAULT, min_signatures_per_key=KEY_COMBS_MIN_PER_KEY_DEFAULT):

@@ -359,6 +359,19 @@ constexpr int KEY_COMBS_MAX = 1 << 17;     // the most keys of a batch that can 
 constexpr int KEY_COMBS_MIN_BATCH = 4096;   // combs are considered from so many signatures on (up to there a wave verifies each signature, section 7a)
 constexpr int KEY_SORT_BINS = 8192;        // up to so many keys the counting sort goes through per-block bins in LDS
 constexpr int KEY_TEETH_BY_WAVE_MAX = 4096;   // up to so many keys a WAVE computes a key's teeth (latency), beyond a lane (throughput)
+// the fewest entries of a key's comb that one lane of k_verify_key_combs builds and normalises with one shared inversion
+// (the kernel doubles it while the keys are too many for one wave per SIMD).  2^20 signatures of 2^10 keys, whole
+// step, alternating on one box: 32 entries per lane 8.25 - 8.28 ms, 16: 8.04 - 8.06, 8: 7.98 - 8.00
+// (profiles/r04/experiments.md H)
+#ifndef GD_KEY_COMB_SEG
+#define GD_KEY_COMB_SEG 8
+#endif
+#ifndef GD_KEY_COMB_SEG_MAX
+#define GD_KEY_COMB_SEG_MAX 64
+#endif
+constexpr int KEY_COMB_SEG = GD_KEY_COMB_SEG, KEY_COMB_SEG_MAX = GD_KEY_COMB_SEG_MAX;   // (a comb of 7 teeth has 64 entries)
+static_assert(KEY_COMB_SEG >= 1 && KEY_COMB_SEG <= KEY_COMB_SEG_MAX && KEY_COMB_SEG_MAX <= 64 &&
+              (KEY_COMB_SEG & (KEY_COMB_SEG - 1)) == 0 && (KEY_COMB_SEG_MAX & (KEY_COMB_SEG_MAX - 1)) == 0, "segments divide a comb");
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)
 // the launches of one group of key-comb verifications (one shared inversion per lane over all of them): where each
 // launch's positions start, relative to the group's, and how many they are

@@ -120,7 +120,7 @@ GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ ke
 // call's capacity (2^15 by default, KEY_COMBS_MAX at most).
 //   k_verify_key_teeth     (kernels_wave.hip) wave k: decode key k, teeth 2^(16 m) * A_k, m < 28, by row arithmetic;
 //                          k_verify_key_teeth_lanes: a lane per key instead, when the keys are many
-//   k_verify_key_combs     16 lanes per key: a lane walks 16 entries of one comb in Gray-code order (one addition of a
+//   k_verify_key_combs     a lane walks KEY_COMB_SEG (8) entries of one comb in Gray-code order (one addition of a
 //                          doubled tooth per entry) and normalises them with one shared inversion
 //   k_verify_key_count / _scan / _scatter   the signatures in the order of their keys (below)
 //   k_ed448_verify_keycomb the verification itself, two passes around the lane's shared inversion
@@ -150,17 +150,23 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
     }
 }
 // Entry 64 j + idx of a key's comb is T_(6+7j) + sum_{k<6} (+-) T_(k+7j), + iff bit k of idx.  A lane owns a SEGMENT of
-// 16 consecutive Gray codes of one comb of one key (16 lanes per key): its first entry is the signed sum of 7 teeth
-// (6 additions), each further one differs from its predecessor in one sign, i.e. by (+-) 2 T_k (1 addition) -- 21
-// additions for 16 entries instead of 96 -- and the 16 share one inversion (Montgomery's trick along the lane).
+// SEG consecutive Gray codes of one comb of one key: its first entry is the signed sum of 7 teeth (6 additions), each
+// further one differs from its predecessor in one sign, i.e. by (+-) 2 T_k (1 addition) -- SEG + 5 additions for SEG
+// entries instead of 6 SEG -- and the SEG share one inversion (Montgomery's trick along the lane).
+// SEG is chosen on the device from the number of keys: few keys leave the device idle and the kernel is one lane's
+// LATENCY, which a short segment shortens (KEY_COMB_SEG = 8 entries: 13 additions and a 446-squaring inversion); many
+// keys make it a matter of THROUGHPUT, and a lane's inversion is shared by as many entries as one comb allows (up to
+// 64: 6 % of the work per entry that segments of 8 cost).  The smallest power of two from KEY_COMB_SEG on that leaves
+// at most one wave per SIMD.
 // The entries wait unnormalised in their own slots of the comb; chain: 8 uint4 per (key, entry) for the trick.
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain) {
-    constexpr uint32_t SEG = 16;
     if (!ctrl[2]) return;                           // (ctrl[3] is 0 then: no geometry to derive)
-    const uint32_t teeth_per = ctrl[3], NT = 4 * teeth_per, per_comb = 1u << (teeth_per - 1), entries = 4 * per_comb,
-                   per_key = entries / SEG;
-    const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK, total = combed * per_key;
+    const uint32_t teeth_per = ctrl[3], NT = 4 * teeth_per, per_comb = 1u << (teeth_per - 1), entries = 4 * per_comb;
+    const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK;
+    uint32_t SEG = (uint32_t)KEY_COMB_SEG;
+    while (SEG < (uint32_t)KEY_COMB_SEG_MAX && (uint64_t)combed * (entries / SEG) > stride / 2) SEG *= 2;
+    const uint32_t per_key = entries / SEG, total = combed * per_key;
     for (uint32_t t = blockIdx.x * BLOCK + threadIdx.x; t < total; t += stride) {
         const uint32_t k = t / per_key, j = (t % per_key) / (per_comb / SEG), g0 = (t % (per_comb / SEG)) * SEG;
         const TeethAt tooth{teeth + (size_t)KEY_TEETH_U4 * k}, twice{teeth + (size_t)KEY_TEETH_U4 * k + 16 * NT};

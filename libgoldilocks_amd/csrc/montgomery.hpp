@@ -66,7 +66,7 @@ GD_FN void ml_step_sel(fe &x2, fe &z2, fe &x3, fe &z3, const fe &x1, bool sw) {
     const fe t1 = fe_select(s2, s3, sw);                            // A = sum of the pair to double      mag 2
     const fe t2 = fe_weak(fe_select(d2, d3, sw));                   // B = its difference                 mag 1
     const fe dm = fe_weak(fe_sub<2>(da, cb));                       // +-(DA - CB)                        mag 1
-    z3 = fe_mul(x1, fe_sqr(dm));                                    // z3 = x1 (DA - CB)^2
+    z3 = fe_mul(fe_sqr(dm), x1);                                    // z3 = x1 (DA - CB)^2   (x1 second: its half sums are loop-invariant)
     x3 = fe_sqr(fe_add(da, cb));                                    // x3 = (DA + CB)^2       (input mag 2)
     const fe aa = fe_sqr(t1);                                       // AA                     (input mag 2)
     const fe bb = fe_sqr(t2);                                       // BB

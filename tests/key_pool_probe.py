@@ -6,8 +6,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make, timeit
 QUICK = "--quick" in sys.argv     # 2^20 signatures around the combs' break-even only
-for n in ((1 << 20,) if QUICK else (1 << 16, 1 << 17, 1 << 18, 1 << 20)):
-    for nk in ((1024, n // 32, n // 16, n // 8) if QUICK else (16, 1024, n // 128, n // 32, n // 16, n // 8, n // 4, n)):
+SMALL = "--small" in sys.argv     # ... and 2^16 .. 2^18 signatures around theirs
+for n in ((1 << 20,) if QUICK else (1 << 16, 1 << 17, 1 << 18) if SMALL else (1 << 16, 1 << 17, 1 << 18, 1 << 20)):
+    for nk in ((1024, n // 32, n // 16, n // 8) if QUICK else (n // 64, n // 32, n // 16, n // 8) if SMALL else (16, 1024, n // 128, n // 32, n // 16, n // 8, n // 4, n)):
         sig, pk, msg = make(n, nk)
         st = torch.empty(n, dtype=torch.int32, device="cuda")
         f = lambda: ga.dev("ed448_verify", st.data_ptr(), sig.data_ptr(), pk.data_ptr(), msg.data_ptr(), None, 32, 0, None, 0, n, None)
