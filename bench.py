@@ -292,7 +292,12 @@ def make_workload(name, cx, access):
                     got=host(status[:m]))
     # 2^10 keys: every key gets a fixed-base comb, the wide one at 2^10 signatures per key (kernels_verify.hip);
     # all-distinct keys: every lane for itself
-    return dict(step=step, kernel="k_ed448_verify" if name == "verify_distinct" else "k_ed448_verify_keycomb_wide", check=check, sample=sample)
+    # (the key-comb verification is a first pass, S*B computed ahead beside the combs' build, and a finish kernel: the
+    # step's memory traffic is the three kernels' together; `kernel` names the dominant one)
+    if name == "verify_distinct":
+        return dict(step=step, kernel="k_ed448_verify", check=check, sample=sample)
+    return dict(step=step, kernel="k_ed448_verify_keycomb_wide", check=check, sample=sample,
+                traffic_kernels=("k_ed448_verify_keycomb_wide", "k_ed448_verify_keycomb_finish", "k_verify_base_part"))
 
 
 def verify_inputs(cx, distinct=False):
@@ -547,7 +552,7 @@ def kernel_source_sha16():
 
 
 def pmc_traffic(kernel):
-    """HBM bytes per launch from the PMC passes of tools/profile_round.sh (profiles/pmc_traffic.json) -- a measurement of
+    """HBM bytes per launch (kernel: a name, or the names of the kernels that make up a step: their sum) from the PMC passes of tools/profile_round.sh (profiles/pmc_traffic.json) -- a measurement of
     another run, so it says which kernels it was taken on: the figure is only reported as `traffic` when the kernels'
     sources are still the ones it was measured on; otherwise traffic is null and the stale figure goes to traffic_stale."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -557,17 +562,20 @@ def pmc_traffic(kernel):
     stamp = d.get("_measured_on") or {}
     current = stamp.get("kernel_source_sha16") == kernel_source_sha16()
     info = dict(stamp, current=current, file="profiles/pmc_traffic.json")
+    if isinstance(kernel, (tuple, list)):
+        parts = [d.get(k) for k in kernel]
+        return (sum(parts) if all(x is not None for x in parts) else None), dict(info, kernels=list(kernel))
     return d.get(kernel), info
 
 
-def roofline(name, kernel, n, avg_ms, table_access):
+def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None):
     spec = dict(WORKLOADS[name])
     if table_access == "index-independent" and spec.get("macs_index_independent"):
         spec["macs"] = spec["macs_index_independent"]
     if n < spec.get("recomb_min", 0):
         spec["macs"] = spec["macs_reference_comb"]
     achieved = spec["bytes"] * n / (avg_ms * 1e-3) / 1e9
-    traffic, measured_on = pmc_traffic(kernel)
+    traffic, measured_on = pmc_traffic(traffic_kernels or kernel)
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": traffic if measured_on and measured_on["current"] else None, "kernel": kernel, "kernel_ms_avg": avg_ms,
          "bytes_per_op": spec["bytes"],
@@ -669,7 +677,7 @@ def run_rank(args):
             "per_gpu": [dict({"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
                               "kernel_ms_avg": r[3], "batch": int(r[4])},
                              **({"slice": [int(r[5]), int(r[5]) + int(r[4])]} if scaling == "strong" else {})) for r in rows],
-            "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access),
+            "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels")),
         }
         line.update(extra)
         if "sample" in w and world == 1:
@@ -684,7 +692,7 @@ def run_rank(args):
             _, cworst, cms = time_workload(torch, shard, cw, csteps, cwarm, None, None)
             cok, ctext, _ = cw["check"]()
             cavg = sum(cms) / len(cms)
-            r = roofline(cname, cw["kernel"], n, cavg, access)
+            r = roofline(cname, cw["kernel"], n, cavg, access, cw.get("traffic_kernels"))
             configs[key] = {"value": n * csteps / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
                             "table_access": access, "steps": csteps, "warmup": cwarm, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
                             "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit", "traffic_measured_on", "traffic_stale") if k in r},

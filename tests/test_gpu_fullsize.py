@@ -246,6 +246,41 @@ def test_host_array_verification_pipeline_in_chunks(ga, O, keys):
     assert (st[pick] == want).all() and (want == 0).sum() >= 50
 
 
+@pytest.mark.parametrize("n", [131071, 131072, 131073, 3 * 131072 + 5, (1 << 19) - 1, 1 << 19])
+def test_verification_sizes_around_the_launch_and_pipeline_thresholds(ga, O, n):
+    """The phased verification at the sizes where its plan changes: one lane short of a full grid, exactly a full grid (the
+    first size with S*B computed ahead), one more, a ragged multi-round batch, and the host-array entry point one signature
+    below and exactly at the size from which it pipelines (two chunks).  64 keys (combs), every 53rd signature corrupted in
+    turn in S, R, key or message: the accept set must be exactly the untouched lanes, through the device entry point and
+    through the host arrays alike."""
+    import torch
+    nk = 64
+    sk = np.frombuffer(_gen.stream(b"thr/sk", 57 * nk), np.uint8).reshape(nk, 57)
+    which = np.arange(n) * 40503 % nk
+    sk_n = np.ascontiguousarray(sk[which])
+    msg = np.zeros((n, 16), np.uint8)
+    msg[:, :4] = np.arange(n, dtype=np.uint32).view(np.uint8).reshape(n, 4)
+    pk = ga.ed448_derive_public_key_batch(sk_n)
+    sig = ga.ed448_sign_batch(sk_n, pk, [m.tobytes() for m in msg])
+    idx = np.arange(n)
+    bad = (idx % 53) == 7
+    kind = (idx // 53) % 4
+    sig[bad & (kind == 0), 70] ^= 2
+    sig[bad & (kind == 1), 11] ^= 0x10
+    pk[bad & (kind == 2), 3] ^= 1
+    msg[bad & (kind == 3), 15] ^= 0x40
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dst = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    dsig, dpk, dmsg = d(sig), d(pk), d(msg)
+    ga.dev("ed448_verify", dst.data_ptr(), dsig.data_ptr(), dpk.data_ptr(), dmsg.data_ptr(), None, 16, 0, None, 0, n, None)
+    torch.cuda.synchronize()
+    st = dst.cpu().numpy()
+    assert ((st == -1) == ~bad).all() and ((st == -1) | (st == 0)).all()
+    assert ga.last_verify_key_counts()[2] > 0                      # combs
+    st2 = ga.ed448_verify_batch(sig, pk, [m.tobytes() for m in msg])
+    assert (st2 == st).all()
+
+
 def test_sharded_host_batches_match_single_device(ga, O):
     """goldilocks_amd_use_devices: the contiguous-slice sharding of the host-array batches (one host
     thread per listed device).  A 1-GPU box lists device 0 three times, so the shards run one after
@@ -528,7 +563,7 @@ def test_verification_shares_the_tables_of_repeated_keys(ga, O):
             served[name] = ga.last_verify_key_counts()
         nkeys = len({bytes(k) for k in pks})
         assert served == dict(off=(0, 0, 0), tables=(nkeys, nkeys, 0), tiny=(nkeys, 0, 0), combs=(nkeys, 0, nkeys),
-                              default=(nkeys, nkeys, 0)), served          # (default: 32 signatures per key are the rule, this batch has 31.7)
+                              default=(nkeys, 0, nkeys)), served          # (default at 2^17 signatures: combs from 16 signatures per key; this batch has 31.7)
         # few keys only (the lanes whose key is one of a kind left out): 2^16 signatures of 38 keys -> combs by default
         few = np.flatnonzero(~own)[: 1 << 16]
         d_few = torch.from_numpy(few).cuda()

@@ -523,8 +523,10 @@ class Audit:
                     srcs.append(self.src_val(st, dst_ops[:1]))
             val = combine(srcs)
             is_v = mn.startswith("v_")
-            if mn == "v_readfirstlane_b32":
+            if mn == "v_readfirstlane_b32":     # an SGPR result: not predicated, but WHICH lane is first depends on EXEC
                 is_v = False
+                if exec_t:
+                    val = (True, val[1])
             # pointers stay pointers only through address arithmetic; anything else drops the provenance
             if not re.match(r"^(v_mov_b32|v_mov_b64|s_mov_b32|s_mov_b64|v_add_co_u32|v_addc_co_u32|v_add_u32|v_lshl_add_u64|"
                             r"v_mad_u64_u32|v_mad_i64_i32|s_add_u32|s_addc_u32|s_add_i32|v_add3_u32|v_lshl_add_u32|v_add_lshl_u32|"

@@ -1,0 +1,10 @@
+#!/bin/bash
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+cd "$ROOT"
+mkdir -p gpurun_out/final
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/final/gputest.txt 2>&1; tail -6 gpurun_out/final/gputest.txt
+python -c "
+import sys; sys.path.insert(0, '.')
+import __graft_entry__ as g
+g.smoke()" 2>&1 | tail -3
