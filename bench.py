@@ -72,9 +72,9 @@ WORKLOADS = {
     "fixed": dict(metric="Ed448 fixed-base scalarmuls/sec", unit="scalarmuls/s", bytes=312, macs=101_664,
                   macs_reference_comb=138_848, recomb_min=1 << 18,
                   desc="goldilocks_448_precomputed_scalarmul, a caller's 5x5x18 comb table: re-combed to 4x7x16 per call, staged in LDS"),
-    "base": dict(metric="Ed448 base-point scalarmuls/sec", unit="scalarmuls/s", bytes=312, macs=36_480,
+    "base": dict(metric="Ed448 base-point scalarmuls/sec", unit="scalarmuls/s", bytes=312, macs=36_480, base_table_additions=True,
                  macs_index_independent=101_664,   # the library's 4 x 7 x 16 comb of the base point, staged in LDS
-                 desc="goldilocks_448_precomputed_scalarmul(precomputed_base), 16-bit window table"),
+                 desc="goldilocks_448_precomputed_scalarmul(precomputed_base), the base point's window table"),
     # half-size scalars (csrc/lattice.hpp): two decodings + two window tables + one 45-window ladder over both
     # points + two correcting additions + 28 base-point additions
     # macs_own_key: every lane decodes its key and builds the key's table itself (what "verify_distinct" runs);
@@ -84,13 +84,13 @@ WORKLOADS = {
     # additions, R's test with a shared inversion; per key 3.46 M more (its decoding, 432 doublings, 256 entries);
     # macs_key_comb_wide: keys with 256 signatures or more get 4 x 8 x 14 combs -- what 2^20 signatures of 2^10 keys
     # run at: 13 doublings + 55 additions, 7.09 M per key (512 entries) = 6 922 per signature at 2^10 keys
-    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=136_984 + 6_922,
+    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=136_984 + 6_922, base_table_additions=True,
                    macs_key_comb=149_976, macs_per_key_comb=3_458_392,
                    macs_key_comb_wide=136_984, macs_per_key_comb_wide=7_088_472,
                    macs_pooled_tables=522_128 + 87, macs_own_key=611_480, macs_shared_keys=522_128, keys=1024,
                    desc="goldilocks_ed448_verify, 32-byte messages, 2^10 distinct keys (SURVEY 8d), 1% corrupted"),
     "verify_distinct": dict(metric="Ed448 verifies/sec, every signature under its own key", unit="verifies/s", bytes=207,
-                            macs=611_480, keys=None,
+                            macs=611_480, keys=None, base_table_additions=True,
                             desc="goldilocks_ed448_verify, 32-byte messages, as many distinct keys as signatures, 1% corrupted"),
     "sign": dict(metric="Ed448 signatures/sec", unit="signatures/s", bytes=260, macs=None,
                  desc="goldilocks_ed448_sign, 32-byte messages, no context"),
@@ -568,10 +568,19 @@ def pmc_traffic(kernel):
     return d.get(kernel), info
 
 
-def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None):
+def base_table_windows(bits):
+    """Digits of a scalar in the base point's window table of `bits`-bit digits (scalarmul.hpp bwt_windows)."""
+    return -(-446 // bits)
+
+
+def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_table_bits=0):
     spec = dict(WORKLOADS[name])
     if table_access == "index-independent" and spec.get("macs_index_independent"):
         spec["macs"] = spec["macs_index_independent"]
+    elif spec.get("macs") and spec.get("base_table_additions") and base_table_bits:
+        # the figures are priced for 16-bit digits (28 of them); the device's table may be wider: a mixed addition
+        # (7 multiplications) less per digit saved
+        spec["macs"] -= (28 - base_table_windows(base_table_bits)) * 7 * 192
     if n < spec.get("recomb_min", 0):
         spec["macs"] = spec["macs_reference_comb"]
     achieved = spec["bytes"] * n / (avg_ms * 1e-3) / 1e9
@@ -673,11 +682,13 @@ def run_rank(args):
                                     if args.global_log2_batch is not None else "independent batch per GPU")
                                    + ", no data-path collective", "control_plane": backend or "single process",
                        "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],
+                       # digits of the base point's window table on this device (0: this workload never asked for it)
+                       "base_table_bits": ga.get_base_table_bits(),
                        "parity_spot_check": "ok" if ok else "FAILED", "check": check},
             "per_gpu": [dict({"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
                               "kernel_ms_avg": r[3], "batch": int(r[4])},
                              **({"slice": [int(r[5]), int(r[5]) + int(r[4])]} if scaling == "strong" else {})) for r in rows],
-            "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels")),
+            "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels"), ga.get_base_table_bits()),
         }
         line.update(extra)
         if "sample" in w and world == 1:
@@ -692,11 +703,12 @@ def run_rank(args):
             _, cworst, cms = time_workload(torch, shard, cw, csteps, cwarm, None, None)
             cok, ctext, _ = cw["check"]()
             cavg = sum(cms) / len(cms)
-            r = roofline(cname, cw["kernel"], n, cavg, access, cw.get("traffic_kernels"))
+            r = roofline(cname, cw["kernel"], n, cavg, access, cw.get("traffic_kernels"), ga.get_base_table_bits())
             configs[key] = {"value": n * csteps / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
                             "table_access": access, "steps": csteps, "warmup": cwarm, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
                             "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit", "traffic_measured_on", "traffic_stale") if k in r},
-                            "mac_frac": r["mac"]["frac"] if "mac" in r else None, "check": ctext,
+                            "mac_frac": r["mac"]["frac"] if "mac" in r else None, "macs_per_op": r["mac"]["macs_per_op"] if "mac" in r else None,
+                            "base_table_bits": ga.get_base_table_bits(), "check": ctext,
                             "parity_spot_check": "ok" if cok else "FAILED"}
             ok = ok and cok
             samples[key] = cw["sample"]()

@@ -392,6 +392,21 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t 
  * twice the entries to build, 9 % less to walk per signature).  0: never.  Process-wide. */
 #define GOLDILOCKS_AMD_KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT 256
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_wide(size_t min_signatures_per_key);
+/* The base point's own window table: T_i[k] = (2k+1) * 2^(w i) * B for the signed w-bit digits of a scalar, one mixed
+ * addition per digit and no doubling.  It serves what multiplies the base point by PUBLIC data -- S*B of every
+ * verification, goldilocks_448_base_double_scalarmul_non_secret -- and, with GOLDILOCKS_AMD_TABLES_FAST, key derivation,
+ * signing, X448 key generation and the base point's precomputed_scalarmul.  A device builds it at the first call that
+ * needs it (tens of milliseconds) and keeps it until goldilocks_amd_shutdown.  Wider digits trade device memory for
+ * additions: 16 bits = 27 additions from 168 MiB (Infinity-Cache resident), 18 = 24 from 600 MiB, 20 = 22 from 2.2 GiB,
+ * 22 = 20 from 7.9 GiB, 24 = 18 from 28.5 GiB of HBM (2^20 verifications on 2^10 keys: 8.08 / 7.91 / 7.77 / 7.67 / 7.55 ms;
+ * base-point multiplications with digit-addressed tables: 498 / 503 / 532 / 571 / 610 M/s).  bits = 0 (the default, or the
+ * environment's GOLDILOCKS_AMD_BASE_TABLE_BITS): the widest whose table takes at most an eighth of the device memory free
+ * at that first call, never below 16 -- 24 bits on an otherwise empty MI355X.  Any even width from 8 to 24 may be asked
+ * for.  Process-wide; a device whose table has another width rebuilds it at its next such call.  Results do not
+ * depend on the width.  Returns 0, or 1 for a width that does not exist. */
+GOLDILOCKS_AMD_API int goldilocks_amd_set_base_table_bits(int bits);
+/* the width of the table the calling thread's device holds (0: none built yet) */
+GOLDILOCKS_AMD_API int goldilocks_amd_get_base_table_bits(void);
 /* Test hook: how the last large verification batch on the calling thread's device served its keys --
  * counts[0] distinct keys seen, counts[1] keys with a pooled window table, counts[2] keys with a comb (at most one of the
  * two is non-zero; all zero if the batch was too small for either), counts[3] the combs' teeth (7 or 8; 0 without

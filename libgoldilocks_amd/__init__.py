@@ -90,6 +90,8 @@ FUNCTIONS = {
     "goldilocks_amd_set_verify_key_pool": (None, "zz"),
     "goldilocks_amd_set_verify_key_combs": (None, "zz"),
     "goldilocks_amd_set_verify_key_combs_wide": (None, "z"),
+    "goldilocks_amd_set_base_table_bits": (C.c_int, "i"),
+    "goldilocks_amd_get_base_table_bits": (C.c_int, ""),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -469,6 +471,17 @@ KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT = 256
 def set_verify_key_combs_wide(min_signatures_per_key=KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT):
     """Keys that sign at least so many signatures of a batch on average get the wider comb (8 teeth); 0: never."""
     lib().goldilocks_amd_set_verify_key_combs_wide(int(min_signatures_per_key))
+
+
+def set_base_table_bits(bits=0):
+    """Digit width of the base point's window table (0: by the device's free memory; an even width from 8 to 24)."""
+    if lib().goldilocks_amd_set_base_table_bits(int(bits)) != 0:
+        raise ValueError(lib().goldilocks_amd_last_error().decode())
+
+
+def get_base_table_bits():
+    """Digit width of the table the current device holds (0: none built yet)."""
+    return lib().goldilocks_amd_get_base_table_bits()
 
 
 def get_table_access():

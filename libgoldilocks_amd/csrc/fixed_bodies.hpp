@@ -276,7 +276,7 @@ __device__ __forceinline__ void x448_body(uint8_t *shared, int32_t *status, cons
             den = p.x;
         } else {
             GlobalBwt tab{table};
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(x448_public_scalar(w)));
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(x448_public_scalar(w), tab));
             const pt p = ladder_bwt(bits, tab);
             num = p.y;
             den = p.x;

@@ -332,14 +332,30 @@ struct LdsShuffleCombBig {
     }
 };
 
-// Fixed-base window table of the base point: BWT_WINDOWS x BWT_PER_WINDOW affine niels (12 uint4 each) in
-// global memory, built once per device (k_build_bwt), cache-resident (L2 / Infinity Cache): every lane
-// gathers one contiguous 192-byte entry per digit.
-constexpr int BWT_ENTRIES = BWT_WINDOWS * BWT_PER_WINDOW;   // 28 x 32768 with 16-bit digits
+// Fixed-base window table of the base point: a header of BWT_HEADER_U4 uint4 -- [0] = (digit bits, windows, 0, 0),
+// [1..4] = the recoding offset (2^(bits*windows) - 1) mod q -- and windows x 2^(bits-1) affine niels (12 uint4 each) in
+// global memory, built once per device at its first use (k_bwt_header, k_bwt_steps, k_build_bwt).  16-bit digits keep
+// it in the Infinity Cache (168 MiB); wider ones trade HBM for additions (24 bits: 28.5 GiB, 18 additions instead of
+// 27): every lane gathers one contiguous 192-byte entry per digit, requested one addition ahead, and the kernels that
+// use it do not wait for it (profiles/r04/experiments.md I).
+constexpr int BWT_HEADER_U4 = 16;
 struct GlobalBwt {
     const uint4 *p;
-    __device__ __forceinline__ niels load(int i, uint32_t idx) const {
-        const uint4 *q = p + 12 * (BWT_PER_WINDOW * i + idx);
+    __device__ __forceinline__ BwtGeom geom() const {
+        const uint4 h = p[0];
+        return BwtGeom{h.x, h.y};
+    }
+    __device__ __forceinline__ sc adjust() const {
+        const uint4 a = p[1], b = p[2], c = p[3], d = p[4];
+        sc r;
+        r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+        r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+        r.w[8] = c.x; r.w[9] = c.y; r.w[10] = c.z; r.w[11] = c.w;
+        r.w[12] = d.x; r.w[13] = d.y;
+        return r;
+    }
+    __device__ __forceinline__ niels load(const BwtGeom &g, uint32_t i, uint32_t idx) const {
+        const uint4 *q = p + BWT_HEADER_U4 + 12 * (((size_t)i << (g.bits - 1)) + idx);
         niels e;
         e.a = fe_load(q);
         e.b = fe_load(q + 4);
@@ -418,13 +434,14 @@ struct LdsMkBits {
 };
 
 // Verification's three scalars in 16 words of LDS per lane: the two half-size ones of the joint ladder are 225
-// bits each (words 0..7 and 8..15), and the base point's full-size one is only made when they are dead (words 0..13;
-// its 16-bit digits never straddle a word, so no padding word is read).
+// bits each (words 0..7 and 8..15), and the base point's full-size one is only made when they are dead (words 0..13
+// and a zero fifteenth).
 struct LdsMkBitsVerify {
     uint32_t *slot0;
     __device__ __forceinline__ LdsBits operator()(const sc &s, int) const {
 #pragma unroll
         for (int k = 0; k < 14; k++) slot0[k * BLOCK] = s.w[k];
+        slot0[14 * BLOCK] = 0;   // (window_bwt reads a digit's second word whether it straddles or not)
         return LdsBits{slot0};
     }
     __device__ __forceinline__ LdsBits words(const uint32_t (&w)[15], int which) const {
@@ -434,7 +451,6 @@ struct LdsMkBitsVerify {
         return LdsBits{slot};
     }
 };
-static_assert(BWT_BITS == 16 || BWT_BITS == 8, "LdsMkBitsVerify: the base point's digits must not straddle words");
 
 #define GD_KERNEL extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 
@@ -597,7 +613,14 @@ GD_KERNEL k_point_pred(int32_t *__restrict__ status, const uint64_t *__restrict_
 GD_KERNEL k_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, const uint64_t *__restrict__ a,
                      const uint64_t *__restrict__ b, uint32_t n, int op, uint32_t aux);
 GD_KERNEL k_import_comb(uint4 *__restrict__ dst, const uint64_t *__restrict__ src, uint32_t ntables);
-GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb);
+// the base point's window table (kernels_fixed.hip): header, the windows' steps 2 * 2^(bits i) * B, the entries in
+// segments of BWT_BUILD_SEG per lane (slab: the entries [first, first + count) of the whole table; chain: a field
+// element of scratch per entry of the slab)
+constexpr uint32_t BWT_BUILD_SEG = 64;
+GD_KERNEL k_bwt_header(uint4 *__restrict__ table, uint32_t bits);
+GD_KERNEL k_bwt_steps(uint4 *__restrict__ steps, const uint4 *__restrict__ comb, uint32_t bits);
+GD_KERNEL k_build_bwt(uint4 *__restrict__ table, const uint4 *__restrict__ comb, const uint4 *__restrict__ steps,
+                      uint4 *__restrict__ chain, uint32_t bits, uint64_t first, uint32_t count);
 GD_KERNEL k_precompute(uint64_t *__restrict__ tables, const uint64_t *__restrict__ base, uint32_t n,
                        uint4 *__restrict__ workspace);
 

@@ -71,28 +71,20 @@ GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__
         const sc k = wave_load_scalars(stage, scalar, i0, m, l);
         pt res = pt_identity();
         if (l < m) {
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(k));
+            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(k, tab));
             res = ladder_bwt(bits, tab);
         }
         wave_store_points(stage, out, i0, m, l, res);
     }
 }
 
-// T_i[k] = (2k+1) * 2^(BWT_BITS*i) * B as affine niels ((Y-X)/2Z, (Y+X)/2Z, 78164 T/2Z), one entry per lane.
-// Launch with exactly BWT_ENTRIES lanes (a multiple of the block size): the comb gather needs full waves.
-GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) {
-    __shared__ uint32_t s_bits[15 * BLOCK];
-    __shared__ uint32_t s_comb[COMB_LDS_WORDS];
-    stage_comb_lds(s_comb, comb);
-    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
-    const uint32_t e = blockIdx.x * BLOCK + threadIdx.x;   // < BWT_ENTRIES by construction
-    const uint32_t i = e / BWT_PER_WINDOW, kk = e % BWT_PER_WINDOW;
-    // the scalar (2k+1) * 2^(BWT_BITS*i) mod q: shift as far as 448 bits allow, reduce, double the rest
+// ---- the base point's window table: T_i[k] = (2k+1) * 2^(bits i) * B as affine niels ((Y-X)/2Z, (Y+X)/2Z, 78164 T/2Z).
+// The scalar m * 2^(bits i) mod q, m < 2^bits: shifted as far as 448 bits allow, reduced, the rest doubled.
+__device__ __forceinline__ sc bwt_entry_scalar(uint32_t m, uint32_t bits, uint32_t i) {
     sc v = sc_zero();
-    const uint32_t m = 2 * kk + 1;               // < 2^BWT_BITS
-    uint32_t bit = BWT_BITS * i, extra = 0;
-    if (bit + BWT_BITS > 448) {
-        extra = bit + BWT_BITS - 448;
+    uint32_t bit = bits * i, extra = 0;
+    if (bit + bits > 448) {
+        extra = bit + bits - 448;
         bit -= extra;
     }
     const uint32_t wd = bit >> 5, sh = bit & 31;
@@ -100,18 +92,82 @@ GD_KERNEL k_build_bwt(uint4 *__restrict__ dst, const uint4 *__restrict__ comb) {
     for (int w = 0; w < 14; w++) {
         uint32_t x = 0;
         if ((uint32_t)w == wd) x = m << sh;
-        if ((uint32_t)w == wd + 1 && sh + BWT_BITS > 32) x = m >> (32 - sh);
+        if ((uint32_t)w == wd + 1 && sh + bits > 32) x = m >> (32 - sh);
         v.w[w] = x;
     }
     v = sc_reduce(v);
     for (uint32_t k = 0; k < extra; k++) v = sc_add(v, v);
-    LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(v));
-    pt p = ladder_comb(bits, tab);
-    fe zi = fe_invert(fe_weak(fe_add(p.z, p.z)));
-    uint4 *q = dst + 12 * (size_t)e;
-    fe_store(q, fe_mul(fe_weak(fe_sub<2>(p.y, p.x)), zi));
-    fe_store(q + 4, fe_mul(fe_weak(fe_add(p.x, p.y)), zi));
-    fe_store(q + 8, fe_mul(fe_mulw(p.t, TWO_EFF_D), zi));
+    return v;
+}
+GD_KERNEL k_bwt_header(uint4 *__restrict__ table, uint32_t bits) {
+    if (blockIdx.x || threadIdx.x >= (uint32_t)BWT_HEADER_U4) return;
+    const sc a = bwt_adjust_for(bits);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (threadIdx.x == 0) v = make_uint4(bits, bwt_windows(bits), 0, 0);
+    if (threadIdx.x == 1) v = make_uint4(a.w[0], a.w[1], a.w[2], a.w[3]);
+    if (threadIdx.x == 2) v = make_uint4(a.w[4], a.w[5], a.w[6], a.w[7]);
+    if (threadIdx.x == 3) v = make_uint4(a.w[8], a.w[9], a.w[10], a.w[11]);
+    if (threadIdx.x == 4) v = make_uint4(a.w[12], a.w[13], 0, 0);
+    table[threadIdx.x] = v;
+}
+// steps[i] = 2 * 2^(bits i) * B as a projective niels: what takes an entry of window i to the next.  One block (the
+// comb gather needs full waves: lanes beyond the windows repeat the last one).
+GD_KERNEL k_bwt_steps(uint4 *__restrict__ steps, const uint4 *__restrict__ comb, uint32_t bits) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint32_t s_comb[COMB_LDS_WORDS];
+    stage_comb_lds(s_comb, comb);
+    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
+    const uint32_t windows = bwt_windows(bits), i = threadIdx.x < windows ? threadIdx.x : windows - 1;
+    LdsBits b = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(bwt_entry_scalar(1u, bits, i)));
+    pt p = ladder_comb(b, tab);
+    pt_double(p, true);
+    if (!blockIdx.x && threadIdx.x < windows) pniels_store(steps + 16 * i, pt_to_pniels(p));
+}
+// A lane owns BWT_BUILD_SEG consecutive entries of one window: the first from the comb (a whole scalar multiplication),
+// each further one by adding the window's step, all normalised with ONE shared inversion (Montgomery's trick along the
+// lane, as k_verify_key_combs): 34 multiplications per entry instead of the 1 200 of an entry per lane with its own
+// multiplication and inversion -- 2^23 x 19 entries in tens of milliseconds.  The unnormalised entries wait in their
+// own slots; chain: 8 uint4 per entry of the slab [first, first + count) (both multiples of BWT_BUILD_SEG).
+GD_KERNEL k_build_bwt(uint4 *__restrict__ table, const uint4 *__restrict__ comb, const uint4 *__restrict__ steps,
+                      uint4 *__restrict__ chain, uint32_t bits, uint64_t first, uint32_t count) {
+    __shared__ uint32_t s_bits[15 * BLOCK];
+    __shared__ uint32_t s_comb[COMB_LDS_WORDS];
+    stage_comb_lds(s_comb, comb);
+    LdsShuffleComb tab{s_comb, threadIdx.x & 63u};
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    const bool live = (uint64_t)t * BWT_BUILD_SEG < count;
+    const uint32_t off = live ? t * BWT_BUILD_SEG : 0u;          // (idle lanes of the last block repeat the first segment)
+    const uint64_t e0 = first + off;
+    const uint32_t i = (uint32_t)(e0 >> (bits - 1)), k0 = (uint32_t)e0 & ((1u << (bits - 1)) - 1);
+    LdsBits b = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(bwt_entry_scalar(2 * k0 + 1, bits, i)));
+    pt p = ladder_comb(b, tab);
+    const pniels step = pniels_load(steps + 16 * i);
+    uint4 *const entries = table + BWT_HEADER_U4 + 12 * e0;
+    uint4 *const slots = chain + 8 * (size_t)off;
+    InvChain ch;
+    ch.begin();
+#pragma unroll 1
+    for (uint32_t s = 0;; s++) {
+        uint4 *q = entries + 12 * s;
+        if (live) {
+            fe_store(q, fe_weak(fe_sub<2>(p.y, p.x)));
+            fe_store(q + 4, fe_weak(fe_add(p.x, p.y)));
+            fe_store(q + 8, fe_mulw(p.t, TWO_EFF_D));
+        }
+        ch.push(slots + 8 * s, fe_add(p.z, p.z), live);
+        if (s + 1 == BWT_BUILD_SEG) break;
+        pt_add_pniels(p, step, false, true);
+    }
+    ch.invert();
+    if (!live) return;
+#pragma unroll 1
+    for (uint32_t s = BWT_BUILD_SEG; s-- > 0;) {
+        const fe zi = ch.pop(slots + 8 * s);
+        uint4 *q = entries + 12 * s;
+        fe_store(q, fe_mul(fe_load(q), zi));
+        fe_store(q + 4, fe_mul(fe_load(q + 4), zi));
+        fe_store(q + 8, fe_mul(fe_load(q + 8), zi));
+    }
 }
 
 // entry e = 64 j + idx of the 4 x 7 x 16 comb: (2^(16(6+7j)) + sum_{k<6} (+-) 2^(16(k+7j))) * B, + iff bit k of idx,

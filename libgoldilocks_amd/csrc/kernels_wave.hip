@@ -203,7 +203,7 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_double_scalarmul_wave(uint
             P = wc::walk_two_tables(L, tab1, tab, Bits{bits}, Bits{bits + 16}, 90, false, false);
         } else {
             P = wc::scalarmul(L, tab, bits, wc::load_point(L, b2 + 32 * (size_t)op), k2);
-            const sc r = sc_recode_bwt(k1);
+            const sc r = sc_recode_bwt(k1, GlobalBwt{bwt});
 #pragma unroll
             for (int k = 0; k < 14; k++) bits[k] = r.w[k];
             bits[14] = 0;

@@ -25,6 +25,11 @@ GD_CONST uint32_t SC_ADJ8[14] = {0x529eec33u, 0x721cf5b5u, 0xc8e9c2abu, 0x7a4cf6
 // (2^456 - 1) mod q: the same for 38 signed 12-bit windows (experiment, -DGD_BWT_BITS=12)
 GD_CONST uint32_t SC_ADJ12[14] = {0x9eec33ffu, 0x1cf5b552u, 0xe9c2ab72u, 0x4cf635c8u, 0xa725bf7au,
                                   0xc492d944u, 0xd77058eeu, 0x0000020cu, 0, 0, 0, 0, 0, 0};
+// (2^460 - 1) mod q and (2^462 - 1) mod q: 23 signed 20-bit and 21 signed 22-bit windows (-DGD_BWT_BITS=20 / 22)
+GD_CONST uint32_t SC_ADJ20[14] = {0xeec33fffu, 0xcf5b5529u, 0x9c2ab721u, 0xcf635c8eu, 0x725bf7a4u,
+                                  0x492d944au, 0x77058eecu, 0x000020cdu, 0, 0, 0, 0, 0, 0};
+GD_CONST uint32_t SC_ADJ22[14] = {0xbb0cffffu, 0x3d6d54a7u, 0x70aadc87u, 0x3d8d723au, 0xc96fde93u,
+                                  0x24b65129u, 0xdc163bb1u, 0x00008335u, 0, 0, 0, 0, 0, 0};
 
 GD_FN sc sc_zero() {
     sc r;
@@ -167,5 +172,7 @@ GD_FN sc sc_recode_signed(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_A
 // [-255, 255] (same derivation as above with 8-bit windows: sum 255*256^i = 2^448 - 1).
 GD_FN sc sc_recode_signed8(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_ADJ8))); }
 GD_FN sc sc_recode_signed12(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_ADJ12))); }
+GD_FN sc sc_recode_signed20(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_ADJ20))); }
+GD_FN sc sc_recode_signed22(const sc &s) { return sc_halve(sc_add(s, sc_const(SC_ADJ22))); }
 
 }  // namespace gd

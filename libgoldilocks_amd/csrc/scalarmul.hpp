@@ -195,66 +195,84 @@ GD_FN niels comb_big_normalise(const pt &p) {
 template <class TEETH>
 GD_FN niels comb_big_entry(const TEETH &teeth, uint32_t e) { return comb_big_normalise(comb_big_entry_projective(teeth, e)); }
 
-// Fixed-base, no doublings: s*B = sum_i (+-) T_i[idx_i] over the signed BWT_BITS-bit digits of the
-// recoded scalar W = (s + 2^(BWT_BITS*BWT_WINDOWS) - 1)/2 mod q, with T_i[k] = (2k+1) * 2^(BWT_BITS*i) * B
-// as affine niels, built once per device.  With 8-bit digits: 56 x 128 entries (1.3 MiB), 55 mixed
-// additions; with 16-bit digits (the default): 28 x 32768 entries (168 MiB, Infinity-Cache resident),
-// 27 mixed additions -- instead of the comb's 17 doublings + 89 additions.  The reference
-// has no such table; results are the same group element (parity is on encodings).
-// BWT: bwt.load(i, idx) -> niels.
-#ifndef GD_BWT_BITS
-#define GD_BWT_BITS 16
+// Fixed-base, no doublings: s*B = sum_i (+-) T_i[idx_i] over the signed w-bit digits of the recoded scalar
+// W = (s + 2^(w*windows) - 1)/2 mod q, with T_i[k] = (2k+1) * 2^(w*i) * B as affine niels, built once per device.
+// The digit width w is the TABLE's (its header says so; goldilocks_amd_set_base_table_bits): 8 bits are 56 x 128
+// entries (1.3 MiB) and 55 mixed additions; 16 bits 28 x 32 768 entries (168 MiB, Infinity-Cache resident) and 27;
+// 24 bits 19 x 2^23 entries (28.5 GiB of the 288 GiB of HBM) and 18 -- instead of the comb's 17 doublings + 89
+// additions.  The reference has no such table; results are the same group element (parity is on encodings).
+// BWT: geom() -> BwtGeom, adjust() -> the recoding offset (2^(w*windows) - 1) mod q, load(geom, i, idx) -> niels.
+struct BwtGeom {
+    uint32_t bits, windows;
+};
+constexpr uint32_t BWT_BITS_MIN = 8, BWT_BITS_MAX = 24;
+#ifdef __HIPCC__
+#define GD_HD __host__ __device__ inline
+#else
+#define GD_HD inline
 #endif
-constexpr int BWT_BITS = GD_BWT_BITS;
-static_assert(BWT_BITS == 8 || BWT_BITS == 10 || BWT_BITS == 12 || BWT_BITS == 14 || BWT_BITS == 16,
-              "recoding constants exist for 8/14/16-bit (2^448-1), 10-bit (2^450-1) and 12-bit (2^456-1) digits");
-constexpr int BWT_WINDOWS = (446 + BWT_BITS - 1) / BWT_BITS;   // 56 or 45
-constexpr int BWT_PER_WINDOW = 1 << (BWT_BITS - 1);             // entries per window: 128 or 512
-GD_FN sc sc_recode_bwt(const sc &s) {
-    return BWT_BITS == 10 ? sc_recode_signed(s) : BWT_BITS == 12 ? sc_recode_signed12(s) : sc_recode_signed8(s);
+GD_HD constexpr uint32_t bwt_windows(uint32_t bits) { return (446 + bits - 1) / bits; }
+GD_HD constexpr bool bwt_bits_supported(uint32_t bits) { return bits >= BWT_BITS_MIN && bits <= BWT_BITS_MAX && bits % 2 == 0; }
+GD_HD constexpr uint64_t bwt_entries(uint32_t bits) { return (uint64_t)bwt_windows(bits) << (bits - 1); }
+// the recoding offsets that exist: 8/14/16 bits span 448 bits, 10/18 span 450, 12/24 span 456, 20 span 460, 22 span 462
+GD_FN sc bwt_adjust_for(uint32_t bits) {
+    const uint32_t span = bits * bwt_windows(bits);
+    return span == 450   ? sc_const(SC_ADJ)
+           : span == 456 ? sc_const(SC_ADJ12)
+           : span == 460 ? sc_const(SC_ADJ20)
+           : span == 462 ? sc_const(SC_ADJ22)
+                         : sc_const(SC_ADJ8);
 }
+template <class BWT>
+GD_FN sc sc_recode_bwt(const sc &s, const BWT &bwt) {
+    return sc_halve(sc_add(s, bwt.adjust()));
+}
+// (BITS holds a zero fifteenth word: the top digit of a span beyond 448 bits reaches into it, and a digit's second
+// word is read whether it straddles or not)
 template <class BITS>
-GD_FN uint32_t window_bwt(const BITS &bits, int i) {
-    const int pos = BWT_BITS * i, k = pos >> 5, sh = pos & 31;
-    uint32_t lo = bits.word(k) >> sh;
-    uint32_t hi = sh + BWT_BITS > 32 ? bits.word(k + 1) << (32 - sh) : 0u;   // the digit straddles two words
-    return (lo | hi) & ((1u << BWT_BITS) - 1);
+GD_FN uint32_t window_bwt(const BITS &bits, uint32_t i, uint32_t w) {
+    const uint32_t pos = w * i, k = pos >> 5, sh = pos & 31;
+    const uint64_t two = (uint64_t)bits.word((int)k) | (uint64_t)bits.word((int)k + 1) << 32;
+    return (uint32_t)(two >> sh) & ((1u << w) - 1);
 }
-GD_FN void signed_digit_bwt(uint32_t w, uint32_t &idx, bool &neg) {
-    neg = w < (uint32_t)BWT_PER_WINDOW;
-    idx = (neg ? ~w : w) & (uint32_t)(BWT_PER_WINDOW - 1);
+GD_FN void signed_digit_bwt(uint32_t d, uint32_t w, uint32_t &idx, bool &neg) {
+    const uint32_t per_window = 1u << (w - 1);
+    neg = d < per_window;
+    idx = (neg ? ~d : d) & (per_window - 1);
 }
 // acc += s*B through the same table: one mixed addition per digit onto a caller's accumulator (acc.t valid).
-// The entry of the NEXT digit is requested before the current addition: a gather from a 168-MiB table is a
-// miss almost every time, and 28 of them in a row, each waited for, cost as much as 8 of the 28 additions
+// The entry of the NEXT digit is requested before the current addition: a gather from a table of hundreds of MiB is
+// a miss almost every time, and 28 of them in a row, each waited for, cost as much as 8 of the 28 additions
 // (tools/verifyphases: 12.6 clocks per multiply-accumulate against the ladder's 9.7).
 template <class BITS, class BWT>
 GD_FN void ladder_bwt_onto(pt &acc, const BITS &bits, const BWT &bwt) {
+    const BwtGeom g = bwt.geom();
     uint32_t idx;
     bool neg;
-    signed_digit_bwt(window_bwt(bits, BWT_WINDOWS - 1), idx, neg);
-    niels next = bwt.load(BWT_WINDOWS - 1, idx);
+    signed_digit_bwt(window_bwt(bits, g.windows - 1, g.bits), g.bits, idx, neg);
+    niels next = bwt.load(g, g.windows - 1, idx);
 #pragma unroll 1
-    for (int i = BWT_WINDOWS - 1; i >= 0; i--) {
+    for (uint32_t i = g.windows; i-- > 0;) {
         const niels e = next;
         const bool neg_e = neg;
         if (i > 0) {
-            signed_digit_bwt(window_bwt(bits, i - 1), idx, neg);
-            next = bwt.load(i - 1, idx);
+            signed_digit_bwt(window_bwt(bits, i - 1, g.bits), g.bits, idx, neg);
+            next = bwt.load(g, i - 1, idx);
         }
         pt_add_niels(acc, e, neg_e, true);
     }
 }
 template <class BITS, class BWT>
 GD_FN pt ladder_bwt(const BITS &bits, const BWT &bwt) {
+    const BwtGeom g = bwt.geom();
     uint32_t idx;
     bool neg;
-    signed_digit_bwt(window_bwt(bits, BWT_WINDOWS - 1), idx, neg);
-    pt acc = niels_to_pt(bwt.load(BWT_WINDOWS - 1, idx), neg);
+    signed_digit_bwt(window_bwt(bits, g.windows - 1, g.bits), g.bits, idx, neg);
+    pt acc = niels_to_pt(bwt.load(g, g.windows - 1, idx), neg);
 #pragma unroll 1
-    for (int i = BWT_WINDOWS - 2; i >= 0; i--) {
-        signed_digit_bwt(window_bwt(bits, i), idx, neg);
-        pt_add_niels(acc, bwt.load(i, idx), neg, true);
+    for (uint32_t i = g.windows - 1; i-- > 0;) {
+        signed_digit_bwt(window_bwt(bits, i, g.bits), g.bits, idx, neg);
+        pt_add_niels(acc, bwt.load(g, i, idx), neg, true);
     }
     return acc;
 }
@@ -277,12 +295,12 @@ struct FixedBwt {
     const BWT &bwt;
     template <class MK>
     GD_MFN pt mul(const sc &s, MK &mk) const {
-        auto bits = mk(sc_recode_bwt(s), 0);
+        auto bits = mk(sc_recode_bwt(s, bwt), 0);
         return ladder_bwt(bits, bwt);
     }
     template <class MK>
     GD_MFN void add_to(pt &acc, const sc &s, MK &mk) const {
-        auto bits = mk(sc_recode_bwt(s), 0);
+        auto bits = mk(sc_recode_bwt(s, bwt), 0);
         ladder_bwt_onto(acc, bits, bwt);
     }
 };

@@ -128,8 +128,9 @@ __device__ __forceinline__ void double_scalarmul_body(uint64_t *out, const uint6
             r = ladder_double(bits1, t1, bits2, t2);
         } else {
             r = ladder_varbase(bits2, t2);
-            LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(sc_load_abi(s1 + 7 * (size_t)i)));
-            ladder_bwt_onto(r, bits1, GlobalBwt{bwt});
+            const GlobalBwt base_tab{bwt};
+            LdsBits bits1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_bwt(sc_load_abi(s1 + 7 * (size_t)i), base_tab));
+            ladder_bwt_onto(r, bits1, base_tab);
         }
         pt_store_abi(out + 32 * (size_t)i, r);
     }

@@ -438,14 +438,15 @@ __device__ __forceinline__ wfe pack_point(const Lane &L, wfe X, wfe Y, wfe Z, wf
 template <class BITS>
 __device__ __forceinline__ wfe add_base_multiple(const Lane &L, wfe acc, const BITS &bits, const uint4 *bwt) {
     const uint32_t swap_row = L.row ^ 1u;
-    const uint32_t *tab = reinterpret_cast<const uint32_t *>(bwt);
+    const BwtGeom g = GlobalBwt{bwt}.geom();
+    const uint32_t *tab = reinterpret_cast<const uint32_t *>(bwt + BWT_HEADER_U4);
 #pragma unroll 1
-    for (int w = BWT_WINDOWS - 1; w >= 0; w--) {
+    for (uint32_t w = g.windows; w-- > 0;) {
         uint32_t idx;
         bool neg;
-        signed_digit_bwt(window_bwt(bits, w), idx, neg);
+        signed_digit_bwt(window_bwt(bits, w, g.bits), g.bits, idx, neg);
         const uint32_t frow = (neg && L.row < 2) ? (L.row ^ 1u) : L.row;
-        const uint32_t *e = tab + 48 * ((size_t)BWT_PER_WINDOW * w + idx);
+        const uint32_t *e = tab + 48 * (((size_t)w << (g.bits - 1)) + idx);
         const wfe ev = L.row == 3 ? (L.i == 0 ? 1u : 0u) : e[frow * 16 + L.i];
         acc = add_entry(L, acc, ev, neg, swap_row);
     }
@@ -486,7 +487,7 @@ __device__ __forceinline__ bool verify(const Lane &L, const WaveTable &tab_a, co
     // an even rho or |tau| was walked as the next odd number: one copy of its point too many (wave-uniform)
     if (pr.rho_even) V = add_entry(L, V, tab_a.lookup(L, 0, !flip_a), !flip_a, swap_row);   // - PA
     if (pr.tau_even) V = add_entry(L, V, tab_r.lookup(L, 0, false), false, swap_row);       // - PR = + R
-    const sc rs = sc_recode_bwt(pr.ts);
+    const sc rs = sc_recode_bwt(pr.ts, GlobalBwt{bwt});
 #pragma unroll
     for (int k = 0; k < 14; k++) bits[k] = rs.w[k];
     bits[14] = 0;

@@ -518,33 +518,37 @@ void hs_x448_derive_public_key(uint8_t *out, const uint8_t *scalar, const uint64
     words_to_bytes(out, o, 56);
 }
 
-// s*B through the BWT_WINDOWS x BWT_PER_WINDOW window table.  The device builds the whole table
-// (k_build_bwt); the checker computes just the entries a ladder asks for, with the same recipe:
-// T_i[k] = ((2k+1) * 2^(BWT_BITS*i) mod q) * B from the comb, as affine niels.
+// s*B through the window table of w-bit digits.  The device builds the whole table (k_build_bwt: a lane's first entry
+// from the comb, the others by adding the window's step, one shared inversion); the checker computes just the entries
+// a ladder asks for, each by itself: T_i[k] = ((2k+1) * 2^(w i) mod q) * B from the comb, as affine niels -- the same
+// group elements, and an affine form is unique.
 struct HostBwt {
     const HostComb *comb;
-    niels load(int i, uint32_t k) const {
+    uint32_t bits;
+    BwtGeom geom() const { return BwtGeom{bits, bwt_windows(bits)}; }
+    sc adjust() const { return bwt_adjust_for(bits); }
+    niels load(const BwtGeom &g, uint32_t i, uint32_t k) const {
         sc v = sc_zero();
         uint32_t m = 2 * k + 1;
-        int bit = BWT_BITS * i, extra = 0;
-        if (bit + BWT_BITS > 448) {
-            extra = bit + BWT_BITS - 448;
+        int bit = (int)(g.bits * i), extra = 0;
+        if (bit + (int)g.bits > 448) {
+            extra = bit + (int)g.bits - 448;
             bit -= extra;
         }
         v.w[bit >> 5] |= m << (bit & 31);
-        if ((bit & 31) + BWT_BITS > 32 && (bit >> 5) + 1 < 14) v.w[(bit >> 5) + 1] |= m >> (32 - (bit & 31));
+        if ((bit & 31) + (int)g.bits > 32 && (bit >> 5) + 1 < 14) v.w[(bit >> 5) + 1] |= m >> (32 - (bit & 31));
         v = sc_reduce(v);
         for (int d = 0; d < extra; d++) v = sc_add(v, v);
         HostBits b = make_bits(v);
         return host_affine_niels(ladder_comb(b, *comb));
     }
 };
-void hs_bwt_scalarmul(uint64_t *out, const uint64_t *comb_table, const uint64_t *scalars, int n) {
+void hs_bwt_scalarmul(uint64_t *out, const uint64_t *comb_table, const uint64_t *scalars, int n, int bits) {
     static HostComb comb;
     for (int i = 0; i < 80; i++) comb.e[i] = niels_from_abi(comb_table + 24 * i);
-    HostBwt bwt{&comb};
+    HostBwt bwt{&comb, (uint32_t)bits};
     for (int j = 0; j < n; j++) {
-        sc r = sc_recode_bwt(sc_from_abi(scalars + 7 * j));
+        sc r = sc_recode_bwt(sc_from_abi(scalars + 7 * j), bwt);
         HostBits b;
         for (int i = 0; i < 14; i++) b.w[i] = r.w[i];
         b.w[14] = 0;

@@ -138,14 +138,16 @@ def test_x448_and_signing(H, O):
         assert bytes(s1) == bytes(s2)
 
 
-def test_fixed_base_window_table_ladder(H, O):
-    """The 56 x 128 signed 8-bit window table (the device's fast path for the base point)."""
-    H.hs_bwt_scalarmul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
-    n = 24
-    s = _gen.random_scalars(n, b"hs-bwt")
+@pytest.mark.parametrize("bits", [8, 10, 12, 14, 16, 18, 20, 22, 24])
+def test_fixed_base_window_table_ladder(H, O, bits):
+    """The base point's window table of signed `bits`-bit digits (S*B of verification, the device's fast path for the
+    base point): every width the library can be asked for, its recoding offset and its top digit."""
+    H.hs_bwt_scalarmul.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    n = 12
+    s = _gen.random_scalars(n, b"hs-bwt%d" % bits)
     s[:6] = _gen.scalars_from_ints([0, 1, Q - 1, 2**445, 2, 255])
     out = np.empty((n, 32), np.uint64)
-    H.hs_bwt_scalarmul(out.ctypes.data, C.cast(O.orc_precomputed_base(), C.c_void_p), s.ctypes.data, n)
+    H.hs_bwt_scalarmul(out.ctypes.data, C.cast(O.orc_precomputed_base(), C.c_void_p), s.ctypes.data, n, bits)
     assert (_gen.oracle_encode(out) == _gen.oracle_encode(_gen.oracle_fixed(O, s))).all()
 
 

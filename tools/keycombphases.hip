@@ -192,7 +192,8 @@ int main() {
     int32_t *status;
     uint4 *bwt, *combs, *park;
     unsigned long long *totals;
-    const size_t bwt_bytes = (size_t)BWT_ENTRIES * 12 * sizeof(uint4), comb_bytes = (size_t)nkeys * kc_plan::ENTRIES * 12 * sizeof(uint4);
+    const uint32_t bwt_bits = 16;   // the table's digits (timing only: random entries behind a valid header)
+    const size_t bwt_bytes = ((size_t)bwt_entries(bwt_bits) * 12 + BWT_HEADER_U4) * sizeof(uint4), comb_bytes = (size_t)nkeys * kc_plan::ENTRIES * 12 * sizeof(uint4);
     CHECK(hipMalloc(&sig, 114 * (size_t)n));
     CHECK(hipMalloc(&pk, 57 * (size_t)n));
     CHECK(hipMalloc(&msg, msg_len * (size_t)n));
@@ -209,6 +210,8 @@ int main() {
             x ^= x << 13; x ^= x >> 7; x ^= x << 17;
             h[i] = (uint32_t)x & 0x0fffffffu;
         }
+        h[0] = bwt_bits;
+        h[1] = bwt_windows(bwt_bits);
         CHECK(hipMemcpy(bwt, h, bwt_bytes, hipMemcpyHostToDevice));
         CHECK(hipMemcpy(combs, h + 12345, comb_bytes - 4 * 12345, hipMemcpyHostToDevice));
         for (size_t i = 0; i < 114 * (size_t)n / 4; i++) {

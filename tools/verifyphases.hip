@@ -138,17 +138,21 @@ int main(int argc, char **argv) {
     CHECK(hipMalloc(&msg, msg_len * (size_t)n));
     CHECK(hipMalloc(&status, 4 * (size_t)n));
     CHECK(hipMalloc(&ws, (size_t)grid * BLOCK * 2 * TABLE_U4 * sizeof(uint4)));
-    CHECK(hipMalloc(&bwt, (size_t)BWT_ENTRIES * 12 * sizeof(uint4)));
+    const uint32_t bwt_bits = 16;   // the table's digits (timing only: random entries behind a valid header)
+    const size_t bwt_bytes = ((size_t)bwt_entries(bwt_bits) * 12 + BWT_HEADER_U4) * sizeof(uint4);
+    CHECK(hipMalloc(&bwt, bwt_bytes));
     CHECK(hipMalloc(&totals, NPH * sizeof(unsigned long long)));
     // random bytes everywhere (the window table's entries: limbs below 2^28)
     {
-        const size_t nb = (size_t)BWT_ENTRIES * 12 * sizeof(uint4);
+        const size_t nb = bwt_bytes;
         uint32_t *h = (uint32_t *)malloc(nb);
         uint64_t x = 0x9e3779b97f4a7c15ull;
         for (size_t i = 0; i < nb / 4; i++) {
             x ^= x << 13; x ^= x >> 7; x ^= x << 17;
             h[i] = (uint32_t)x & 0x0fffffffu;
         }
+        h[0] = bwt_bits;
+        h[1] = bwt_windows(bwt_bits);
         CHECK(hipMemcpy(bwt, h, nb, hipMemcpyHostToDevice));
         for (size_t i = 0; i < 114 * (size_t)n / 4; i++) {
             x ^= x << 13; x ^= x >> 7; x ^= x << 17;
