@@ -412,9 +412,20 @@ GOLDILOCKS_AMD_API int goldilocks_amd_get_base_table_bits(void);
  * two is non-zero; all zero if the batch was too small for either), counts[3] the combs' teeth (7 or 8; 0 without
  * combs).  Waits for the device. */
 GOLDILOCKS_AMD_API int goldilocks_amd_last_verify_key_counts(uint32_t counts[4]);
-/* "gfx950", number of CUs, workspace bytes currently held */
+/* "gfx950", number of CUs, device memory the library currently holds on the calling thread's device besides its small
+ * tables: workspace + staging + the base point's window table */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
         size_t *workspace_bytes);
+/* Gives device memory of the calling thread's device back without ending the context: the library keeps its workspace
+ * (sized by the largest batch so far: 10 GiB after 2^20 verifications), the staging buffers of the host-array entry points
+ * and the base point's window table (28.5 GiB by default) from their first use until goldilocks_amd_shutdown, because
+ * allocating them costs milliseconds per call.  A service that is done with a burst can release any of them; the next call
+ * that needs one allocates (and, for the table, builds: 0.16 s) it again.  Waits for the device.  Returns 0 on success. */
+#define GOLDILOCKS_AMD_RELEASE_WORKSPACE 1u
+#define GOLDILOCKS_AMD_RELEASE_STAGING 2u
+#define GOLDILOCKS_AMD_RELEASE_BASE_TABLE 4u
+#define GOLDILOCKS_AMD_RELEASE_ALL 7u
+GOLDILOCKS_AMD_API int goldilocks_amd_release_memory(uint32_t what);
 
 GOLDILOCKS_AMD_API int goldilocks_amd_point_scalarmul_dev(void *scaled /* point_s[n] */,
         const void *base /* point_s[n] */, const void *scalar /* scalar_s[n] */, size_t n, void *stream);

@@ -92,6 +92,7 @@ FUNCTIONS = {
     "goldilocks_amd_set_verify_key_combs_wide": (None, "z"),
     "goldilocks_amd_set_base_table_bits": (C.c_int, "i"),
     "goldilocks_amd_get_base_table_bits": (C.c_int, ""),
+    "goldilocks_amd_release_memory": (C.c_int, "I"),
     "goldilocks_amd_point_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_precomputed_scalarmul_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_double_scalarmul_dev": (C.c_int, "pppppzp"),
@@ -482,6 +483,14 @@ def set_base_table_bits(bits=0):
 def get_base_table_bits():
     """Digit width of the table the current device holds (0: none built yet)."""
     return lib().goldilocks_amd_get_base_table_bits()
+
+
+RELEASE_WORKSPACE, RELEASE_STAGING, RELEASE_BASE_TABLE, RELEASE_ALL = 1, 2, 4, 7
+
+
+def release_memory(what=RELEASE_ALL):
+    """Give the current device's workspace / staging buffers / base-point window table back (they come back on demand)."""
+    _check(lib().goldilocks_amd_release_memory(int(what)))
 
 
 def get_table_access():

@@ -104,3 +104,26 @@ def test_default_width_follows_the_free_memory_and_bad_widths_are_refused(ga, O,
         with pytest.raises(ValueError):
             ga.set_base_table_bits(bad)
     assert ga.get_base_table_bits() == bits          # (a refused width changes nothing)
+
+
+def test_release_memory_gives_everything_back_and_it_returns_on_demand(ga, O, width):
+    """goldilocks_amd_release_memory: workspace, staging and the window table go (device_info counts them) and the next
+    calls bring them back with the same results."""
+    width(16)
+    sigs, pks, msgs = _gen.signatures(O, 64, msglen=20, seed=b"bt/release", nkeys=4)
+    reps = 80                                                # 5 120 signatures: the lane kernels and their workspace
+    big = (np.concatenate([sigs] * reps), np.concatenate([pks] * reps), list(msgs) * reps)
+    big[0][7, 3] ^= 1
+    first = np.asarray(ga.ed448_verify_batch(*big))
+    assert (first == -1).sum() == len(first) - 1 and first[7] == 0
+    held = ga.device_info()["workspace_bytes"]
+    table = 28 * 32768 * 192 + 256                           # 16-bit digits: 28 windows of 2^15 entries behind the header
+    assert ga.get_base_table_bits() == 16 and held > table
+    ga.release_memory(ga.RELEASE_BASE_TABLE)
+    assert ga.get_base_table_bits() == 0 and ga.device_info()["workspace_bytes"] == held - table
+    ga.release_memory()
+    assert ga.device_info()["workspace_bytes"] == 0
+    assert (np.asarray(ga.ed448_verify_batch(*big)) == first).all()
+    assert ga.get_base_table_bits() == 16 and table < ga.device_info()["workspace_bytes"] <= held   # (what THIS batch needs)
+    with pytest.raises(ga.GoldilocksAmdError):
+        ga.release_memory(8)
