@@ -571,6 +571,12 @@ def base_table_windows(bits):
     return -(-446 // bits)
 
 
+def table_access_uses_base_table(name, table_access):
+    """Verification multiplies the base point by public data whatever the mode; the base point's own multiplication
+    takes its window table only with digit-addressed tables."""
+    return name.startswith("verify") or table_access != "index-independent"
+
+
 def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_table_bits=0):
     spec = dict(WORKLOADS[name])
     if table_access == "index-independent" and spec.get("macs_index_independent"):
@@ -591,6 +597,12 @@ def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_t
         r["traffic_measured_on"] = measured_on
         if not measured_on["current"]:
             r["traffic_stale"] = traffic
+    if spec.get("base_table_additions") and table_access_uses_base_table(name, table_access) and base_table_bits:
+        # memory for additions: every digit of a scalar is one 192-byte entry of the base point's
+        # table, i.e. two 128-byte lines, and with digits beyond 16 bits the table (28.5 GiB at 24) is in no cache
+        r["traffic_of_base_table_gathers"] = base_table_windows(base_table_bits) * 256 * n
+        r["traffic_note"] = ("most of `traffic` is the base point's window table, gathered on purpose: one entry per digit "
+                             "instead of a mixed addition more per digit saved; the kernels do not wait for it")
     if spec["macs"]:
         macs = spec["macs"] * n / (avg_ms * 1e-3)
         r["mac"] = {"achieved": macs / 1e12, "peak": VALU_MAC_PEAK / 1e12, "unit": "T MAC/s",
@@ -704,7 +716,8 @@ def run_rank(args):
             r = roofline(cname, cw["kernel"], n, cavg, access, cw.get("traffic_kernels"), ga.get_base_table_bits())
             configs[key] = {"value": n * csteps / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
                             "table_access": access, "steps": csteps, "warmup": cwarm, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
-                            "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit", "traffic_measured_on", "traffic_stale") if k in r},
+                            "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit", "traffic_measured_on", "traffic_stale",
+                                                               "traffic_of_base_table_gathers", "traffic_note") if k in r},
                             "mac_frac": r["mac"]["frac"] if "mac" in r else None, "macs_per_op": r["mac"]["macs_per_op"] if "mac" in r else None,
                             "base_table_bits": ga.get_base_table_bits(), "check": ctext,
                             "parity_spot_check": "ok" if cok else "FAILED"}
