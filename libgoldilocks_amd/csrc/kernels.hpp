@@ -452,13 +452,6 @@ struct LdsMkBitsVerify {
     }
 };
 
-// The kernels that build a batch's key combs are chains of dependent arithmetic on a device they do not fill, and S*B of
-// the batch's first rounds runs beside them (k_verify_base_part): their waves go first when both are ready to issue.
-#ifdef GD_PREP_PRIO
-#define GD_PREP_PRIORITY() __builtin_amdgcn_s_setprio(GD_PREP_PRIO)
-#else
-#define GD_PREP_PRIORITY() ((void)0)
-#endif
 #define GD_KERNEL extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 
 // ---------------------------------------------------------------- kernel prototypes

@@ -161,7 +161,6 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
 // The entries wait unnormalised in their own slots of the comb; chain: 8 uint4 per (key, entry) for the trick.
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain) {
-    GD_PREP_PRIORITY();
     if (!ctrl[2]) return;                           // (ctrl[3] is 0 then: no geometry to derive)
     const uint32_t teeth_per = ctrl[3], NT = 4 * teeth_per, per_comb = 1u << (teeth_per - 1), entries = 4 * per_comb;
     const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK;

@@ -99,7 +99,6 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_verify_key_teeth(uint4 *__
                                                                        const uint32_t *__restrict__ ctrl,
                                                                        const uint32_t *__restrict__ key_list,
                                                                        const uint8_t *__restrict__ pk) {
-    GD_PREP_PRIORITY();
     const wc::Lane L = wc::make_lane();
     const uint32_t combed = ctrl[2], me = threadIdx.x & 63u, swap_row = L.row ^ 1u;
     if (combed > (uint32_t)KEY_TEETH_BY_WAVE_MAX) return;   // many keys: a lane each (k_verify_key_teeth_lanes)
