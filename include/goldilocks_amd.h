@@ -325,7 +325,7 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  *     condition and no memory address depends on the scalar (tests/test_isa_audit.py).
  *   GOLDILOCKS_AMD_TABLES_FAST (opt-in, for PUBLIC scalars only)
  *     - each lookup reads only the digit's entry (the address depends on the digit): the base point's
- *       16-bit window table in global memory, 5-bit windows for a variable base.
+ *       window table in global memory (goldilocks_amd_set_base_table_bits), 5-bit windows for a variable base.
  *
  * Not affected: verification and base_double_scalarmul_non_secret (public by contract: always the
  * fast tables), goldilocks_x448 with a peer's point (a Montgomery ladder with selects, no table),
@@ -398,8 +398,8 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_wide(size_t min_sign
  * signing, X448 key generation and the base point's precomputed_scalarmul.  A device builds it at the first call that
  * needs it (tens of milliseconds) and keeps it until goldilocks_amd_shutdown.  Wider digits trade device memory for
  * additions: 16 bits = 27 additions from 168 MiB (Infinity-Cache resident), 18 = 24 from 600 MiB, 20 = 22 from 2.2 GiB,
- * 22 = 20 from 7.9 GiB, 24 = 18 from 28.5 GiB of HBM (2^20 verifications on 2^10 keys: 8.08 / 7.91 / 7.77 / 7.67 / 7.55 ms;
- * base-point multiplications with digit-addressed tables: 498 / 503 / 532 / 571 / 610 M/s).  bits = 0 (the default, or the
+ * 22 = 20 from 7.9 GiB, 24 = 18 from 28.5 GiB of HBM (2^20 verifications of distinct signatures on 2^10 keys: 8.10 / - /
+ * 7.86 / 7.72 / 7.59 ms; base-point multiplications with digit-addressed tables: 498 / 503 / 532 / 571 / 610 M/s).  bits = 0 (the default, or the
  * environment's GOLDILOCKS_AMD_BASE_TABLE_BITS): the widest whose table takes at most an eighth of the device memory free
  * at that first call, never below 16 -- 24 bits on an otherwise empty MI355X.  Any even width from 8 to 24 may be asked
  * for.  Process-wide; a device whose table has another width rebuilds it at its next such call.  Results do not
