@@ -700,6 +700,7 @@ def run_rank(args):
                              **({"slice": [int(r[5]), int(r[5]) + int(r[4])]} if scaling == "strong" else {})) for r in rows],
             "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels"), ga.get_base_table_bits()),
         }
+        line["roofline"]["kernel_ms_every_step"] = [round(x, 3) for x in kernel_ms]   # (rank 0's; HIP events on the launch stream)
         line.update(extra)
         if "sample" in w and world == 1:
             samples["headline"] = w["sample"]()
@@ -709,7 +710,18 @@ def run_rank(args):
         configs = {}
         for key, cname, access in CONFIGS:
             cw = make_workload(cname, cx, access)
-            csteps, cwarm = 8, 3       # (the clocks of an idle GPU take three to four launches to come back up)
+            # The clocks of a GPU that idled (building a workload's input leaves it idle for tens of milliseconds) take
+            # 40 - 50 ms of load to come back up (profiles/r04/experiments.md G: a verification step behind 20 ms of
+            # idling takes 9.3 ms instead of 7.6, and five steps to settle): three warm-up launches do for a 34-ms
+            # kernel, not for a 2-ms one.  Warm up for 150 ms' worth of steps, time 8 (12 of the short ones).
+            cw["step"]()
+            torch.cuda.synchronize()
+            t_probe = time.perf_counter()
+            cw["step"]()
+            torch.cuda.synchronize()
+            t_probe = max(time.perf_counter() - t_probe, 1e-4)
+            cwarm = max(3, min(100, int(0.15 / t_probe)))
+            csteps = 8 if t_probe > 0.02 else 12
             _, cworst, cms = time_workload(torch, shard, cw, csteps, cwarm, None, None)
             cok, ctext, _ = cw["check"]()
             cavg = sum(cms) / len(cms)
