@@ -82,11 +82,14 @@ WORKLOADS = {
     # kernels_verify.hip); macs_key_comb: the key has a fixed-base comb of its own (keys that sign at least 16 of the
     # batch's signatures on average): no ladder, no decoding of R -- the key's 4 x 7 x 16 comb, the base point's
     # additions, R's test with a shared inversion; per key 3.46 M more (its decoding, 432 doublings, 256 entries);
-    # macs_key_comb_wide: keys with 256 signatures or more get 4 x 8 x 14 combs -- what 2^20 signatures of 2^10 keys
-    # run at: 13 doublings + 55 additions, 7.09 M per key (512 entries) = 6 922 per signature at 2^10 keys
-    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=136_984 + 6_922, base_table_additions=True,
+    # macs_key_comb_wide: keys with 256 signatures or more get 4 x 8 x 14 combs: 13 doublings + 55 additions, 7.09 M per
+    # key (512 entries) = 6 922 per signature at 2^10 keys of 2^20 signatures; macs_key_comb_xwide: from 1 024 signatures
+    # per key on 5 x 9 x 10 combs -- what 2^20 signatures of 2^10 keys run at: 9 doublings + 49 additions, 18.77 M per
+    # key as the checker counts it (1 280 entries; the device shares an inversion between 32 of them) = 18 325 per signature
+    "verify": dict(metric="Ed448 verifies/sec", unit="verifies/s", bytes=207, macs=124_440 + 18_325, base_table_additions=True,
                    macs_key_comb=149_976, macs_per_key_comb=3_458_392,
                    macs_key_comb_wide=136_984, macs_per_key_comb_wide=7_088_472,
+                   macs_key_comb_xwide=124_440, macs_per_key_comb_xwide=18_765_352,
                    macs_pooled_tables=522_128 + 87, macs_own_key=611_480, macs_shared_keys=522_128, keys=1024,
                    desc="goldilocks_ed448_verify, 32-byte messages, 2^10 distinct keys (SURVEY 8d), 1% corrupted"),
     "verify_distinct": dict(metric="Ed448 verifies/sec, every signature under its own key", unit="verifies/s", bytes=207,
@@ -296,8 +299,18 @@ def make_workload(name, cx, access):
     # step's memory traffic is the three kernels' together; `kernel` names the dominant one)
     if name == "verify_distinct":
         return dict(step=step, kernel="k_ed448_verify", check=check, sample=sample)
-    return dict(step=step, kernel="k_ed448_verify_keycomb_wide", check=check, sample=sample,
-                traffic_kernels=("k_ed448_verify_keycomb_wide", "k_ed448_verify_keycomb_finish", "k_verify_base_part"))
+    # ... and which comb the batch's keys got decides the first pass's kernel: asked of the library after the steps)
+    def kernels_after():
+        teeth = ga.last_verify_key_counts(teeth=True)[3]
+        main = {7: "k_ed448_verify_keycomb", 8: "k_ed448_verify_keycomb_wide", 9: "k_ed448_verify_keycomb_xwide"}.get(teeth)
+        if main is None:
+            return "k_ed448_verify", None, None
+        tag = {7: "", 8: "_wide", 9: "_xwide"}[teeth]
+        V = WORKLOADS["verify"]
+        macs = V["macs_key_comb" + tag] + V["macs_per_key_comb" + tag] * V["keys"] // n
+        return main, (main, "k_ed448_verify_keycomb_finish", "k_verify_base_part"), macs
+    return dict(step=step, kernel="k_ed448_verify_keycomb_xwide", check=check, sample=sample, kernels_after=kernels_after,
+                traffic_kernels=("k_ed448_verify_keycomb_xwide", "k_ed448_verify_keycomb_finish", "k_verify_base_part"))
 
 
 def verify_inputs(cx, distinct=False):
@@ -577,8 +590,10 @@ def table_access_uses_base_table(name, table_access):
     return name.startswith("verify") or table_access != "index-independent"
 
 
-def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_table_bits=0):
+def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_table_bits=0, macs=None):
     spec = dict(WORKLOADS[name])
+    if macs:                # (verification: the multiply-accumulates of the comb geometry the batch's keys really got)
+        spec["macs"] = macs
     if table_access == "index-independent" and spec.get("macs_index_independent"):
         spec["macs"] = spec["macs_index_independent"]
     elif spec.get("macs") and spec.get("base_table_additions") and base_table_bits:
@@ -671,6 +686,8 @@ def run_rank(args):
     cx = Ctx(ga, np, torch, n, rank)
     w = make_workload(name, cx, args.table_access)
     mine, worst, kernel_ms = time_workload(torch, shard, w, args.steps, args.warmup, dist, backend)
+    if "kernels_after" in w:
+        w["kernel"], w["traffic_kernels"], w["macs"] = w["kernels_after"]()
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     rows = shard.gather_over_ranks([rank, device, n * args.steps / mine, avg_ms, n, lo], dist, backend)
     ok, check, extra = w["check"]() if rank == 0 else (True, "n/a", {})
@@ -698,7 +715,7 @@ def run_rank(args):
             "per_gpu": [dict({"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
                               "kernel_ms_avg": r[3], "batch": int(r[4])},
                              **({"slice": [int(r[5]), int(r[5]) + int(r[4])]} if scaling == "strong" else {})) for r in rows],
-            "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels"), ga.get_base_table_bits()),
+            "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels"), ga.get_base_table_bits(), w.get("macs")),
         }
         line["roofline"]["kernel_ms_every_step"] = [round(x, 3) for x in kernel_ms]   # (rank 0's; HIP events on the launch stream)
         line.update(extra)
@@ -723,9 +740,11 @@ def run_rank(args):
             cwarm = max(3, min(100, int(0.15 / t_probe)))
             csteps = 8 if t_probe > 0.02 else 12
             _, cworst, cms = time_workload(torch, shard, cw, csteps, cwarm, None, None)
+            if "kernels_after" in cw:
+                cw["kernel"], cw["traffic_kernels"], cw["macs"] = cw["kernels_after"]()
             cok, ctext, _ = cw["check"]()
             cavg = sum(cms) / len(cms)
-            r = roofline(cname, cw["kernel"], n, cavg, access, cw.get("traffic_kernels"), ga.get_base_table_bits())
+            r = roofline(cname, cw["kernel"], n, cavg, access, cw.get("traffic_kernels"), ga.get_base_table_bits(), cw.get("macs"))
             configs[key] = {"value": n * csteps / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
                             "table_access": access, "steps": csteps, "warmup": cwarm, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
                             "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit", "traffic_measured_on", "traffic_stale",

@@ -392,6 +392,10 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t 
  * twice the entries to build, 9 % less to walk per signature).  0: never.  Process-wide. */
 #define GOLDILOCKS_AMD_KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT 256
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_wide(size_t min_signatures_per_key);
+/* ... and from this many on the widest (5 x 9 x 10, 240 KiB: two and a half times the entries again, another 10 % less to
+ * walk per signature: 9 doublings + 49 additions).  0: never.  Process-wide. */
+#define GOLDILOCKS_AMD_KEY_COMBS_XWIDE_MIN_PER_KEY_DEFAULT 1024
+GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_xwide(size_t min_signatures_per_key);
 /* The base point's own window table: T_i[k] = (2k+1) * 2^(w i) * B for the signed w-bit digits of a scalar, one mixed
  * addition per digit and no doubling.  It serves what multiplies the base point by PUBLIC data -- S*B of every
  * verification, goldilocks_448_base_double_scalarmul_non_secret -- and, with GOLDILOCKS_AMD_TABLES_FAST, key derivation,
@@ -409,7 +413,7 @@ GOLDILOCKS_AMD_API int goldilocks_amd_set_base_table_bits(int bits);
 GOLDILOCKS_AMD_API int goldilocks_amd_get_base_table_bits(void);
 /* Test hook: how the last large verification batch on the calling thread's device served its keys --
  * counts[0] distinct keys seen, counts[1] keys with a pooled window table, counts[2] keys with a comb (at most one of the
- * two is non-zero; all zero if the batch was too small for either), counts[3] the combs' teeth (7 or 8; 0 without
+ * two is non-zero; all zero if the batch was too small for either), counts[3] the combs' teeth (7, 8 or 9; 0 without
  * combs).  Waits for the device. */
 GOLDILOCKS_AMD_API int goldilocks_amd_last_verify_key_counts(uint32_t counts[4]);
 /* "gfx950", number of CUs, device memory the library currently holds on the calling thread's device besides its small

@@ -90,6 +90,7 @@ FUNCTIONS = {
     "goldilocks_amd_set_verify_key_pool": (None, "zz"),
     "goldilocks_amd_set_verify_key_combs": (None, "zz"),
     "goldilocks_amd_set_verify_key_combs_wide": (None, "z"),
+    "goldilocks_amd_set_verify_key_combs_xwide": (None, "z"),
     "goldilocks_amd_set_base_table_bits": (C.c_int, "i"),
     "goldilocks_amd_get_base_table_bits": (C.c_int, ""),
     "goldilocks_amd_release_memory": (C.c_int, "I"),
@@ -472,6 +473,14 @@ KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT = 256
 def set_verify_key_combs_wide(min_signatures_per_key=KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT):
     """Keys that sign at least so many signatures of a batch on average get the wider comb (8 teeth); 0: never."""
     lib().goldilocks_amd_set_verify_key_combs_wide(int(min_signatures_per_key))
+
+
+KEY_COMBS_XWIDE_MIN_PER_KEY_DEFAULT = 1024
+
+
+def set_verify_key_combs_xwide(min_signatures_per_key=KEY_COMBS_XWIDE_MIN_PER_KEY_DEFAULT):
+    """Keys that sign at least so many signatures of a batch on average get the widest comb (5 x 9 teeth); 0: never."""
+    lib().goldilocks_amd_set_verify_key_combs_xwide(int(min_signatures_per_key))
 
 
 def set_base_table_bits(bits=0):

@@ -365,10 +365,15 @@ struct GlobalBwt {
 };
 // A 4 x 7 x 16 comb in global memory, read by the digit (public scalars only): the comb of a verification key that
 // signed many of a batch's signatures (kernels_verify.hip), 256 affine niels = 48 KiB per key.
-constexpr int KEY_TEETH_U4 = 2 * comb_wide::TEETH * comb_wide::COMBS * 16;   // room for 32 teeth + their doubles (pniels) per key while its comb is built
+constexpr int KEY_TEETH_U4 = 2 * comb_xwide::TEETH * comb_xwide::COMBS * 16;   // room for 45 teeth + their doubles (pniels) per key while its comb is built
 constexpr int KEY_COMB_U4 = comb_big::ENTRIES * 12;
-// a key's comb has 7 or 8 teeth per comb (ctrl[3], k_verify_key_mode): entries and uint4 of one key's comb
-__host__ __device__ constexpr uint32_t key_comb_entries(uint32_t teeth) { return 4u << (teeth - 1); }
+// a key's comb has 7, 8 or 9 teeth per comb (ctrl[3], k_verify_key_mode): 4 x 7 x 16, 4 x 8 x 14 or 5 x 9 x 10 -- its
+// combs, their spacing, entries and uint4
+__host__ __device__ constexpr uint32_t key_comb_combs(uint32_t teeth) { return teeth >= (uint32_t)comb_xwide::TEETH ? (uint32_t)comb_xwide::COMBS : 4u; }
+__host__ __device__ constexpr uint32_t key_comb_spacing(uint32_t teeth) {
+    return teeth >= (uint32_t)comb_xwide::TEETH ? (uint32_t)comb_xwide::SPACING : 448u / (4u * teeth);
+}
+__host__ __device__ constexpr uint32_t key_comb_entries(uint32_t teeth) { return key_comb_combs(teeth) << (teeth - 1); }
 __host__ __device__ constexpr uint32_t key_comb_u4(uint32_t teeth) { return 12u * key_comb_entries(teeth); }
 
 constexpr int KEY_COMBS_MAX = 1 << 17;     // the most keys of a batch that can have combs (62 KiB of workspace each)
@@ -529,7 +534,7 @@ GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slo
                           uint32_t *__restrict__ hash_slots, uint32_t hash_mask, uint32_t *__restrict__ ctrl,
                           const uint8_t *__restrict__ pk, uint32_t n, uint32_t seed);
 GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t pool_capacity, uint32_t comb_capacity,
-                            uint32_t comb_min_per_key, uint32_t wide_min_per_key);
+                            uint32_t comb_min_per_key, uint32_t wide_min_per_key, uint32_t xwide_min_per_key);
 GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                               const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk);
 extern "C" __global__ void k_verify_key_teeth(uint4 *__restrict__ teeth, uint8_t *__restrict__ key_ok,
@@ -550,6 +555,16 @@ GD_KERNEL k_ed448_verify_keycomb(const uint8_t *__restrict__ sig,
                                  uint4 *__restrict__ chain_state, uint32_t resume,
                                  const uint4 *__restrict__ qpark, uint32_t q_count);
 GD_KERNEL k_ed448_verify_keycomb_wide(const uint8_t *__restrict__ sig,
+                                 const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
+                                 const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
+                                 const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,
+                                 const uint4 *__restrict__ bwt, const uint32_t *__restrict__ rep,
+                                 const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,
+                                 const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
+                                 uint4 *__restrict__ park, const uint32_t *__restrict__ order,
+                                 uint4 *__restrict__ chain_state, uint32_t resume,
+                                 const uint4 *__restrict__ qpark, uint32_t q_count);
+GD_KERNEL k_ed448_verify_keycomb_xwide(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
                                  const uint8_t *__restrict__ ctx, uint32_t ctx_len, uint32_t n,

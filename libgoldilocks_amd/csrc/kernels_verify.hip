@@ -80,7 +80,7 @@ GD_KERNEL k_verify_dedupe(uint32_t *__restrict__ rep, uint32_t *__restrict__ slo
 }
 // ctrl[1], ctrl[2]: how this batch's keys are served (one thread, after the dedupe)
 GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t pool_capacity, uint32_t comb_capacity,
-                            uint32_t comb_min_per_key, uint32_t wide_min_per_key) {
+                            uint32_t comb_min_per_key, uint32_t wide_min_per_key, uint32_t xwide_min_per_key) {
     if (blockIdx.x || threadIdx.x) return;
     const uint32_t distinct = ctrl[0];
     uint32_t pooled = 0, combed = 0;
@@ -88,8 +88,14 @@ GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t po
     else if (2 * (uint64_t)distinct <= n && distinct <= pool_capacity) pooled = distinct;
     ctrl[1] = pooled;
     ctrl[2] = combed;
-    // teeth per comb: 8 (scalarmul.hpp comb_wide) for keys that sign hundreds of signatures each, else 7 (comb_big)
-    ctrl[3] = !combed ? 0u : wide_min_per_key && (uint64_t)distinct * wide_min_per_key <= n ? (uint32_t)comb_wide::TEETH : (uint32_t)comb_big::TEETH;
+    // teeth per comb: 9 (scalarmul.hpp comb_xwide, 5 combs) for keys that sign a thousand signatures each -- two
+    // thousand when the keys are more than 1 024: then their 1 280 entries each are a matter of throughput, not of one
+    // lane's latency (tests/wide_comb_probe.py) --, 8 (comb_wide) for hundreds, else 7 (comb_big)
+    const uint64_t xwide_from = (uint64_t)xwide_min_per_key * (distinct > 1024u ? 2u : 1u);
+    ctrl[3] = !combed ? 0u
+              : xwide_min_per_key && (uint64_t)distinct * xwide_from <= n ? (uint32_t)comb_xwide::TEETH
+              : wide_min_per_key && (uint64_t)distinct * wide_min_per_key <= n   ? (uint32_t)comb_wide::TEETH
+                                                                                 : (uint32_t)comb_big::TEETH;
 }
 GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                               const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk) {
@@ -130,7 +136,7 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
                                    const uint32_t *__restrict__ key_list, const uint8_t *__restrict__ pk) {
     const uint32_t combed = ctrl[2];
     if (combed <= (uint32_t)KEY_TEETH_BY_WAVE_MAX) return;
-    const int NT = 4 * (int)ctrl[3], spacing = 448 / NT;
+    const int NT = (int)(key_comb_combs(ctrl[3]) * ctrl[3]), spacing = (int)key_comb_spacing(ctrl[3]);
     const uint32_t stride = gridDim.x * BLOCK;
     for (uint32_t k = blockIdx.x * BLOCK + threadIdx.x; k < combed; k += stride) {
         uint32_t w[15];
@@ -162,7 +168,8 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain) {
     if (!ctrl[2]) return;                           // (ctrl[3] is 0 then: no geometry to derive)
-    const uint32_t teeth_per = ctrl[3], NT = 4 * teeth_per, per_comb = 1u << (teeth_per - 1), entries = 4 * per_comb;
+    const uint32_t teeth_per = ctrl[3], NT = key_comb_combs(teeth_per) * teeth_per, per_comb = 1u << (teeth_per - 1),
+                   entries = key_comb_entries(teeth_per);
     const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK;
     uint32_t SEG = (uint32_t)KEY_COMB_SEG;
     while (SEG < (uint32_t)KEY_COMB_SEG_MAX && (uint64_t)combed * (entries / SEG) > stride / 2) SEG *= 2;
@@ -375,6 +382,10 @@ __device__ __forceinline__ void verify_keycomb_body(const uint8_t *__restrict__ 
 GD_KERNEL k_ed448_verify_keycomb(KEYCOMB_ARGS) {        // keys with 7 teeth per comb (4 x 7 x 16)
     verify_keycomb_body<comb_big>(sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
                                   key_ok, ctrl, park, order, chain_state, resume, qpark, q_count);
+}
+GD_KERNEL k_ed448_verify_keycomb_xwide(KEYCOMB_ARGS) {  // keys with 9 (5 x 9 x 10): a thousand signatures per key
+    verify_keycomb_body<comb_xwide>(sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
+                                    key_ok, ctrl, park, order, chain_state, resume, qpark, q_count);
 }
 GD_KERNEL k_ed448_verify_keycomb_wide(KEYCOMB_ARGS) {   // keys with 8 (4 x 8 x 14): hundreds of signatures per key
     verify_keycomb_body<comb_wide>(sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,

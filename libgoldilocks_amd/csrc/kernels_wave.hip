@@ -109,7 +109,7 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_verify_key_teeth(uint4 *__
         if (me == 0) key_ok[k] = ok ? 1 : 0;
         wc::wfe P = wc::pack_point<0>(L, X, Y, Z, T);
         uint32_t *out = reinterpret_cast<uint32_t *>(teeth + (size_t)KEY_TEETH_U4 * k);
-        const int NT = 4 * (int)ctrl[3], spacing = 448 / NT;   // 7 teeth per comb, spacing 16, or 8 and 14 (k_verify_key_mode)
+        const int NT = (int)(key_comb_combs(ctrl[3]) * ctrl[3]), spacing = (int)key_comb_spacing(ctrl[3]);   // 4 x 7 teeth, spacing 16; 4 x 8, 14; 5 x 9, 10 (k_verify_key_mode)
 #pragma unroll 1
         for (int m = 0; m < NT; m++) {          // T_m, and 2 T_m (the first doubling towards T_(m+1)) behind the NT teeth
             out[64 * m + me] = wc::to_pniels(L, P, swap_row);

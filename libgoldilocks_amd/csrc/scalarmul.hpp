@@ -132,6 +132,9 @@ using comb_big = comb_plan<7, 4, 16>;
 // 4 combs of 8 teeth, spacing 14: 512 entries (96 KiB), 13 doublings + 55 additions -- for a verification key that signs
 // hundreds of a batch's signatures (kernels_verify.hip): twice the table to build, 9 % less to walk
 using comb_wide = comb_plan<8, 4, 14>;
+// 5 combs of 9 teeth, spacing 10 (450 bits): 1 280 entries (240 KiB), 9 doublings + 49 additions -- for a key that signs a
+// thousand of them: two and a half times the wide comb's table, another 10 % less to walk
+using comb_xwide = comb_plan<9, 5, 10>;
 
 template <class PLAN, class BITS>
 GD_FN uint32_t comb_teeth_of(const BITS &bits, int i, int j) {

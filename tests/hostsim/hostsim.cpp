@@ -465,6 +465,10 @@ int hs_ed448_verify_keycomb_wide(const uint8_t *sig, const uint8_t *pk, const ui
                                  const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
     return verify_keycomb_host<comb_wide>(sig, pk, msg, msglen, prehashed, ctx, ctxlen, comb_table);
 }
+int hs_ed448_verify_keycomb_xwide(const uint8_t *sig, const uint8_t *pk, const uint8_t *msg, size_t msglen, uint8_t prehashed,
+                                 const uint8_t *ctx, uint8_t ctxlen, const uint64_t *comb_table) {
+    return verify_keycomb_host<comb_xwide>(sig, pk, msg, msglen, prehashed, ctx, ctxlen, comb_table);
+}
 // the short pair of a challenge: rho (15 words), tau (8 words, two's complement)
 void hs_half_size_pair(uint32_t *rho, uint32_t *tau, const uint64_t *h) {
     wide15 r;

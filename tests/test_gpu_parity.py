@@ -389,7 +389,7 @@ def test_golden_f7_verify_torsion(ga):
     assert sum(len(v) for v in groups.values()) == 48
 
 
-@pytest.mark.parametrize("keys", ["combs", "wide combs", "pooled tables", "every lane for itself"])
+@pytest.mark.parametrize("keys", ["combs", "wide combs", "widest combs", "pooled tables", "every lane for itself"])
 def test_golden_f3_f7_through_the_large_batch_kernels(ga, keys):
     """Large batches verify through other kernels than small ones, and how a batch's keys repeat decides which
     (kernels_verify.hip: a fixed-base comb per key without R's decoding / a pooled window table per key / every lane
@@ -405,6 +405,7 @@ def test_golden_f3_f7_through_the_large_batch_kernels(ga, keys):
         ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT if keys != "every lane for itself" else 0, 4097)
         ga.set_verify_key_combs(ga.KEY_COMBS_DEFAULT if "combs" in keys else 0, 8)
         ga.set_verify_key_combs_wide(1 if keys == "wide combs" else 0)         # 8 teeth for every key / for none
+        ga.set_verify_key_combs_xwide(1 if keys == "widest combs" else 0)      # 5 combs of 9 teeth for every key / for none
         checked = 0
         for (ctx, ph), cs in groups.items():
             reps = -(-8192 // len(cs))
@@ -416,7 +417,7 @@ def test_golden_f3_f7_through_the_large_batch_kernels(ga, keys):
             want = np.array([cs[i]["verdict"] for i in order])
             assert (got == want).all(), sorted({cs[i]["kind"] for i in order[got != want]})
             nkeys = len({c["pk"] for c in cs})                                  # ... and the batch went the way it was meant to
-            assert ga.last_verify_key_counts(teeth=True) == {"combs": (nkeys, 0, nkeys, 7), "wide combs": (nkeys, 0, nkeys, 8),
+            assert ga.last_verify_key_counts(teeth=True) == {"combs": (nkeys, 0, nkeys, 7), "wide combs": (nkeys, 0, nkeys, 8), "widest combs": (nkeys, 0, nkeys, 9),
                                                              "pooled tables": (nkeys, nkeys, 0, 0), "every lane for itself": (0, 0, 0, 0)}[keys]
             checked += len(cs)
         assert checked == 256 + 48
@@ -424,9 +425,10 @@ def test_golden_f3_f7_through_the_large_batch_kernels(ga, keys):
         ga.set_verify_key_pool()
         ga.set_verify_key_combs()
         ga.set_verify_key_combs_wide()
+        ga.set_verify_key_combs_xwide()
 
 
-@pytest.mark.parametrize("keys", ["combs", "wide combs", "pooled tables", "every lane for itself"])
+@pytest.mark.parametrize("keys", ["combs", "wide combs", "widest combs", "pooled tables", "every lane for itself"])
 def test_degenerate_r_and_keys_through_the_large_batch_kernels(ga, O, keys):
     """The key-comb kernel tests R without decoding it (eddsa.hpp ed448_verify_keycomb_begin): x_R = L / K with
     K = 2 Y_P (2v - u - y^2 v) v y.  The encodings where that degenerates -- y_R = 0 (K = 0: the slow path decodes R after
@@ -453,15 +455,17 @@ def test_degenerate_r_and_keys_through_the_large_batch_kernels(ga, O, keys):
         ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT if keys != "every lane for itself" else 0, 4097)
         ga.set_verify_key_combs(ga.KEY_COMBS_DEFAULT if "combs" in keys else 0, 8)
         ga.set_verify_key_combs_wide(1 if keys == "wide combs" else 0)
+        ga.set_verify_key_combs_xwide(1 if keys == "widest combs" else 0)
         got = np.asarray(ga.ed448_verify_batch(sigs[order], pks[order], [m.tobytes() for m in msgs[order]]))
         assert (got == want48[order]).all(), sorted(set(order[got != want48[order]]))
         distinct, pooled, combed, teeth = ga.last_verify_key_counts(teeth=True)
-        assert (pooled, combed, teeth) == {"combs": (0, distinct, 7), "wide combs": (0, distinct, 8), "pooled tables": (distinct, 0, 0),
+        assert (pooled, combed, teeth) == {"combs": (0, distinct, 7), "wide combs": (0, distinct, 8), "widest combs": (0, distinct, 9), "pooled tables": (distinct, 0, 0),
                                            "every lane for itself": (0, 0, 0)}[keys]
     finally:
         ga.set_verify_key_pool()
         ga.set_verify_key_combs()
         ga.set_verify_key_combs_wide()
+        ga.set_verify_key_combs_xwide()
 
 
 def test_small_batches_of_few_keys_get_combs_by_default(ga, O):

@@ -102,7 +102,7 @@ def test_soak_sign_verify(ga, O):
     assert (st == want_st).all() and (st[~bad] == -1).all()
 
 
-@pytest.mark.parametrize("keys", ["combs", "wide combs", "pooled tables"])
+@pytest.mark.parametrize("keys", ["combs", "wide combs", "widest combs", "pooled tables"])
 def test_soak_verify_repeated_keys(ga, O, keys):
     """The verification kernels for keys that repeat in a batch (kernels_verify.hip: a comb per key and R not decoded /
     a pooled window table per key): 32 768 signatures of 64 keys, a bit flipped anywhere in a quarter of the
@@ -125,13 +125,15 @@ def test_soak_verify_repeated_keys(ga, O, keys):
         ga.set_verify_key_pool(ga.KEY_POOL_DEFAULT, 4097)
         ga.set_verify_key_combs(ga.KEY_COMBS_DEFAULT if "combs" in keys else 0, 2)
         ga.set_verify_key_combs_wide(1 if keys == "wide combs" else 0)
+        ga.set_verify_key_combs_xwide(1 if keys == "widest combs" else 0)
         st = ga.ed448_verify_batch(sig, pk, [m.tobytes() for m in msg], context=b"rk")
         distinct, pooled, combed, teeth = ga.last_verify_key_counts(teeth=True)
-        assert distinct > nk and (combed if "combs" in keys else pooled) == distinct and teeth == dict(combs=7).get(keys, 8 if "wide" in keys else 0)
+        assert distinct > nk and (combed if "combs" in keys else pooled) == distinct and teeth == {"combs": 7, "wide combs": 8, "widest combs": 9}.get(keys, 0)
     finally:
         ga.set_verify_key_pool()
         ga.set_verify_key_combs()
         ga.set_verify_key_combs_wide()
+        ga.set_verify_key_combs_xwide()
     want = np.empty(N, np.int32)
     ctx = (C.c_uint8 * 2).from_buffer_copy(b"rk")
     O.orc_ed448_verify_batch(_p(want), _p(sig), _p(pk), _p(msg), 40, 0, ctx, 2, N, _gen.NTHREADS)

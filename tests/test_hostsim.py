@@ -227,7 +227,7 @@ def test_mac_counts_match_bench(H, O):
     # 6 additions each and their normalisation (counted with ONE inversion per key; the device shares one between the
     # keys a lane serves)
     counts = {}
-    for wide, hook in ((False, H.hs_ed448_verify_keycomb), (True, H.hs_ed448_verify_keycomb_wide)):
+    for wide, hook in ((False, H.hs_ed448_verify_keycomb), (True, H.hs_ed448_verify_keycomb_wide), ("x", H.hs_ed448_verify_keycomb_xwide)):
         hook.restype = C.c_int
         seen = set()
         for i in range(3):
@@ -251,8 +251,12 @@ def test_mac_counts_match_bench(H, O):
     assert per_sig_wide == c["niels_to_pt"] + 55 * c["add_niels_t"] - 13 * 192 + 13 * c["dbl_t"] + rest
     assert (W["verify"]["macs_key_comb"], W["verify"]["macs_per_key_comb"]) == (per_sig, per_key)
     assert (W["verify"]["macs_key_comb_wide"], W["verify"]["macs_per_key_comb_wide"]) == (per_sig_wide, per_key_wide)
-    assert W["verify"]["macs"] == per_sig_wide + per_key_wide * W["verify"]["keys"] // 2**20      # 2^10 keys x 2^10 signatures: wide
-    assert per_sig_wide < per_sig < 0.30 * W["verify"]["macs_shared_keys"]
+    # ... and the widest, of keys with a thousand (5 x 9 x 10): 9 doublings + 49 additions
+    per_key_xwide, per_sig_xwide = counts["x"][0], counts["x"][1] + adjust
+    assert per_sig_xwide == c["niels_to_pt"] + 49 * c["add_niels_t"] - 9 * 192 + 9 * c["dbl_t"] + rest
+    assert (W["verify"]["macs_key_comb_xwide"], W["verify"]["macs_per_key_comb_xwide"]) == (per_sig_xwide, per_key_xwide), (per_sig_xwide, per_key_xwide)
+    assert W["verify"]["macs"] == per_sig_xwide + per_key_xwide * W["verify"]["keys"] // 2**20    # 2^10 keys x 2^10 signatures: the widest
+    assert per_sig_xwide < per_sig_wide < per_sig < 0.30 * W["verify"]["macs_shared_keys"]
 
 
 def test_big_comb_of_the_base_point_matches_oracle(H, O):
@@ -335,6 +339,7 @@ def test_verification_with_half_size_scalars(H, O):
     H.hs_ed448_verify_lattice_shared_key.restype = C.c_int
     H.hs_ed448_verify_keycomb.restype = C.c_int
     H.hs_ed448_verify_keycomb_wide.restype = C.c_int
+    H.hs_ed448_verify_keycomb_xwide.restype = C.c_int
     want = _gen.oracle_verify(O, sigs, pks, mlist)
     for i in range(n):
         m = (C.c_uint8 * len(mlist[i])).from_buffer_copy(mlist[i])
@@ -354,6 +359,9 @@ def test_verification_with_half_size_scalars(H, O):
         got = H.hs_ed448_verify_keycomb_wide(sigs[i].ctypes.data_as(C.c_void_p), pks[i].ctypes.data_as(C.c_void_p), m,
                                              C.c_size_t(len(mlist[i])), C.c_uint8(0), None, C.c_uint8(0), tab)
         assert got == want[i], ("wide key comb", i)
+        got = H.hs_ed448_verify_keycomb_xwide(sigs[i].ctypes.data_as(C.c_void_p), pks[i].ctypes.data_as(C.c_void_p), m,
+                                              C.c_size_t(len(mlist[i])), C.c_uint8(0), None, C.c_uint8(0), tab)
+        assert got == want[i], ("widest key comb", i)
     assert (want == -1).sum() >= 10 and (want == 0).sum() >= 10
     accepted = rejected = 0
     for c in f7:
@@ -368,6 +376,8 @@ def test_verification_with_half_size_scalars(H, O):
                                          C.c_uint8(len(ctx)), tab) == c["verdict"], ("key comb", c["kind"])
         assert H.hs_ed448_verify_keycomb_wide(sig, pk, mb, C.c_size_t(len(msg)), C.c_uint8(c["prehashed"]), cb,
                                               C.c_uint8(len(ctx)), tab) == c["verdict"], ("wide key comb", c["kind"])
+        assert H.hs_ed448_verify_keycomb_xwide(sig, pk, mb, C.c_size_t(len(msg)), C.c_uint8(c["prehashed"]), cb,
+                                               C.c_uint8(len(ctx)), tab) == c["verdict"], ("widest key comb", c["kind"])
         accepted += got == -1; rejected += got == 0
     assert accepted >= 4 and rejected >= 4
 
