@@ -381,7 +381,7 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
  * tests/key_pool_probe.py) and has at most `keys` distinct keys, in batches of more than 2^12
  * signatures (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the
  * combs off; 2^17 is the most and the default.  `keys` is a CEILING: a batch can use at most n / min_signatures_per_key
- * combs, so that is what a call reserves workspace for -- 64 KiB of device memory per such key (2^20 signatures: up to 2^17
+ * combs, so that is what a call reserves workspace for -- 71 KiB of device memory per such key (2^20 signatures: up to 2^17
  * keys, 8 GiB), never more than a quarter of the device's free memory, kept until goldilocks_amd_shutdown -- whatever the
  * batch's keys then turn out to be (the device decides; the call does not wait for it).  Turning the pool off
  * (goldilocks_amd_set_verify_key_pool(0, ..)) turns the combs off with it.  Process-wide. */
