@@ -382,7 +382,7 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
  * signatures (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the
  * combs off; 2^17 is the most and the default.  `keys` is a CEILING: a batch can use at most n / min_signatures_per_key
  * combs, so that is what a call reserves workspace for -- 71 KiB of device memory per such key (2^20 signatures: up to 2^17
- * keys, 8 GiB), never more than a quarter of the device's free memory, kept until goldilocks_amd_shutdown -- whatever the
+ * keys, 9 GiB), never more than a quarter of the device's free memory, kept until goldilocks_amd_shutdown -- whatever the
  * batch's keys then turn out to be (the device decides; the call does not wait for it).  Turning the pool off
  * (goldilocks_amd_set_verify_key_pool(0, ..)) turns the combs off with it.  Process-wide. */
 #define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 17)
