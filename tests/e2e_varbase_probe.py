@@ -1,3 +1,5 @@
+"""Manual probe: goldilocks_448_point_scalarmul_batch from host arrays, 2^20 operations, seven calls (profiles/r04/experiments.md N).
+   python tests/e2e_varbase_probe.py"""
 import os, sys, time, ctypes as C
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -15,4 +17,4 @@ for rep in range(7):
     rc = L.goldilocks_448_point_scalarmul_batch(ptr(out), ptr(bases), ptr(s), n)
     ts.append((time.perf_counter() - t0) * 1e3)
     assert rc == 0
-print(os.environ.get("GOLDILOCKS_AMD_VARBASE_LATER_CHUNKS", "3 (default)"), "later chunks: median %.2f ms  %s" % (sorted(ts)[3], " ".join("%.2f" % t for t in ts)), flush=True)
+print(os.environ.get("GOLDILOCKS_AMD_VARBASE_LATER_CHUNKS", "product"), "schedule: median %.2f ms  %s" % (sorted(ts)[3], " ".join("%.2f" % t for t in ts)), flush=True)

@@ -194,6 +194,11 @@ def test_host_array_pipeline_matches_fixture_and_ragged_tail(ga, O):
     # pipelined call runs one operation per wave, the single launch one per lane)
     enc = ga.point_encode_batch
     assert (enc(dout.cpu().numpy().view(np.uint64)) == enc(part)).all() and (enc(part) == enc(out[:n])).all()
+    # the schedule is a first and a last chunk of one residency and equal chunks of at most six between them: sizes
+    # with no middle, a middle of one operation's worth less than a residency, one and two middle chunks, ragged ones
+    want = enc(out)
+    for m in (2 * 131072 + 1, 3 * 131072 - 1, 3 * 131072, 4 * 131072 + 9, 7 * 131072 + 131071, N - 1):
+        assert (enc(ga.point_scalarmul_batch(bases[:m], s[:m])) == want[:m]).all(), m
 
 
 @pytest.mark.parametrize("keys", ["combs", "pooled", "distinct"])
