@@ -24,6 +24,7 @@
 #pragma once
 #include "point.hpp"
 #include "sc14.hpp"
+#include "gf28s.hpp"
 
 namespace gd {
 
@@ -35,26 +36,9 @@ constexpr int ML_BITS = 446;                // bits of q
 // that goes into the lane's shared inversion, once when the ladder runs) rather than parked in memory.
 GD_FN fe ml_denominator(const pt &b) { return fe_weak(fe_sub<2>(b.y, b.z)); }   // Y - Z: zero iff P is the identity
 
-// One ladder step on (x2 : z2) = k P, (x3 : z3) = (k+1) P (already swapped so that the pair to double is 2).
-GD_FN void ml_step(fe &x2, fe &z2, fe &x3, fe &z3, const fe &x1) {
-    fe t1 = fe_add(x2, z2);                         // A = x2 + z2            mag 2
-    fe t2 = fe_weak(fe_sub<2>(x2, z2));             // B = x2 - z2            mag 1
-    fe d = fe_sub<2>(x3, z3);                       // D = x3 - z3            mag 3 (times mag 2 only)
-    fe da = fe_mul(t1, d);                          // DA
-    fe c = fe_add(z3, x3);                          // C = x3 + z3            mag 2
-    fe cb = fe_mul(c, t2);                          // CB
-    fe dm = fe_weak(fe_sub<2>(da, cb));             // DA - CB                mag 1
-    z3 = fe_mul(x1, fe_sqr(dm));                    // z3 = x1 (DA - CB)^2
-    x3 = fe_sqr(fe_add(da, cb));                    // x3 = (DA + CB)^2       (input mag 2)
-    fe aa = fe_sqr(t1);                             // AA                     (input mag 2)
-    fe bb = fe_sqr(t2);                             // BB
-    fe caa = fe_mulw(aa, ML_C);                     // 39081 AA
-    fe e = fe_weak(fe_sub<2>(aa, bb));              // E = AA - BB            mag 1
-    x2 = fe_mul(caa, bb);                           // x2 = 39081 AA BB
-    z2 = fe_mul(fe_add(caa, e), e);                 // z2 = E (39081 AA + E)  (2 x 1)
-}
-
-// The same step with the conditional swap folded in.  Exchanging the two pairs exchanges DA and CB, so DA + CB and
+// One ladder step on (x2 : z2) = k P, (x3 : z3) = (k+1) P with the conditional swap folded in, on the UNSIGNED limbs of
+// gf28.hpp: the library's step until round 5, kept as the reference side of tools/stepbench's A/B (the kernels run
+// ml_step_sel_s below).  Exchanging the two pairs exchanges DA and CB, so DA + CB and
 // (DA - CB)^2 -- the new (x3 : z3) -- do not depend on the swap at all: only the pair that is DOUBLED has to be
 // selected, i.e. one sum and one difference (32 selects per step instead of 64).  The differences are selected
 // unreduced (mag 3: they multiply the other pair's sum, mag 2, as they are) and the selected one is reduced once.
@@ -76,12 +60,40 @@ GD_FN void ml_step_sel(fe &x2, fe &z2, fe &x3, fe &z3, const fe &x1, bool sw) {
     z2 = fe_mul(fe_add(caa, e), e);                                 // z2 = E (39081 AA + E)  (2 x 1)
 }
 
+// The same step on the signed, register-paired limbs of gf28s.hpp: no bias and no weak reduction behind a difference,
+// the sums of products added pair-wise.  The state stays in that form for all 446 steps.
+struct MlStateS {
+    sfp x2, z2, x3, z3;   // products: mag 1, pairable
+};
+GD_FN void ml_step_sel_s(MlStateS &st, const smultiplier &m1, bool sw) {
+    const sfp s2 = sfe_add(st.x2, st.z2), s3 = sfe_add(st.x3, st.z3);          // mag 2, pairable
+    const sfs d2 = sfe_sub(st.x2, st.z2), d3 = sfe_sub(st.x3, st.z3);          // mag 1, signed
+    const sfp da = sfe_mul(s2, d3);                                             // DA (or CB, swapped)     2 x 1
+    const sfp cb = sfe_mul(s3, d2);
+    const sfp t1 = sfe_select(s2, s3, sw);                                      // A = sum of the pair to double
+    const sfs t2 = sfe_select(d2, d3, sw);                                      // B = its difference
+    st.z3 = sfe_mul(sfe_sqr<false>(sfe_sub(da, cb)), m1);                       // z3 = x1 (DA - CB)^2
+    st.x3 = sfe_sqr<true>(sfe_add(da, cb));                                     // x3 = (DA + CB)^2        (sum of two products)
+    const sfp aa = sfe_sqr<true>(t1);                                           // AA                      (sum of two products)
+    const sfp bb = sfe_sqr<false>(t2);                                          // BB
+    const sfp caa = sfe_mulw(aa, (int32_t)ML_C);                                // 39081 AA
+    const sfs e = sfe_sub(aa, bb);                                              // E = AA - BB             mag 1, signed
+    st.x2 = sfe_mul(caa, bb);                                                   // x2 = 39081 AA BB
+    st.z2 = sfe_mul(sfe_add(caa, e), e);                                        // z2 = E (39081 AA + E)   2 x 1
+}
+
 // bits.word(k): k-th 32-bit word of the scalar, already reduced mod q (446 bits).
 // b: the base point; x1 = u(P) = (Y + Z)/(Y - Z) in affine form (anything if P is the identity or (0,-1)).
 template <class BITS>
 GD_FN pt ml_scalarmul_u(const pt &b, const fe &x1, const BITS &bits) {
     const fe yz = fe_add(b.y, b.z);                 // Y + Z                  mag 2
-    fe x2 = fe_one(), z2 = fe_zero(), x3 = x1, z3 = fe_one();
+    // the ladder's state lives in the signed, register-paired form of gf28s.hpp for all 446 steps
+    MlStateS st;
+    st.x2 = sfe_from_fe(fe_one());
+    st.z2 = sfe_from_fe(fe_zero());
+    st.x3 = sfe_from_fe(x1);
+    st.z3 = sfe_from_fe(fe_one());
+    const smultiplier m1 = s_multiplier(st.x3);     // x1's half sums are loop-invariant
     bool swap = false;
     // one read of the scalar per 32 steps: the word's next bit is kept in the sign position
 #pragma unroll 1
@@ -94,17 +106,11 @@ GD_FN pt ml_scalarmul_u(const pt &b, const fe &x1, const BITS &bits) {
             w <<= 1;
             const bool sw = swap != k_t;
             swap = k_t;
-#if defined(GD_ML_FULL_SWAP)
-            fe a2 = fe_select(x2, x3, sw), a3 = fe_select(x3, x2, sw);
-            fe c2 = fe_select(z2, z3, sw), c3 = fe_select(z3, z2, sw);
-            ml_step(a2, c2, a3, c3, x1);
-            x2 = a2; z2 = c2; x3 = a3; z3 = c3;
-#else
-            ml_step_sel(x2, z2, x3, z3, x1, sw);
-#endif
+            ml_step_sel_s(st, m1, sw);
         }
     }
-    // (X1 : Z1) = u(sP), (X2 : Z2) = u((s+1)P)
+    // (X1 : Z1) = u(sP), (X2 : Z2) = u((s+1)P), back in the unsigned form (mag 1)
+    const fe x2 = sfe_to_fe(st.x2), z2 = sfe_to_fe(st.z2), x3 = sfe_to_fe(st.x3), z3 = sfe_to_fe(st.z3);
     const fe X1 = fe_select(x2, x3, swap), Z1 = fe_select(z2, z3, swap);
     const fe X2 = fe_select(x3, x2, swap), Z2 = fe_select(z3, z2, swap);
     const bool q_trivial = fe_is_zero(X1) | fe_is_zero(Z1);     // '|', not '||': no branch on the scalar

@@ -4,6 +4,7 @@
 //   goldilocks_x448_derive_public_key     src/goldilocks.c:1115-1141   fixed-base comb + (y/x)^2
 #pragma once
 #include "scalarmul.hpp"
+#include "gf28s.hpp"
 
 namespace gd {
 
@@ -16,7 +17,9 @@ template <class BITS>
 GD_FN void x448_ladder(fe &rx, fe &rz, const uint32_t base[14], const BITS &bits) {
     fe x1;
     (void)fe_deserialize_words(x1, base);   // the reference ignores the range check too (:1014)
-    fe x2 = fe_one(), z2 = fe_zero(), x3 = x1, z3 = fe_one();
+    // the state stays in the signed, register-paired form of gf28s.hpp (no bias, no weak reduction behind a difference)
+    sfp x2 = sfe_from_fe(fe_one()), z2 = sfe_from_fe(fe_zero()), x3 = sfe_from_fe(x1), z3 = sfe_from_fe(fe_one());
+    const smultiplier m1 = s_multiplier(x3);
     bool swap = false;
 #pragma unroll 1
     for (int t = 447; t >= 0; t--) {
@@ -27,26 +30,26 @@ GD_FN void x448_ladder(fe &rx, fe &rz, const uint32_t base[14], const BITS &bits
         const bool sw = swap != k_t;
         swap = k_t;
         // Exchanging the two pairs exchanges DA and CB: DA + CB and (DA - CB)^2 do not depend on the swap, only the
-        // pair that is doubled is selected -- one sum and one (unreduced) difference, 32 selects per step, not 64
-        // (montgomery.hpp ml_step_sel).
-        const fe s2 = fe_add(x2, z2), s3 = fe_add(x3, z3);          // mag 2
-        const fe d2 = fe_sub<2>(x2, z2), d3 = fe_sub<2>(x3, z3);    // mag 3 (only multiplied by mag 2)
-        fe da = fe_mul(s2, d3);                         // DA (or CB: the same pair)
-        fe cb = fe_mul(s3, d2);
-        fe t1 = fe_select(s2, s3, sw);                  // A = x2 + z2 of the pair to double      mag 2
-        fe t2 = fe_weak(fe_select(d2, d3, sw));         // B = x2 - z2                            mag 1
-        fe dm = fe_weak(fe_sub<2>(da, cb));             // +-(DA - CB)            mag 1
-        z3 = fe_mul(x1, fe_sqr(dm));                    // z3 = x1 (DA-CB)^2
-        x3 = fe_sqr(fe_add(da, cb));                    // x3 = (DA+CB)^2   (input mag 2)
-        fe aa = fe_sqr(t1);                             // AA   (input mag 2)
-        fe bb = fe_sqr(t2);                             // BB
-        x2 = fe_mul(aa, bb);
-        fe e = fe_sub<2>(aa, bb);                       // E = AA - BB            mag 3 (mulw, and times f: 2 x 3)
-        fe f = fe_add(fe_mulw(e, 39081), aa);           // AA + a24 E             mag 2
-        z2 = fe_mul(f, e);
+        // pair that is doubled is selected -- one sum and one difference, 32 selects per step, not 64
+        // (montgomery.hpp ml_step_sel_s).
+        const sfp s2 = sfe_add(x2, z2), s3 = sfe_add(x3, z3);          // mag 2, pairable
+        const sfs d2 = sfe_sub(x2, z2), d3 = sfe_sub(x3, z3);          // mag 1, signed
+        const sfp da = sfe_mul(s2, d3);                 // DA (or CB: the same pair)
+        const sfp cb = sfe_mul(s3, d2);
+        const sfp t1 = sfe_select(s2, s3, sw);          // A = x2 + z2 of the pair to double
+        const sfs t2 = sfe_select(d2, d3, sw);          // B = x2 - z2
+        z3 = sfe_mul(sfe_sqr<false>(sfe_sub(da, cb)), m1);   // z3 = x1 (DA-CB)^2
+        x3 = sfe_sqr<true>(sfe_add(da, cb));            // x3 = (DA+CB)^2
+        const sfp aa = sfe_sqr<true>(t1);               // AA
+        const sfp bb = sfe_sqr<false>(t2);              // BB
+        x2 = sfe_mul(aa, bb);
+        const sfs e = sfe_sub(aa, bb);                  // E = AA - BB            mag 1, signed
+        const sfp f = sfe_add(sfe_mulw(e, 39081), aa);  // AA + a24 E             mag 2
+        z2 = sfe_mul(f, e);
     }
-    rx = fe_select(x2, x3, swap);
-    rz = fe_select(z2, z3, swap);
+    const fe x2u = sfe_to_fe(x2), z2u = sfe_to_fe(z2), x3u = sfe_to_fe(x3), z3u = sfe_to_fe(z3);
+    rx = fe_select(x2u, x3u, swap);
+    rz = fe_select(z2u, z3u, swap);
 }
 GD_FN bool x448_finish(uint32_t out[14], const fe &rx, const fe &rzi) {
     fe r = fe_mul(rx, rzi);

@@ -194,6 +194,21 @@ static int verify_keycomb_host(const uint8_t *sig, const uint8_t *pk, const uint
     return verdict ? -1 : 0;
 }
 
+// ---- the signed, register-paired layer (gf28s.hpp) at its documented limits.  An operand is k copies of a field
+// element added limb-wise (pair-wise when k > 0: "pairable"), or its limb-wise negative (k < 0: "signed").
+template <class F>
+static void with_signed_operand(const uint64_t *a, int k, F f) {
+    const sfp x = sfe_from_fe(fe_weak(fe_from_limbs56(a)));
+    if (k > 0) {
+        sfp xs = x;
+        for (int i = 1; i < k; i++) xs = sfe_add(xs, x);
+        f(xs);
+    } else {
+        sfs xs = sfe_sub(sfe_from_fe(fe_zero()), x);
+        for (int i = 1; i < -k; i++) xs = sfe_sub(xs, x);
+        f(xs);
+    }
+}
 extern "C" {
 
 void hs_fe_mul(uint64_t *o, const uint64_t *a, const uint64_t *b) {
@@ -232,6 +247,37 @@ void hs_fe_sqr_mag(uint64_t *o, const uint64_t *a, int ma) {
     fe x = fe_weak(fe_from_limbs56(a)), xs = fe_zero();
     for (int i = 0; i < ma; i++) xs = fe_add(xs, x);
     fe_to_limbs56(o, fe_sqr(xs));
+}
+
+void hs_sfe_mul_mag(uint64_t *o, const uint64_t *a, const uint64_t *b, int ka, int kb) {
+    with_signed_operand(a, ka, [&](const auto &xs) {
+        with_signed_operand(b, kb, [&](const auto &ys) { fe_to_limbs56(o, sfe_to_fe(sfe_mul(xs, ys))); });
+    });
+}
+// sum2 = 0: the plain square; 1: the square of a sum of two products (columns 0..2 of the high half read unsigned)
+void hs_sfe_sqr_mag(uint64_t *o, const uint64_t *a, int ka, int sum2) {
+    if (sum2) {
+        const sfp x = sfe_from_fe(fe_weak(fe_from_limbs56(a)));
+        sfp xs = x;
+        for (int i = 1; i < ka; i++) xs = sfe_add(xs, x);
+        fe_to_limbs56(o, sfe_to_fe(sfe_sqr<true>(xs)));
+    } else {
+        with_signed_operand(a, ka, [&](const auto &xs) { fe_to_limbs56(o, sfe_to_fe(sfe_sqr<false>(xs))); });
+    }
+}
+void hs_sfe_mulw_mag(uint64_t *o, const uint64_t *a, int ka, uint32_t w) {
+    with_signed_operand(a, ka, [&](const auto &xs) { fe_to_limbs56(o, sfe_to_fe(sfe_mulw(xs, (int32_t)w))); });
+}
+// (a - b) * c and (a - b)^2 the way the ladder forms them: a difference of two products, no bias, no reduction
+void hs_sfe_diff_mul(uint64_t *o, const uint64_t *a, const uint64_t *b, const uint64_t *c) {
+    const sfp x = sfe_mul(sfe_from_fe(fe_weak(fe_from_limbs56(a))), sfe_from_fe(fe_one()));
+    const sfp y = sfe_mul(sfe_from_fe(fe_weak(fe_from_limbs56(b))), sfe_from_fe(fe_one()));
+    const sfs d = sfe_sub(x, y);
+    const sfp z = sfe_from_fe(fe_weak(fe_from_limbs56(c)));
+    fe_to_limbs56(o, sfe_to_fe(sfe_mul(sfe_add(z, z), d)));       // sum x difference
+    fe_to_limbs56(o + 8, sfe_to_fe(sfe_sqr<false>(d)));
+    fe_to_limbs56(o + 16, sfe_to_fe(sfe_sqr<true>(sfe_add(x, y))));
+    fe_to_limbs56(o + 24, sfe_to_fe(sfe_mul(sfe_add(sfe_mulw(d, 39081), x), d)));   // x448's f * e
 }
 
 void hs_sc_recode(uint64_t *o, const uint64_t *s) { sc_to_abi(o, sc_recode_signed(sc_from_abi(s))); }

@@ -59,6 +59,56 @@ def test_field_and_magnitude_contract(H, O):
         bs = (C.c_uint8 * 56)(); H.hs_fe_serialize(bs, C.byref(a)); assert bytes(bs) == _ser(O, a)
 
 
+def _signed_cases(rnd):
+    allones = Gf()
+    for i in range(8):
+        allones.limb[i] = (1 << 56) - 1
+    return [Gf.from_int(rnd.getrandbits(448) % P) for _ in range(150)] + [allones, Gf.from_int(0), Gf.from_int(1), Gf.from_int(P - 1)]
+
+
+def test_signed_paired_field_layer_at_its_limits(H):
+    """gf28s.hpp (the ladders' field layer) under the checker: signed 64-bit finished columns, 32-bit pre-added halves,
+    pair-wise additions whose low halves must not carry -- at the magnitudes its header documents, with the all-ones
+    element (every limb 2^28 - 1) among the operands."""
+    rnd = random.Random(5)
+    cases = _signed_cases(rnd)
+    for a in cases:
+        b = cases[rnd.randrange(len(cases))]
+        c = cases[rnd.randrange(len(cases))]
+        o = Gf()
+        for ka, kb in ((1, 1), (2, 1), (1, 2), (3, 1), (2, -1), (-1, 2), (-1, -1), (-2, 1), (1, -2), (3, -1), (-3, 1)):
+            H.hs_sfe_mul_mag(C.byref(o), C.byref(a), C.byref(b), ka, kb)
+            assert o.value() == a.value() * b.value() * ka * kb % P, (ka, kb)
+        for ka, sum2 in ((1, 0), (-1, 0), (1, 1), (2, 1)):
+            H.hs_sfe_sqr_mag(C.byref(o), C.byref(a), ka, sum2)
+            assert o.value() == (ka * a.value()) ** 2 % P, (ka, sum2)
+        for ka in (1, 2, 3, -1, -2):
+            w = rnd.getrandbits(18)
+            H.hs_sfe_mulw_mag(C.byref(o), C.byref(a), ka, w)
+            assert o.value() == ka * a.value() * w % P
+        o4 = (Gf * 4)()
+        H.hs_sfe_diff_mul(o4, C.byref(a), C.byref(b), C.byref(c))
+        d = a.value() - b.value()
+        assert o4[0].value() == 2 * c.value() * d % P
+        assert o4[1].value() == d * d % P
+        assert o4[2].value() == (a.value() + b.value()) ** 2 % P
+        assert o4[3].value() == (39081 * d + a.value()) * d % P
+
+
+@pytest.mark.parametrize("call", ["H.hs_sfe_sqr_mag(o, a, 2, 0)",        # a sum of two products through the plain square
+                                  "H.hs_sfe_mul_mag(o, a, a, 2, 2)",      # sum x sum
+                                  "H.hs_sfe_sqr_mag(o, a, 3, 1)"])
+def test_signed_layer_checker_traps_beyond_the_contract(H, call):
+    """The checker is not vacuous: the same entry points abort (SIGILL from __builtin_trap) one step beyond the limits."""
+    import sys
+    code = ("import ctypes as C, sys; sys.path.insert(0, %r); from _libs import Gf\n"
+            "H = C.CDLL(%r); a = Gf()\n"
+            "for i in range(8): a.limb[i] = (1 << 56) - 1\n"
+            "o = Gf(); a = C.byref(a); o = C.byref(o)\n%s\n") % (os.path.dirname(os.path.abspath(__file__)), H._name, call)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True)
+    assert r.returncode < 0, (call, r.returncode, r.stderr[-500:])
+
+
 def test_scalars(H, O):
     rnd = random.Random(3)
     for it in range(100):
