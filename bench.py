@@ -55,7 +55,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 LOG2_BATCH = 20
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-VALU_MAC_PEAK = 36.0e12     # measured: 560-576 G v_mad_u64_u32 wave-instr/s x 64 lanes (profiles/r01/ubench.txt)
+# The integer-multiply ceiling: the best issue rate tools/ubench measured for ANY quarter-rate VALU instruction on this
+# part, 600 G wave-instructions/s (v_mul_u32_u24 599.8, v_mul_hi_u32 596; profiles/r01/ubench.txt, 8 waves per SIMD) x 64
+# lanes.  The multiply-accumulates themselves top out lower (v_mad_i64_i32 589 G = 37.7 T, v_mad_u64_u32 579 G = 37.0 T); the
+# paper figure is 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T.  All three are on the line (roofline.mac.peaks).
+VALU_MAC_PEAK = 38.4e12
+VALU_MAC_PEAKS = {"used": "best_issue_rate_measured", "best_issue_rate_measured": 38.4, "v_mad_i64_i32_measured": 37.7,
+                  "v_mad_u64_u32_measured": 37.0, "paper_quarter_rate_at_2.4GHz": 39.3, "unit": "T MAC/s",
+                  "source": "profiles/r01/ubench.txt (tools/ubench.hip, wall clock)"}
 
 # Per-workload figures.  bytes: algorithmic I/O per op.  macs: 32x32->64 multiply-
 # accumulates per op, counted by the host checker build of the same lane code
@@ -621,7 +628,7 @@ def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_t
     if spec["macs"]:
         macs = spec["macs"] * n / (avg_ms * 1e-3)
         r["mac"] = {"achieved": macs / 1e12, "peak": VALU_MAC_PEAK / 1e12, "unit": "T MAC/s",
-                    "frac": macs / VALU_MAC_PEAK, "macs_per_op": spec["macs"]}
+                    "frac": macs / VALU_MAC_PEAK, "macs_per_op": spec["macs"], "peaks": VALU_MAC_PEAKS}
     return r
 
 
@@ -651,12 +658,14 @@ def run_stub(args, shard, rank, world):
 
 
 # the other BASELINE configs on the default line: (key, workload, table access of its calls)
-CONFIGS = (("fixed", "fixed", "index-independent"),          # config 3: a caller's comb table, staged in LDS
-           ("base", "base", "index-independent"),            # ... the built-in base point, library default
-           ("verify", "verify", "index-independent"),        # config 4 (public data: the mode changes nothing)
-           ("verify_distinct_keys", "verify_distinct", "index-independent"),   # ... when no key repeats
-           ("varbase_fast", "varbase", "fast"),              # the opt-in for public scalars
-           ("base_fast", "base", "fast"))
+# (key, workload, table access, base-table digits: 0 = the library's default, 20 bits / 2.2 GiB)
+CONFIGS = (("fixed", "fixed", "index-independent", 0),          # config 3: a caller's comb table, staged in LDS
+           ("base", "base", "index-independent", 0),            # ... the built-in base point, library default
+           ("verify", "verify", "index-independent", 0),        # config 4 (public data: the mode changes nothing)
+           ("verify_distinct_keys", "verify_distinct", "index-independent", 0),   # ... when no key repeats
+           ("varbase_fast", "varbase", "fast", 0),              # the opt-in for public scalars
+           ("base_fast", "base", "fast", 0),
+           ("verify_table24", "verify", "index-independent", 24))   # config 4 with the opt-in 24-bit table (28.5 GiB)
 
 
 def run_rank(args):
@@ -711,6 +720,8 @@ def run_rank(args):
                        "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],
                        # digits of the base point's window table on this device (0: this workload never asked for it)
                        "base_table_bits": ga.get_base_table_bits(),
+                       # what the library holds on the device after the timed steps (workspace + staging + tables)
+                       "device_memory_bytes": ga.device_info()["workspace_bytes"],
                        "parity_spot_check": "ok" if ok else "FAILED", "check": check},
             "per_gpu": [dict({"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
                               "kernel_ms_avg": r[3], "batch": int(r[4])},
@@ -725,7 +736,8 @@ def run_rank(args):
     # the other BASELINE configs, a few steps each (default single-GPU run of the headline only)
     if default_line and not args.no_configs:
         configs = {}
-        for key, cname, access in CONFIGS:
+        for key, cname, access, table_bits in CONFIGS:
+            ga.set_base_table_bits(table_bits)
             cw = make_workload(cname, cx, access)
             # The clocks of a GPU that idled (building a workload's input leaves it idle for tens of milliseconds) take
             # 40 - 50 ms of load to come back up (profiles/r04/experiments.md G: a verification step behind 20 ms of
@@ -750,11 +762,16 @@ def run_rank(args):
                             "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit", "traffic_measured_on", "traffic_stale",
                                                                "traffic_of_base_table_gathers", "traffic_note") if k in r},
                             "mac_frac": r["mac"]["frac"] if "mac" in r else None, "macs_per_op": r["mac"]["macs_per_op"] if "mac" in r else None,
-                            "base_table_bits": ga.get_base_table_bits(), "check": ctext,
+                            "base_table_bits": ga.get_base_table_bits(), "base_table_bits_is_library_default": table_bits == 0,
+                            # what the library holds on the device now (workspace + staging + the base point's table)
+                            "device_memory_bytes": ga.device_info()["workspace_bytes"], "check": ctext,
                             "parity_spot_check": "ok" if cok else "FAILED"}
             ok = ok and cok
             samples[key] = cw["sample"]()
             del cw
+            if table_bits:                       # an opt-in table goes again: the next config sees the default's footprint
+                ga.set_base_table_bits(0)
+                ga.release_memory(ga.RELEASE_BASE_TABLE)
         line["configs"] = configs
 
     if default_line and not args.no_end_to_end:

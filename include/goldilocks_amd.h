@@ -381,13 +381,17 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
  * tests/key_pool_probe.py) and has at most `keys` distinct keys, in batches of more than 2^12
  * signatures (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the
  * combs off; 2^17 is the most and the default.  `keys` is a CEILING: a batch can use at most n / min_signatures_per_key
- * combs, so that is what a call reserves workspace for -- 71 KiB of device memory per such key (2^20 signatures: up to 2^17
- * keys, 9 GiB), never more than a quarter of the device's free memory, kept until goldilocks_amd_shutdown -- whatever the
- * batch's keys then turn out to be (the device decides; the call does not wait for it).  Turning the pool off
+ * combs, so that is what a call reserves workspace for -- 71 KiB of device memory per such key, never more than
+ * goldilocks_amd_set_verify_key_combs_bytes (4 GiB by default: 59 000 keys) nor than a quarter of the device's free memory,
+ * kept until goldilocks_amd_shutdown -- whatever the batch's keys then turn out to be (the device decides; the call does
+ * not wait for it).  A batch with more distinct keys than fit is served by the pool's rules.  Turning the pool off
  * (goldilocks_amd_set_verify_key_pool(0, ..)) turns the combs off with it.  Process-wide. */
 #define GOLDILOCKS_AMD_KEY_COMBS_DEFAULT (1u << 17)
 #define GOLDILOCKS_AMD_KEY_COMBS_MIN_PER_KEY_DEFAULT 8
 GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs(size_t keys, size_t min_signatures_per_key);
+/* the ceiling on the workspace a call reserves for per-key combs (2^17 keys, the most the library serves, take 9 GiB) */
+#define GOLDILOCKS_AMD_KEY_COMBS_BYTES_DEFAULT ((size_t)4 << 30)
+GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_bytes(size_t bytes);
 /* ... and keys that sign at least this many signatures of the batch on average get the wider comb (4 x 8 x 14, 96 KiB:
  * twice the entries to build, 9 % less to walk per signature).  0: never.  Process-wide. */
 #define GOLDILOCKS_AMD_KEY_COMBS_WIDE_MIN_PER_KEY_DEFAULT 256
@@ -403,11 +407,22 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_xwide(size_t min_sig
  * needs it (tens of milliseconds) and keeps it until goldilocks_amd_shutdown.  Wider digits trade device memory for
  * additions: 16 bits = 27 additions from 168 MiB (Infinity-Cache resident), 18 = 24 from 600 MiB, 20 = 22 from 2.2 GiB,
  * 22 = 20 from 7.9 GiB, 24 = 18 from 28.5 GiB of HBM (2^20 verifications of distinct signatures on 2^10 keys: 8.10 / - /
- * 7.86 / 7.72 / 7.59 ms; base-point multiplications with digit-addressed tables: 498 / 503 / 532 / 571 / 610 M/s).  bits = 0 (the default, or the
- * environment's GOLDILOCKS_AMD_BASE_TABLE_BITS): the widest whose table takes at most an eighth of the device memory free
- * at that first call, never below 16 -- 24 bits on an otherwise empty MI355X.  Any even width from 8 to 24 may be asked
- * for.  Process-wide; a device whose table has another width rebuilds it at its next such call.  Results do not
- * depend on the width.  Returns 0, or 1 for a width that does not exist. */
+ * 7.86 / 7.72 / 7.59 ms; base-point multiplications with digit-addressed tables: 498 / 503 / 532 / 571 / 610 M/s).
+ * bits = 0 (the default) is GOLDILOCKS_AMD_BASE_TABLE_BITS_DEFAULT = 20: 2.2 GiB whatever else the device holds -- the
+ * wider tables buy 2 - 4 % for up to 26 GiB more and are the caller's decision.  GOLDILOCKS_AMD_BASE_TABLE_BITS_AUTO asks
+ * for the widest whose table takes at most an eighth of the device memory free at that first call, never below 16 (24 bits
+ * on an otherwise empty MI355X).  Any even width from 8 to 24 may be asked for.  The environment's
+ * GOLDILOCKS_AMD_BASE_TABLE_BITS (a width, or "auto") sets the process's initial request.  Process-wide; a device whose
+ * table has another width rebuilds it at its next such call (which then waits for the device, also on the
+ * stream-asynchronous _dev entry points: hipDeviceSynchronize + the build).  Results do not depend on the width.
+ * Returns 0, or 1 for a width that does not exist.
+ *
+ * DEVICE MEMORY THE LIBRARY HOLDS at these defaults, until goldilocks_amd_shutdown or goldilocks_amd_release_memory:
+ * the base point's table 2.2 GiB + the workspace, which grows with the largest batch seen: at most 6 GiB for 2^20
+ * verifications (the per-key combs' ceiling above included), 128 MiB for 2^20 variable-base multiplications -- 8.5 GiB in
+ * all, asserted by tests/test_gpu_base_table.py -- + the host-array entry points' staging (1.2 x the batch's bytes). */
+#define GOLDILOCKS_AMD_BASE_TABLE_BITS_DEFAULT 20
+#define GOLDILOCKS_AMD_BASE_TABLE_BITS_AUTO 1
 GOLDILOCKS_AMD_API int goldilocks_amd_set_base_table_bits(int bits);
 /* the width of the table the calling thread's device holds (0: none built yet) */
 GOLDILOCKS_AMD_API int goldilocks_amd_get_base_table_bits(void);
@@ -422,7 +437,7 @@ GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, i
         size_t *workspace_bytes);
 /* Gives device memory of the calling thread's device back without ending the context: the library keeps its workspace
  * (sized by the largest batch so far: 10 GiB after 2^20 verifications), the staging buffers of the host-array entry points
- * and the base point's window table (28.5 GiB by default) from their first use until goldilocks_amd_shutdown, because
+ * and the base point's window table (2.2 GiB by default) from their first use until goldilocks_amd_shutdown, because
  * allocating them costs milliseconds per call.  A service that is done with a burst can release any of them; the next call
  * that needs one allocates (and, for the table, builds: 0.16 s) it again.  Waits for the device.  Returns 0 on success. */
 #define GOLDILOCKS_AMD_RELEASE_WORKSPACE 1u

@@ -90,6 +90,7 @@ FUNCTIONS = {
     "goldilocks_amd_set_verify_key_pool": (None, "zz"),
     "goldilocks_amd_set_verify_key_combs": (None, "zz"),
     "goldilocks_amd_set_verify_key_combs_wide": (None, "z"),
+    "goldilocks_amd_set_verify_key_combs_bytes": (None, "z"),
     "goldilocks_amd_set_verify_key_combs_xwide": (None, "z"),
     "goldilocks_amd_set_base_table_bits": (C.c_int, "i"),
     "goldilocks_amd_get_base_table_bits": (C.c_int, ""),
@@ -483,8 +484,17 @@ def set_verify_key_combs_xwide(min_signatures_per_key=KEY_COMBS_XWIDE_MIN_PER_KE
     lib().goldilocks_amd_set_verify_key_combs_xwide(int(min_signatures_per_key))
 
 
+BASE_TABLE_BITS_DEFAULT, BASE_TABLE_BITS_AUTO = 20, 1
+
+
+def set_verify_key_combs_bytes(nbytes=4 << 30):
+    """Ceiling on the workspace a verification reserves for per-key combs (71 KiB per key)."""
+    lib().goldilocks_amd_set_verify_key_combs_bytes(int(nbytes))
+
+
 def set_base_table_bits(bits=0):
-    """Digit width of the base point's window table (0: by the device's free memory; an even width from 8 to 24)."""
+    """Digit width of the base point's window table: 0 = the default (20 bits, 2.2 GiB), BASE_TABLE_BITS_AUTO = the widest
+    that takes at most an eighth of the device's free memory, or an even width from 8 to 24."""
     if lib().goldilocks_amd_set_base_table_bits(int(bits)) != 0:
         raise ValueError(lib().goldilocks_amd_last_error().decode())
 

@@ -37,6 +37,10 @@ constexpr int PRECOMP_U4 = 80 * 20 + 64;  // uint4 per lane for k_precompute: 80
 // (fixed_bodies.hpp): numerator(s) | denominator | prefix product [| nonce | secret scalar]
 constexpr int DERIVE_SLOT_U4 = 16, SIGN_SLOT_U4 = 24, X448_SLOT_U4 = 12;
 constexpr int ML_SLOT_U4 = 8;   // the table-free variable-base ladder: denominator | prefix product
+// the two-ladder kernels park the FIRST product of an operation in its slots (free once the chain has been popped) until
+// every input of the operation has been read: any output may then alias any input, as in the reference
+constexpr int ML_DUAL_SLOT_U4 = 16;     // point_dual_scalarmul: chain slot, later s2 * P (one point = 16 uint4)
+constexpr int ML_DOUBLE_SLOT_U4 = 24;   // point_double_scalarmul: two chain slots, later s2 * b2 | 1/(Y1 - Z1)
 constexpr int SHARED_INV_OPS_PER_LANE = 8;   // a launch covers at most this many operations per resident lane
 constexpr uint64_t MAX_MESSAGE_BYTES = 0x7fffff00ull;   // GOLDILOCKS_AMD_MAX_MESSAGE_BYTES: byte counters are 32-bit
 
@@ -176,6 +180,20 @@ __device__ __forceinline__ void lds_wipe_lane(uint32_t *slot, int words) {
     for (int k = 0; k < words; k++) slot[k * BLOCK] = 0;
 }
 
+__device__ __forceinline__ void pt_store_u4(uint4 *q, const pt &p) {   // a point parked in workspace: 16 uint4
+    fe_store(q, p.x);
+    fe_store(q + 4, p.y);
+    fe_store(q + 8, p.z);
+    fe_store(q + 12, p.t);
+}
+__device__ __forceinline__ pt pt_load_u4(const uint4 *q) {
+    pt p;
+    p.x = fe_load(q);
+    p.y = fe_load(q + 4);
+    p.z = fe_load(q + 8);
+    p.t = fe_load(q + 12);
+    return p;
+}
 __device__ __forceinline__ void pniels_store(uint4 *q, const pniels &e) {
     fe_store(q, e.a);
     fe_store(q + 4, e.b);
@@ -510,7 +528,7 @@ GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__
 GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
                              const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                              uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt);
-GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                    uint4 *__restrict__ workspace);
 GD_KERNEL k_point_encode_eddsa_shared(uint8_t *__restrict__ enc, const uint64_t *__restrict__ pts, uint32_t n,
@@ -611,7 +629,7 @@ GD_KERNEL k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restric
 GD_KERNEL k_point_dual_scalarmul(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
                                  const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                  uint4 *__restrict__ workspace);
-GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
+GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *out2, const uint64_t *base,
                                        const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                        uint4 *__restrict__ workspace);
 GD_KERNEL k_point_from_hash(uint64_t *__restrict__ out, const uint8_t *__restrict__ hash, uint32_t n, int uniform);

@@ -16,13 +16,13 @@ GD_KERNEL k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restric
     direct_scalarmul_ladder_body(scaled, status, base, scalar, n, allow_identity, short_circuit, point_base_abi);
 }
 
-GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
+GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *out2, const uint64_t *base,
                                     const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                     uint4 *__restrict__ workspace) {
     point_dual_scalarmul_ladder_body(out1, out2, base, s1, s2, n, workspace);
 }
 
-GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
                                 const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                 uint4 *__restrict__ workspace) {
     double_scalarmul_ladder_body(out, b1, s1, b2, s2, n, workspace);

@@ -226,8 +226,10 @@ __device__ __forceinline__ void direct_scalarmul_ladder_body(uint8_t *__restrict
 }
 
 // "next" row f4, index-independent: two ladders from one u(P); the inversion behind it is shared along the lane
-// as in the headline kernel (ML_SLOT_U4 uint4 of workspace per operation).  out1 may alias base.
-__device__ __forceinline__ void point_dual_scalarmul_ladder_body(uint64_t *out1, uint64_t *__restrict__ out2,
+// as in the headline kernel.  ML_DUAL_SLOT_U4 uint4 of workspace per operation: the chain's slot, which -- popped --
+// holds s2 * P until s1 * P is there as well and both are written: out1 and out2 may alias base (the reference
+// computes into temporaries, src/goldilocks.c:543-642).
+__device__ __forceinline__ void point_dual_scalarmul_ladder_body(uint64_t *out1, uint64_t *out2,
                                                                  const uint64_t *base, const uint64_t *__restrict__ s1,
                                                                  const uint64_t *__restrict__ s2, uint32_t n,
                                                                  uint4 *__restrict__ workspace) {
@@ -235,30 +237,37 @@ __device__ __forceinline__ void point_dual_scalarmul_ladder_body(uint64_t *out1,
     InvChain ch;
     ch.begin();
     for_each_op<true>(n, [&](uint32_t i, bool live) GD_LAMBDA_INLINE {
-        ch.push(workspace + (size_t)ML_SLOT_U4 * i, ml_denominator(pt_load_abi(base + 32 * (size_t)i)), live);
+        ch.push(workspace + (size_t)ML_DUAL_SLOT_U4 * i, ml_denominator(pt_load_abi(base + 32 * (size_t)i)), live);
     });
     ch.invert();
     // ONE copy of the ladder, walked twice (a loop the compiler may not unroll): two inlined copies keep the first
     // result and both recoveries' temporaries alive across each other -- 1 321 spilled registers, profiles/r03 --
-    // where the single ladder of k_point_scalarmul_ct spills 77.  The second scalar's product goes first: out1 may
-    // alias base, which is read again at the top of each round.
+    // where the single ladder of k_point_scalarmul_ct spills 77.
     for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
-        const fe di = ch.pop(workspace + (size_t)ML_SLOT_U4 * i);
+        uint4 *slot = workspace + (size_t)ML_DUAL_SLOT_U4 * i;
+        const fe di = ch.pop(slot);
 #pragma unroll 1
         for (int which = 1; which >= 0; which--) {
             const pt b = pt_load_abi(base + 32 * (size_t)i);
             const uint64_t *k = (which ? s2 : s1) + 7 * (size_t)i;
             LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(k)));
             const pt r = ml_scalarmul(b, di, bits);
-            pt_store_abi((which ? out2 : out1) + 32 * (size_t)i, r);
+            if (which) {
+                pt_store_u4(slot, r);
+            } else {
+                pt_store_abi(out1 + 32 * (size_t)i, r);
+                pt_store_abi(out2 + 32 * (size_t)i, pt_load_u4(slot));
+            }
         }
     });
     lds_wipe_lane(s_bits + threadIdx.x, 15);
 }
 
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i], index-independent: two ladders and one addition; both denominators of an
-// operation go into the lane's chain (2 * ML_SLOT_U4 uint4 of workspace per operation).  out may alias b2.
-__device__ __forceinline__ void double_scalarmul_ladder_body(uint64_t *out, const uint64_t *__restrict__ b1,
+// operation go into the lane's chain.  ML_DOUBLE_SLOT_U4 uint4 of workspace per operation: the two chain slots, which --
+// popped -- hold s2 * b2, and 1/(Y1 - Z1) behind them.  out is written when both base points have been read: it may
+// alias either (the reference computes into temporaries, src/goldilocks.c:467-541).
+__device__ __forceinline__ void double_scalarmul_ladder_body(uint64_t *out, const uint64_t *b1,
                                                              const uint64_t *__restrict__ s1, const uint64_t *b2,
                                                              const uint64_t *__restrict__ s2, uint32_t n,
                                                              uint4 *__restrict__ workspace) {
@@ -266,24 +275,30 @@ __device__ __forceinline__ void double_scalarmul_ladder_body(uint64_t *out, cons
     InvChain ch;
     ch.begin();
     for_each_op<true>(n, [&](uint32_t i, bool live) GD_LAMBDA_INLINE {
-        uint4 *slot = workspace + (size_t)(2 * ML_SLOT_U4) * i;
+        uint4 *slot = workspace + (size_t)ML_DOUBLE_SLOT_U4 * i;
         ch.push(slot, ml_denominator(pt_load_abi(b1 + 32 * (size_t)i)), live);
         ch.push(slot + ML_SLOT_U4, ml_denominator(pt_load_abi(b2 + 32 * (size_t)i)), live);
     });
     ch.invert();
     // one copy of the ladder, walked twice (see point_dual_scalarmul_ladder_body): s2*b2 first -- its chain slot is
-    // the one pushed last -- parked in out[i] (which may alias b2[i], read before), then s1*b1 and the addition.
+    // the one pushed last -- parked in the operation's slots, then s1*b1 and the addition.
     for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
-        const uint4 *slot = workspace + (size_t)(2 * ML_SLOT_U4) * i;
+        uint4 *slot = workspace + (size_t)ML_DOUBLE_SLOT_U4 * i;
+        fe di = ch.pop(slot + ML_SLOT_U4);
+        fe_store(slot + 2 * ML_SLOT_U4, ch.pop(slot));
 #pragma unroll 1
         for (int which = 1; which >= 0; which--) {
             const pt b = pt_load_abi((which ? b2 : b1) + 32 * (size_t)i);
-            const fe di = ch.pop(slot + which * ML_SLOT_U4);
             const uint64_t *k = (which ? s2 : s1) + 7 * (size_t)i;
             LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(k)));
             pt r = ml_scalarmul(b, di, bits);
-            if (!which) r = pt_add(r, pt_load_abi(out + 32 * (size_t)i), false);
-            pt_store_abi(out + 32 * (size_t)i, r);
+            if (which) {
+                pt_store_u4(slot, r);
+                di = fe_load(slot + 2 * ML_SLOT_U4);
+            } else {
+                r = pt_add(r, pt_load_u4(slot), false);
+                pt_store_abi(out + 32 * (size_t)i, r);
+            }
         }
     });
     lds_wipe_lane(s_bits + threadIdx.x, 15);

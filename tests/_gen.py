@@ -66,6 +66,18 @@ def oracle_varbase(O, bases, scalars):
     return out
 
 
+def oracle_double(O, b1, s1, b2, s2):
+    """s1[i] * b1[i] + s2[i] * b2[i] by the oracle's goldilocks_448_point_double_scalarmul, one call per operation"""
+    from _libs import Point, Scalar
+    b1, s1, b2, s2 = (np.ascontiguousarray(a, dtype=np.uint64) for a in (b1, s1, b2, s2))
+    out = np.empty((len(s1), 32), dtype=np.uint64)
+    pt = lambda a: C.cast(_p(a), C.POINTER(Point))
+    sc = lambda a: C.cast(_p(a), C.POINTER(Scalar))
+    for i in range(len(s1)):
+        O.orc_point_double_scalarmul(pt(out[i]), pt(b1[i]), sc(s1[i]), pt(b2[i]), sc(s2[i]))
+    return out
+
+
 def oracle_encode(points):
     from _libs import oracle
     O = oracle()

@@ -20,7 +20,7 @@ WIDTHS = [8, 16, 18, 20]          # 1.3 MiB, 168 MiB, 600 MiB, 2.2 GiB (22 and 2
 
 @pytest.fixture()
 def width(ga):
-    """Sets a width for the body and leaves the library on its default (by free memory) afterwards."""
+    """Sets a width for the body and leaves the library on its default (20 bits) afterwards."""
     def set_(bits):
         ga.set_base_table_bits(bits)
     try:
@@ -89,12 +89,18 @@ def test_every_user_of_the_table_at_this_width(ga, O, width, bits):
         assert (got == np.array(verdicts)[order]).all()
 
 
-def test_default_width_follows_the_free_memory_and_bad_widths_are_refused(ga, O, width):
-    width(0)
-    s = _gen.stream_scalars(64, b"bt/default")
-    got = ga.point_encode_batch(ga.precomputed_scalarmul_batch(s, flags=ga.CALL_TABLES_FAST))
-    assert (got == _gen.oracle_encode(_gen.oracle_fixed(O, s))).all()
+def test_default_width_is_fixed_auto_follows_the_free_memory_and_bad_widths_are_refused(ga, O, width):
+    """The default is 20 bits (2.2 GiB) whatever the device holds; GOLDILOCKS_AMD_BASE_TABLE_BITS_AUTO asks for the widest
+    table within an eighth of the free memory (the default until round 4)."""
     import torch
+    s = _gen.stream_scalars(64, b"bt/default")
+    want = _gen.oracle_encode(_gen.oracle_fixed(O, s))
+    width(0)
+    assert (ga.point_encode_batch(ga.precomputed_scalarmul_batch(s, flags=ga.CALL_TABLES_FAST)) == want).all()
+    assert ga.get_base_table_bits() == ga.BASE_TABLE_BITS_DEFAULT == 20
+    ga.release_memory(ga.RELEASE_BASE_TABLE)
+    width(ga.BASE_TABLE_BITS_AUTO)
+    assert (ga.point_encode_batch(ga.precomputed_scalarmul_batch(s, flags=ga.CALL_TABLES_FAST)) == want).all()
     free, _total = torch.cuda.mem_get_info()
     bits = ga.get_base_table_bits()
     assert bits in (16, 18, 20, 22, 24)
@@ -104,6 +110,31 @@ def test_default_width_follows_the_free_memory_and_bad_widths_are_refused(ga, O,
         with pytest.raises(ValueError):
             ga.set_base_table_bits(bad)
     assert ga.get_base_table_bits() == bits          # (a refused width changes nothing)
+    ga.release_memory(ga.RELEASE_BASE_TABLE)
+
+
+def test_default_footprint_after_a_full_size_verification_is_bounded(ga, O, width):
+    """include/goldilocks_amd.h documents what the library holds on a device at its default settings: 2.2 GiB of base-point
+    table and a workspace of at most 6 GiB after 2^20 verifications (config 4's batch: 2^10 keys x 1 024 signatures) --
+    8.5 GiB in all, whatever else is free on the device."""
+    import torch
+    width(0)
+    ga.release_memory()
+    n = 1 << 20
+    sigs, pks, msgs = _gen.signatures(O, 1 << 12, msglen=32, seed=b"bt/footprint", nkeys=1 << 10)
+    reps = n // len(sigs)
+    dsig = torch.from_numpy(np.concatenate([sigs] * reps)).cuda()
+    dpk = torch.from_numpy(np.concatenate([pks] * reps)).cuda()
+    dmsg = torch.from_numpy(np.concatenate([np.frombuffer(b"".join(msgs), dtype=np.uint8)] * reps)).cuda()
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    ga.dev("ed448_verify", st.data_ptr(), dsig.data_ptr(), dpk.data_ptr(), dmsg.data_ptr(), None, 32, 0, None, 0, n, None)
+    assert int((st == -1).sum()) == n
+    assert ga.get_base_table_bits() == 20
+    held = ga.device_info()["workspace_bytes"]
+    table = 23 * (1 << 19) * 192 + 256               # 20-bit digits: 23 windows of 2^19 entries behind the header
+    assert table < held <= int(8.5 * 2**30), held
+    assert held - table <= 6 << 30, held - table
+    ga.release_memory()
 
 
 def test_release_memory_gives_everything_back_and_it_returns_on_demand(ga, O, width):

@@ -214,3 +214,57 @@ def test_ladder_kernels_over_several_launches_of_one_call(ga, O):
     ga.dev("point_op", summed.data_ptr(), o1.data_ptr(), o2.data_ptr(), 0, n, None)          # s P + k P by point_add
     ga.dev("point_pred", st.data_ptr(), dbl.data_ptr(), summed.data_ptr(), 0, n, None)
     assert int((st == -1).sum()) == n
+
+
+@pytest.mark.parametrize("mode", ["index-independent", "fast"])
+def test_two_scalar_device_entries_with_every_output_aliasing(ga, O, mode):
+    """goldilocks_amd_point_double_scalarmul_dev / _point_dual_scalarmul_dev with each output aliasing each input
+    array (the reference computes into temporaries and allows all of it, src/goldilocks.c:467-541, :543-642) above
+    the wave-kernel threshold, several operations per lane: the results must equal the un-aliased call's, and a
+    sample the oracle's."""
+    import torch
+    flags = ga.CALL_TABLES_INDEX_INDEPENDENT if mode == "index-independent" else ga.CALL_TABLES_FAST
+    n = ga.device_info()["compute_units"] * 2 * 256 * 2 + 333
+    k1 = torch.from_numpy(_gen.stream_scalars(n, b"alias2/b1").view(np.int64)).cuda()
+    k2 = torch.from_numpy(_gen.stream_scalars(n, b"alias2/b2").view(np.int64)).cuda()
+    s1 = torch.from_numpy(_gen.stream_scalars(n, b"alias2/s1").view(np.int64)).cuda()
+    s2 = torch.from_numpy(_gen.stream_scalars(n, b"alias2/s2").view(np.int64)).cuda()
+    b1 = torch.empty((n, 32), dtype=torch.int64, device="cuda")
+    b2 = torch.empty_like(b1)
+    ga.dev("precomputed_scalarmul", b1.data_ptr(), None, k1.data_ptr(), n, None)
+    ga.dev("precomputed_scalarmul", b2.data_ptr(), None, k2.data_ptr(), n, None)
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+
+    def same(x, y):
+        ga.dev("point_pred", st.data_ptr(), x.data_ptr(), y.data_ptr(), 0, n, None)
+        return int((st == -1).sum()) == n
+
+    # double: combo = s1 b1 + s2 b2
+    ref = torch.empty_like(b1)
+    ga.dev("point_double_scalarmul", ref.data_ptr(), b1.data_ptr(), s1.data_ptr(), b2.data_ptr(), s2.data_ptr(), n, None, flags=flags)
+    idx = np.unique(np.concatenate([np.arange(0, n, 9973), [0, 63, 64, n - 1]]))
+    h = lambda t: t.cpu().numpy().view(np.uint64)[idx]
+    want = _gen.oracle_encode(_gen.oracle_double(O, h(b1), h(s1), h(b2), h(s2)))
+    assert (ga.point_encode_batch(h(ref)) == want).all()
+    x = b1.clone()                                           # out == b1
+    ga.dev("point_double_scalarmul", x.data_ptr(), x.data_ptr(), s1.data_ptr(), b2.data_ptr(), s2.data_ptr(), n, None, flags=flags)
+    assert same(x, ref)
+    x = b2.clone()                                           # out == b2
+    ga.dev("point_double_scalarmul", x.data_ptr(), b1.data_ptr(), s1.data_ptr(), x.data_ptr(), s2.data_ptr(), n, None, flags=flags)
+    assert same(x, ref)
+    ref11 = torch.empty_like(b1)                             # out == b1 == b2
+    ga.dev("point_double_scalarmul", ref11.data_ptr(), b1.data_ptr(), s1.data_ptr(), b1.data_ptr(), s2.data_ptr(), n, None, flags=flags)
+    x = b1.clone()
+    ga.dev("point_double_scalarmul", x.data_ptr(), x.data_ptr(), s1.data_ptr(), x.data_ptr(), s2.data_ptr(), n, None, flags=flags)
+    assert same(x, ref11)
+    # dual: (a1, a2) = (s1 b, s2 b)
+    r1, r2 = torch.empty_like(b1), torch.empty_like(b1)
+    ga.dev("point_dual_scalarmul", r1.data_ptr(), r2.data_ptr(), b1.data_ptr(), s1.data_ptr(), s2.data_ptr(), n, None, flags=flags)
+    assert (ga.point_encode_batch(h(r1)) == _gen.oracle_encode(_gen.oracle_varbase(O, h(b1), h(s1)))).all()
+    assert (ga.point_encode_batch(h(r2)) == _gen.oracle_encode(_gen.oracle_varbase(O, h(b1), h(s2)))).all()
+    x, y = b1.clone(), torch.empty_like(b1)                  # a1 == base
+    ga.dev("point_dual_scalarmul", x.data_ptr(), y.data_ptr(), x.data_ptr(), s1.data_ptr(), s2.data_ptr(), n, None, flags=flags)
+    assert same(x, r1) and same(y, r2)
+    x, y = torch.empty_like(b1), b1.clone()                  # a2 == base
+    ga.dev("point_dual_scalarmul", x.data_ptr(), y.data_ptr(), y.data_ptr(), s1.data_ptr(), s2.data_ptr(), n, None, flags=flags)
+    assert same(x, r1) and same(y, r2)

@@ -91,8 +91,10 @@ def compile_isa(tu, force=False):
     srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     if not force and os.path.exists(out) and all(os.path.getmtime(s) <= os.path.getmtime(out) for s in srcs):
         return out
-    cmd = [HIPCC, "-std=c++17", "-O3", "--offload-arch=gfx950", "--offload-device-only", "-S", "-o", out + ".tmp",
-           os.path.join(CSRC, tu)]
+    # the shipped library's own flag list (__graft_entry__.lib_flags): the audited ISA is the ISA of the .so
+    sys.path.insert(0, ROOT)
+    from __graft_entry__ import lib_flags
+    cmd = [HIPCC] + lib_flags() + ["--offload-device-only", "-S", "-o", out + ".tmp", os.path.join(CSRC, tu)]
     subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     os.replace(out + ".tmp", out)
     return out
