@@ -418,9 +418,10 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_xwide(size_t min_sig
  * Returns 0, or 1 for a width that does not exist.
  *
  * DEVICE MEMORY THE LIBRARY HOLDS at these defaults, until goldilocks_amd_shutdown or goldilocks_amd_release_memory:
- * the base point's table 2.2 GiB + the workspace, which grows with the largest batch seen: at most 6 GiB for 2^20
- * verifications (the per-key combs' ceiling above included), 128 MiB for 2^20 variable-base multiplications -- 8.5 GiB in
- * all, asserted by tests/test_gpu_base_table.py -- + the host-array entry points' staging (1.2 x the batch's bytes). */
+ * the base point's table 2.2 GiB + the workspace, which grows with the largest batch seen: at most 7.5 GiB for 2^20
+ * verifications (measured 7.0: the per-key combs' ceiling of 4 GiB above, 2 GiB of pooled per-key tables, 1 GiB of
+ * per-lane tables and bookkeeping), 128 MiB for 2^20 variable-base multiplications -- 10 GiB in all, asserted by
+ * tests/test_gpu_base_table.py -- + the host-array entry points' staging (1.2 x the batch's bytes). */
 #define GOLDILOCKS_AMD_BASE_TABLE_BITS_DEFAULT 20
 #define GOLDILOCKS_AMD_BASE_TABLE_BITS_AUTO 1
 GOLDILOCKS_AMD_API int goldilocks_amd_set_base_table_bits(int bits);

@@ -59,6 +59,28 @@ struct fe {
     uint32_t v[16];
 };
 
+// (a << SH) + b on the limb pair (lo, hi) = limbs 2k, 2k+1 with ONE v_lshl_add_u64: the two limbs are the halves of a
+// 64-bit register pair, and as the magnitude contract keeps every limb (and every sum of limbs formed here) below 2^32,
+// the low half never carries into the high half.  Every VALU instruction of these kernels costs the same four cycles
+// (DESIGN.md section 7), so an addition of two elements is 8 instructions instead of 16.  The instruction is written out
+// and its operands are opaque: left to itself the compiler takes the 64-bit addition apart again.
+template <int SH>
+GD_FN void fe_pair_add(uint32_t &lo, uint32_t &hi, uint32_t alo, uint32_t ahi, uint32_t blo, uint32_t bhi) {
+#if defined(GF_CHECKED)
+    if ((((uint64_t)alo << SH) + blo) >> 32 || (((uint64_t)ahi << SH) + bhi) >> 32) __builtin_trap();
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GD_NO_PAIRED_ADDS)
+    const uint64_t a = (uint64_t)alo | ((uint64_t)ahi << 32), b = (uint64_t)blo | ((uint64_t)bhi << 32);
+    uint64_t c;
+    asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(c) : "v"(a), "v"(b), "n"(SH));
+    lo = (uint32_t)c;
+    hi = (uint32_t)(c >> 32);
+#else
+    lo = (alo << SH) + blo;
+    hi = (ahi << SH) + bhi;
+#endif
+}
+
 #if defined(GF_CHECKED)
 // Host-side checker accumulator: 128-bit, aborts if a 64-bit accumulator would
 // have overflowed or gone negative.  It also counts the multiply-accumulates (one v_mad_u64_u32 each on
@@ -110,6 +132,25 @@ struct acc_t {
 };
 #endif
 
+// ... with a compile-time constant pair as the addend: the constant is a scalar register pair (no moves into VGPRs)
+template <uint32_t BLO, uint32_t BHI>
+GD_FN void fe_pair_add_const(uint32_t &lo, uint32_t &hi, uint32_t alo, uint32_t ahi) {
+#if defined(GF_CHECKED)
+    if (((uint64_t)alo + BLO) >> 32 || ((uint64_t)ahi + BHI) >> 32) __builtin_trap();
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GD_NO_PAIRED_ADDS)
+    const uint64_t a = (uint64_t)alo | ((uint64_t)ahi << 32);
+    const uint64_t b = (uint64_t)BLO | ((uint64_t)BHI << 32);
+    uint64_t c;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(c) : "v"(a), "s"(b));
+    lo = (uint32_t)c;
+    hi = (uint32_t)(c >> 32);
+#else
+    lo = alo + BLO;
+    hi = ahi + BHI;
+#endif
+}
+
 // ---------------------------------------------------------------- constants
 
 GD_FN fe fe_zero() {
@@ -135,7 +176,7 @@ GD_FN fe fe_small(uint32_t w) {  // w < 2^28
 GD_FN fe fe_add(const fe &a, const fe &b) {
     fe c;
 #pragma unroll
-    for (int i = 0; i < 16; i++) c.v[i] = a.v[i] + b.v[i];
+    for (int k = 0; k < 8; k++) fe_pair_add<0>(c.v[2 * k], c.v[2 * k + 1], a.v[2 * k], a.v[2 * k + 1], b.v[2 * k], b.v[2 * k + 1]);
     return c;
 }
 
@@ -146,11 +187,16 @@ GD_FN fe fe_sub(const fe &a, const fe &b) {
     fe c;
     constexpr uint32_t B = (uint32_t)K * M28;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
+    for (int k = 0; k < 8; k++) {
 #if defined(GF_CHECKED)
-        if (b.v[i] > (i == 8 ? B - K : B)) __builtin_trap();
+        if (b.v[2 * k] > (k == 4 ? B - K : B) || b.v[2 * k + 1] > B) __builtin_trap();
 #endif
-        c.v[i] = a.v[i] + (i == 8 ? B - (uint32_t)K : B) - b.v[i];
+        // a + K p pair-wise (the bias is a 64-bit constant: one instruction for two limbs), then - b limb by limb
+        uint32_t lo, hi;
+        if (k == 4) fe_pair_add_const<B - (uint32_t)K, B>(lo, hi, a.v[2 * k], a.v[2 * k + 1]);
+        else fe_pair_add_const<B, B>(lo, hi, a.v[2 * k], a.v[2 * k + 1]);
+        c.v[2 * k] = lo - b.v[2 * k];
+        c.v[2 * k + 1] = hi - b.v[2 * k + 1];
     }
     return c;
 }
@@ -160,10 +206,11 @@ GD_FN fe fe_sub(const fe &a, const fe &b) {
 // Result: every limb <= 2^28 - 1 + 15  (cf. gf_weak_reduce, arch_ref64/f_impl.h:30-38).
 GD_FN fe fe_weak(const fe &a) {
     fe c;
-    uint32_t top = a.v[15] >> 28;
-    c.v[0] = (a.v[0] & M28) + top;
+    const uint32_t top = a.v[15] >> 28;
 #pragma unroll
-    for (int i = 1; i < 16; i++) c.v[i] = (a.v[i] & M28) + (a.v[i - 1] >> 28);
+    for (int k = 0; k < 8; k++)   // masked pair + carry pair: five instructions for two limbs
+        fe_pair_add<0>(c.v[2 * k], c.v[2 * k + 1], a.v[2 * k] & M28, a.v[2 * k + 1] & M28, k ? a.v[2 * k - 1] >> 28 : top,
+                       a.v[2 * k] >> 28);
     c.v[8] += top;
     return c;
 }
@@ -194,10 +241,10 @@ GD_FN void fe_fold_tails(fe &c, acc_t lo, acc_t hi) {
 GD_FN fe fe_mul(const fe &a, const fe &b) {
     uint32_t sa[8], sb[8], sbb[8];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        sa[j] = a.v[j] + a.v[j + 8];
-        sb[j] = b.v[j] + b.v[j + 8];
-        sbb[j] = sb[j] + b.v[j + 8];
+    for (int j = 0; j < 8; j += 2) {
+        fe_pair_add<0>(sa[j], sa[j + 1], a.v[j], a.v[j + 1], a.v[j + 8], a.v[j + 9]);
+        fe_pair_add<0>(sb[j], sb[j + 1], b.v[j], b.v[j + 1], b.v[j + 8], b.v[j + 9]);
+        fe_pair_add<1>(sbb[j], sbb[j + 1], b.v[j + 8], b.v[j + 9], b.v[j], b.v[j + 1]);     // b0 + 2 b1
     }
     fe c;
     acc_t lo, hi;
@@ -283,8 +330,11 @@ GD_FN fe fe_sqr(const fe &a) {
     for (int j = 0; j < 8; j++) {
         u[j] = a.v[j];
         v[j] = a.v[j + 8];
-        s[j] = a.v[j] + a.v[j + 8];
-        t[j] = (a.v[j] << 1) + a.v[j + 8];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        fe_pair_add<0>(s[j], s[j + 1], a.v[j], a.v[j + 1], a.v[j + 8], a.v[j + 9]);
+        fe_pair_add<1>(t[j], t[j + 1], a.v[j], a.v[j + 1], a.v[j + 8], a.v[j + 9]);         // 2 a0 + a1
     }
     fe c;
     acc_t lo, hi;

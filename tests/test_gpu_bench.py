@@ -52,10 +52,17 @@ def test_default_line_carries_configs_end_to_end_and_cpu_baseline():
     assert line["n_gpus"] == 1 and line["config"]["parity_spot_check"] == "ok"
     assert line["roofline"]["kernel"] == "k_point_scalarmul_ct" and line["config"]["table_access"] == "index-independent"
     assert "oracle's goldilocks_448_point_scalarmul" in line["config"]["check"]
-    assert set(line["configs"]) == {"fixed", "base", "verify", "verify_distinct_keys", "varbase_fast", "base_fast"}
+    assert set(line["configs"]) == {"fixed", "base", "verify", "verify_distinct_keys", "varbase_fast", "base_fast", "verify_table24"}
     for c in line["configs"].values():
         assert c["parity_spot_check"] == "ok" and c["value"] > 0 and c["kernel_ms_avg"] > 0
         assert "equal the oracle's" in c["check"]                        # not a self-comparison
+        assert c["device_memory_bytes"] > 0                              # every config states what the library holds
+    # config 4 at the library's default table (20 bits, bounded footprint) and at the opt-in 24 bits
+    assert line["configs"]["verify"]["base_table_bits"] == 20 and line["configs"]["verify"]["base_table_bits_is_library_default"]
+    assert line["configs"]["verify_table24"]["base_table_bits"] == 24
+    assert line["configs"]["verify"]["device_memory_bytes"] < 10 << 30 < line["configs"]["verify_table24"]["device_memory_bytes"]
+    peaks = line["roofline"]["mac"]["peaks"]
+    assert line["roofline"]["mac"]["peak"] == peaks[peaks["used"]] == 38.4
     assert "rejects among them" in line["configs"]["verify"]["check"]
     assert line["configs"]["varbase_fast"]["kernel"] == "k_point_scalarmul"
     assert line["configs"]["base"]["kernel"] == "k_base_scalarmul_ct" and line["configs"]["base_fast"]["kernel"] == "k_base_scalarmul"
