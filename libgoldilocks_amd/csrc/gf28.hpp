@@ -75,6 +75,10 @@ GD_FN void fe_pair_add(uint32_t &lo, uint32_t &hi, uint32_t alo, uint32_t ahi, u
     asm("v_lshl_add_u64 %0, %1, %3, %2" : "=v"(c) : "v"(a), "v"(b), "n"(SH));
     lo = (uint32_t)c;
     hi = (uint32_t)(c >> 32);
+    // (a multiplicand the compiler knows to be the high half of a 64-bit value makes its multiply-add a 64-bit
+    // multiplication: the halves are opaque too)
+    asm("" : "+v"(lo));
+    asm("" : "+v"(hi));
 #else
     lo = (alo << SH) + blo;
     hi = (ahi << SH) + bhi;
@@ -145,6 +149,8 @@ GD_FN void fe_pair_add_const(uint32_t &lo, uint32_t &hi, uint32_t alo, uint32_t 
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(c) : "v"(a), "s"(b));
     lo = (uint32_t)c;
     hi = (uint32_t)(c >> 32);
+    asm("" : "+v"(lo));
+    asm("" : "+v"(hi));
 #else
     lo = alo + BLO;
     hi = ahi + BHI;

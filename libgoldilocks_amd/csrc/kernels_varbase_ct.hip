@@ -1,6 +1,11 @@
 // kernels_varbase_ct.hip -- the index-independent variants of the variable-base kernels: no table at all, a
 // Montgomery ladder of selects (montgomery.hpp); the library's default for every entry point whose scalar may be
 // secret.  Bodies in varbase_bodies.hpp.
+// The ladder's steps run on gf28s.hpp (signed limbs, pair-wise additions where the type allows them); what is left for
+// gf28.hpp here -- the shared inversions and the recovery of the point -- is compiled WITHOUT its pair-wise additions: the
+// aligned pairs change the allocation of the 256 registers the step loop lives in, and the kernels measure 0.7 % slower
+// with them (same-box A/B, profiles/r05/ab_pairs.txt).
+#define GD_NO_PAIRED_ADDS 1
 #include "varbase_bodies.hpp"
 
 namespace gd {
