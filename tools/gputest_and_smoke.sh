@@ -1,4 +1,5 @@
 #!/bin/bash
+# What the driver runs at round end, on the GPU box:   gpurun --timeout 2700 -- "bash tools/gputest_and_smoke.sh"
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$ROOT"

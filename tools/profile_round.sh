@@ -7,7 +7,7 @@
 # committed are written to gpurun_out/profiles_<round>/ by tools/summarize_prof.py (copy them to
 # profiles/<round>/).  The program after `--` is always python3 itself (no env/bash hop).
 set -u
-ROUND=${1:-r04}
+ROUND=${1:-r05}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 DST=$ROOT/gpurun_out/profiles_$ROUND
