@@ -462,6 +462,35 @@ def cpu_info():
     return model, flags
 
 
+def reference_tool_rows(build_label):
+    """Runs oracle/_ref/bench_goldilocks_<build> --micro (the reference's test/bench_goldilocks.cxx, :73-143 its Benchmark
+    class, :190 'Point scalarmul') and returns its Ed448-Goldilocks rows in seconds per operation; None if the binary is
+    not there (it is built where /root/reference is)."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "bench_goldilocks_" + ("x86_64_v3" if build_label == "x86_64_v3" else "x86_64"))
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe, "--micro"], capture_output=True, text=True, timeout=120).stdout
+    except Exception as e:   # noqa: BLE001
+        return {"error": str(e)}
+    scale = {"ns": 1e-9, "µs": 1e-6, "us": 1e-6, "ms": 1e-3, "s": 1.0}
+    rows, section = {}, ""
+    for line in out.splitlines():
+        if line.startswith(("Micro-benchmarks for", "Macro-benchmarks for")):
+            section = line.split("for", 1)[1].strip(" :")
+        m = re.match(r"^(.*?):\s+([0-9.]+)\s*(ns|µs|us|ms|s)\s", line)
+        if m and "448" in section:
+            rows[m.group(1).strip()] = float(m.group(2)) * scale[m.group(3)]
+    wanted = ("Point scalarmul", "Point precmp scalarmul", "Point double scalarmul", "Point double scalarmul_v",
+              "EdDSA sign", "EdDSA verify", "RFC 7748 shared secret")
+    sel = {k: rows[k] for k in wanted if k in rows}
+    return {"tool": "test/bench_goldilocks.cxx --micro (compiled by oracle/Makefile against the reference's arch_x86_64 path, " + build_label + ")",
+            "seconds_per_op": sel,
+            "point_scalarmul_per_s": 1.0 / sel["Point scalarmul"] if sel.get("Point scalarmul") else None, "threads": 1}
+
+
 def cpu_baseline_leg(np, bases_h, scalars_h, samples, budget_s=9.0):
     """Time the reference's CPU path on the host cores and let the oracle re-compute SAMPLE lanes of every
     config.  The only place in this file that touches oracle/ (test infrastructure).
@@ -530,6 +559,10 @@ def cpu_baseline_leg(np, bases_h, scalars_h, samples, budget_s=9.0):
            "build": best_label, "single_thread": single, "single_thread_by_build": singles, "sweep": sweep,
            "compiler": gcc + " (in the build container)", "cpu_model": model, "affinity_cores": affinity,
            "cgroup_quota_cores": quota, "usable_cores": usable}
+
+    # (2b) the reference's OWN tool: test/bench_goldilocks.cxx --micro, compiled in the build container against the same
+    # reference library (oracle/Makefile), run here on the host as it is -- its rows, as it prints them
+    res["reference_tool"] = reference_tool_rows(best_label)
 
     # (3) the oracle re-computes the first lanes of every config
     checks = {}
@@ -698,7 +731,10 @@ def run_rank(args):
     if "kernels_after" in w:
         w["kernel"], w["traffic_kernels"], w["macs"] = w["kernels_after"]()
     avg_ms = sum(kernel_ms) / len(kernel_ms)
-    rows = shard.gather_over_ranks([rank, device, n * args.steps / mine, avg_ms, n, lo], dist, backend)
+    # (each rank's device by its PCI address: a first real 8-GPU run shows at a glance that eight ranks sit on eight devices)
+    props = torch.cuda.get_device_properties(device)
+    pci = [getattr(props, k, -1) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    rows = shard.gather_over_ranks([rank, device, n * args.steps / mine, avg_ms, n, lo] + pci, dist, backend)
     ok, check, extra = w["check"]() if rank == 0 else (True, "n/a", {})
     default_line = rank == 0 and world == 1 and name == "varbase" and args.table_access == "index-independent" \
         and args.global_log2_batch is None
@@ -717,6 +753,8 @@ def run_rank(args):
                        "sharding": ("contiguous slices of one global batch of 2^%d" % args.global_log2_batch
                                     if args.global_log2_batch is not None else "independent batch per GPU")
                                    + ", no data-path collective", "control_plane": backend or "single process",
+                       # ranks whose RCCL bring-up succeeded (None: not attempted); RCCL carries the barrier only if all did
+                       "rccl_ranks_seen": shard.RCCL_RANKS_SEEN[0],
                        "io_layout": "AoS reference structs resident in HBM", "device": info["arch"],
                        # digits of the base point's window table on this device (0: this workload never asked for it)
                        "base_table_bits": ga.get_base_table_bits(),
@@ -724,7 +762,8 @@ def run_rank(args):
                        "device_memory_bytes": ga.device_info()["workspace_bytes"],
                        "parity_spot_check": "ok" if ok else "FAILED", "check": check},
             "per_gpu": [dict({"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
-                              "kernel_ms_avg": r[3], "batch": int(r[4])},
+                              "kernel_ms_avg": r[3], "batch": int(r[4]),
+                              "pci": "%04x:%02x:%02x" % (int(r[6]), int(r[7]), int(r[8])) if r[6] >= 0 else None},
                              **({"slice": [int(r[5]), int(r[5]) + int(r[4])]} if scaling == "strong" else {})) for r in rows],
             "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels"), ga.get_base_table_bits(), w.get("macs")),
         }

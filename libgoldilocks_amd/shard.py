@@ -96,6 +96,9 @@ def launch_ranks(argv, world, timeout=LAUNCH_TIMEOUT_S, poll_s=0.05):
     return code
 
 
+RCCL_RANKS_SEEN = [None]   # set by init_group when an RCCL bring-up was attempted: the number of ranks it succeeded on
+
+
 class Group(object):
     """The control-plane process group of a rank: torch.distributed bound to ONE group, so that callers
     (bench.py, the helpers below) write dist.barrier() / dist.all_reduce(t) whichever backend carries it."""
@@ -162,8 +165,9 @@ def init_group(world, rank, visible_devices, use_gpu=True, rccl_timeout_s=120):
                 mine = 0
                 print("shard.init_group: rank %d: RCCL bring-up failed (%s)" % (rank, e), file=sys.stderr)
             agreed = torch.tensor([mine], dtype=torch.int32)
-            dist.all_reduce(agreed, op=dist.ReduceOp.MIN)    # over gloo: every rank learns the same answer
-            if int(agreed.item()) == 1:
+            dist.all_reduce(agreed, op=dist.ReduceOp.SUM)    # over gloo: every rank learns the same answer
+            RCCL_RANKS_SEEN[0] = int(agreed.item())          # how many ranks' RCCL bring-up succeeded (the line reports it)
+            if RCCL_RANKS_SEEN[0] == world:
                 group, backend = rccl, "nccl"
             elif rank == 0:
                 print("shard.init_group: RCCL did not come up on every rank; the control plane stays on gloo",

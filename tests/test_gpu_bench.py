@@ -75,6 +75,9 @@ def test_default_line_carries_configs_end_to_end_and_cpu_baseline():
     cb = line["cpu_baseline"]
     assert set(cb["single_thread_by_build"]) <= {"x86_64_generic", "x86_64_v3", "oracle_port"} and cb["build"] in cb["single_thread_by_build"]
     assert cb["cores"] >= 1 and cb["single_thread"]["us_per_op"] > 0
+    # the reference's own tool (test/bench_goldilocks.cxx, built by oracle/Makefile where /root/reference is) ran beside it
+    tool = cb["reference_tool"]
+    assert tool is None or 0 < tool["seconds_per_op"]["Point scalarmul"] < 1e-3
     # the stated core count is consistent with the speed-up over one thread (within 2x)
     ratio = cb["value"] / cb["single_thread"]["value"]
     assert cb["cores"] / 2.0 <= max(ratio, 1.0) * 2.0 and ratio <= cb["cores"] * 2.0
