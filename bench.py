@@ -59,6 +59,9 @@ HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # part, 600 G wave-instructions/s (v_mul_u32_u24 599.8, v_mul_hi_u32 596; profiles/r01/ubench.txt, 8 waves per SIMD) x 64
 # lanes.  The multiply-accumulates themselves top out lower (v_mad_i64_i32 589 G = 37.7 T, v_mad_u64_u32 579 G = 37.0 T); the
 # paper figure is 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T.  All three are on the line (roofline.mac.peaks).
+# The ceiling every kernel here actually runs against: a SIMD issues ONE VALU instruction per four cycles whatever its kind
+# (profiles/r01/ubench.txt: 4.1 - 4.4 cycles for every multiply / 64-bit / 3-operand instruction): 1024 SIMDs x 2.4 GHz / 4.
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4          # 614.4 G wave-instructions/s at the nominal clock (600 G measured, tools/ubench)
 VALU_MAC_PEAK = 38.4e12
 VALU_MAC_PEAKS = {"used": "best_issue_rate_measured", "best_issue_rate_measured": 38.4, "v_mad_i64_i32_measured": 37.7,
                   "v_mad_u64_u32_measured": 37.0, "paper_quarter_rate_at_2.4GHz": 39.3, "unit": "T MAC/s",
@@ -619,6 +622,22 @@ def pmc_traffic(kernel):
     return d.get(kernel), info
 
 
+def pmc_valu_insts(kernel):
+    """VALU wave-instructions per 2^20-operation launch of `kernel` (or of the kernels of a step: their sum) from the same
+    stamped PMC passes (SQ_INSTS_VALU); None when they were not taken on the current kernel sources."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    if (d.get("_measured_on") or {}).get("kernel_source_sha16") != kernel_source_sha16():
+        return None
+    v = d.get("_valu_insts") or {}
+    if isinstance(kernel, (tuple, list)):
+        parts = [v.get(k) for k in kernel]
+        return sum(parts) if all(x is not None for x in parts) else None
+    return v.get(kernel)
+
+
 def base_table_windows(bits):
     """Digits of a scalar in the base point's window table of `bits`-bit digits (scalarmul.hpp bwt_windows)."""
     return -(-446 // bits)
@@ -662,6 +681,16 @@ def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_t
         macs = spec["macs"] * n / (avg_ms * 1e-3)
         r["mac"] = {"achieved": macs / 1e12, "peak": VALU_MAC_PEAK / 1e12, "unit": "T MAC/s",
                     "frac": macs / VALU_MAC_PEAK, "macs_per_op": spec["macs"], "peaks": VALU_MAC_PEAKS}
+    # ... and the ceiling all of it runs against: VALU issue, one wave-instruction per SIMD per four cycles.  The instruction
+    # count is SQ_INSTS_VALU of a 2^20-operation launch from the stamped PMC passes (scaled to this launch's n); the time
+    # is this run's.  What is left below 1.0 is the clock the chip holds under this load (it runs the ladder at about
+    # 2.2 GHz, not 2.4) and a few percent of stalls; the lever is instructions per operation.
+    insts = pmc_valu_insts(traffic_kernels or kernel)
+    if insts:
+        per_s = insts * (n / float(1 << LOG2_BATCH)) / (avg_ms * 1e-3)
+        r["valu_issue"] = {"achieved": per_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
+                           "frac": per_s / VALU_ISSUE_PEAK, "valu_instructions_per_op": insts * 64 / float(1 << LOG2_BATCH),
+                           "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json (same kernel sources); peak = 1024 SIMDs x 2.4 GHz / 4"}
     return r
 
 

@@ -102,6 +102,12 @@ def main(raw, out):
         head = ""
     traffic["_measured_on"] = {"kernel_source_sha16": kernel_source_sha16(), "git_head": head or None,
                                "round": os.path.basename(os.path.normpath(out)).replace("profiles_", "")}
+    # VALU wave-instructions per launch (SQ_INSTS_VALU): what the kernels are bound by -- one per SIMD per four cycles
+    valu = {}
+    for r in rows:
+        if r["counter"] == "SQ_INSTS_VALU" and r["avg_per_dispatch"] > 0:
+            valu[r["kernel"]] = max(valu.get(r["kernel"], 0.0), r["avg_per_dispatch"])
+    traffic["_valu_insts"] = valu
     traffic["_note"] = ("HBM bytes per launch (batch 2^20): 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 (KiB units; FETCH_SIZE "
                         "doubled per MI355X_MICROARCH.md HBM section), separate --pmc passes, rocprofv3_pmc_summary.json")
     json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
