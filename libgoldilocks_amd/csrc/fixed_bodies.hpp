@@ -3,6 +3,7 @@
 // kernels_fixed_ct.hip (CT = true) so the two sets compile in parallel.
 #pragma once
 #include "kernels.hpp"
+#include "inv_wave.hpp"
 
 namespace gd {
 
@@ -96,6 +97,17 @@ struct InvChain {
         acc = fe_select(acc, fe_mul(acc, ze), live);
     }
     __device__ __forceinline__ void invert() { acc = fe_invert(acc); }
+    // ... with ONE inversion for the 64 chains of the wave (inv_wave.hpp): every lane of the wave must call; lds = a
+    // region of INV_WAVE_LDS_WORDS words that this wave alone uses while the call lasts.  wipe: the chains' products
+    // belong to secret data (a nonce's or a secret scalar's multiple in projective form): nothing of them stays in LDS.
+    __device__ __forceinline__ void invert_wave(uint32_t *lds, bool wipe) {
+        acc = wave_shared_invert(acc, lds);
+        if (wipe) {
+            const uint32_t l = threadIdx.x & 63u;
+#pragma unroll
+            for (int i = 0; i < 16; i++) lds[l * 16 + i] = 0;
+        }
+    }
     __device__ __forceinline__ fe pop(const uint4 *slot) {   // in the reverse order of push
         const fe ze = fe_load(slot), pre = fe_load(slot + 4);
         const fe zi = fe_mul(acc, pre);
@@ -117,6 +129,15 @@ __device__ __forceinline__ sc sc_load_u4(const uint4 *p) {
     s.w[8] = c.x; s.w[9] = c.y; s.w[10] = c.z; s.w[11] = c.w;
     s.w[12] = d.x; s.w[13] = d.y;
     return s;
+}
+
+// The chains' one inversion per wave (InvChain::invert_wave) in a staging region that the BLOCK shares (the SHAKE staging
+// is word-interleaved across the block's lanes, the comb is the block's): every wave is done with the region before any
+// wave's inversion writes to it, and every inversion is done before the second pass stages its hashes again.
+__device__ __forceinline__ void block_invert_in_stage(InvChain &ch, uint32_t *s_stage) {
+    __syncthreads();
+    ch.invert_wave(s_stage + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS, true);
+    __syncthreads();
 }
 
 // "next" row f1: pk[i] = derive_public_key(sk[i])   (ref: goldilocks_ed448_derive_public_key)
@@ -148,7 +169,7 @@ __device__ __forceinline__ void derive_body(uint8_t *pk, const uint8_t *sk, uint
         FixedBwt<GlobalBwt> fb{bwt_tab};
         for_each_op<CT>(n, [&](uint32_t i, bool live) { first(i, live, fb); });
     }
-    ch.invert();
+    block_invert_in_stage(ch, s_stage);
     for_each_op_reverse(n, [&](uint32_t i) {
         const uint4 *slot = ws + (size_t)DERIVE_SLOT_U4 * i;
         const fe zi = ch.pop(slot + 8);
@@ -210,7 +231,7 @@ __device__ __forceinline__ void sign_body(uint8_t *sig, const uint8_t *sk, const
         FixedBwt<GlobalBwt> fb{bwt_tab};
         for_each_op<CT>(n, [&](uint32_t i, bool live) { first(i, live, fb); });
     }
-    ch.invert();
+    block_invert_in_stage(ch, s_stage);
     for_each_op_reverse(n, [&](uint32_t i) {
         uint4 *slot = ws + (size_t)SIGN_SLOT_U4 * i;
         const fe zi = ch.pop(slot + 8);
@@ -285,7 +306,10 @@ __device__ __forceinline__ void x448_body(uint8_t *shared, int32_t *status, cons
         if (live) fe_store(slot, num);
         ch.push(slot + 4, den, live);
     });
-    ch.invert();
+    {   // one inversion per wave: in the comb's region when there is one (nobody needs it any more), else in its own
+        __shared__ uint32_t s_inv[CT ? 1 : (BLOCK / 64) * INV_WAVE_LDS_WORDS];
+        block_invert_in_stage(ch, CT ? s_comb : s_inv);
+    }
     for_each_op_reverse(n, [&](uint32_t i) {
         uint4 *slot = ws + (size_t)X448_SLOT_U4 * i;
         const fe di = ch.pop(slot + 4);

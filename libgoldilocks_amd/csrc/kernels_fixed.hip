@@ -158,7 +158,8 @@ GD_KERNEL k_build_bwt(uint4 *__restrict__ table, const uint4 *__restrict__ comb,
         if (s + 1 == BWT_BUILD_SEG) break;
         pt_add_pniels(p, step, false, true);
     }
-    ch.invert();
+    __shared__ uint32_t s_inv[(BLOCK / 64) * INV_WAVE_LDS_WORDS];
+    ch.invert_wave(s_inv + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS, false);   // one inversion per wave (inv_wave.hpp)
     if (!live) return;
 #pragma unroll 1
     for (uint32_t s = BWT_BUILD_SEG; s-- > 0;) {
@@ -247,7 +248,8 @@ GD_KERNEL k_point_encode_eddsa_shared(uint8_t *__restrict__ enc, const uint64_t 
         fe_store(slot + 4, yn);
         ch.push(slot + 8, zn, true);
     });
-    ch.invert();
+    __shared__ uint32_t s_inv[(BLOCK / 64) * INV_WAVE_LDS_WORDS];
+    ch.invert_wave(s_inv + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS, false);
     for_each_op_reverse(n, [&](uint32_t i) {
         const uint4 *slot = ws + (size_t)DERIVE_SLOT_U4 * i;
         const fe zi = ch.pop(slot + 8);

@@ -172,7 +172,7 @@ __device__ __forceinline__ void point_scalarmul_ladder_body(uint64_t *out, const
         const pt b = wave_load_points(stage, base, i0, m, l);
         ch.push(workspace + (size_t)ML_SLOT_U4 * (i0 + l), ml_denominator(b), l < m);
     }
-    ch.invert();
+    ch.invert_wave(reinterpret_cast<uint32_t *>(stage), false);   // one inversion per wave, in the wave's own staging region
     for_each_wave_round_reverse(n, [&](uint32_t i0) {
         const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
         const pt b = wave_load_points(stage, base, i0, m, l);
@@ -239,7 +239,8 @@ __device__ __forceinline__ void point_dual_scalarmul_ladder_body(uint64_t *out1,
     for_each_op<true>(n, [&](uint32_t i, bool live) GD_LAMBDA_INLINE {
         ch.push(workspace + (size_t)ML_DUAL_SLOT_U4 * i, ml_denominator(pt_load_abi(base + 32 * (size_t)i)), live);
     });
-    ch.invert();
+    __shared__ uint32_t s_inv[(BLOCK / 64) * INV_WAVE_LDS_WORDS];
+    ch.invert_wave(s_inv + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS, false);
     // ONE copy of the ladder, walked twice (a loop the compiler may not unroll): two inlined copies keep the first
     // result and both recoveries' temporaries alive across each other -- 1 321 spilled registers, profiles/r03 --
     // where the single ladder of k_point_scalarmul_ct spills 77.
@@ -279,7 +280,8 @@ __device__ __forceinline__ void double_scalarmul_ladder_body(uint64_t *out, cons
         ch.push(slot, ml_denominator(pt_load_abi(b1 + 32 * (size_t)i)), live);
         ch.push(slot + ML_SLOT_U4, ml_denominator(pt_load_abi(b2 + 32 * (size_t)i)), live);
     });
-    ch.invert();
+    __shared__ uint32_t s_inv[(BLOCK / 64) * INV_WAVE_LDS_WORDS];
+    ch.invert_wave(s_inv + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS, false);
     // one copy of the ladder, walked twice (see point_dual_scalarmul_ladder_body): s2*b2 first -- its chain slot is
     // the one pushed last -- parked in the operation's slots, then s1*b1 and the addition.
     for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
