@@ -101,6 +101,11 @@ struct InvChain {
     // region of INV_WAVE_LDS_WORDS words that this wave alone uses while the call lasts.  wipe: the chains' products
     // belong to secret data (a nonce's or a secret scalar's multiple in projective form): nothing of them stays in LDS.
     __device__ __forceinline__ void invert_wave(uint32_t *lds, bool wipe) {
+#if defined(GD_NO_WAVE_INVERT)   // (A/B and bisecting: every lane inverts for itself, as until round 5)
+        (void)lds; (void)wipe;
+        invert();
+        return;
+#endif
         acc = wave_shared_invert(acc, lds);
         if (wipe) {
             const uint32_t l = threadIdx.x & 63u;

@@ -5,7 +5,9 @@
 // gf28.hpp here -- the shared inversions and the recovery of the point -- is compiled WITHOUT its pair-wise additions: the
 // aligned pairs change the allocation of the 256 registers the step loop lives in, and the kernels measure 0.7 % slower
 // with them (same-box A/B, profiles/r05/ab_pairs.txt).
+#if !defined(GD_PAIRS_EVERYWHERE)   // (A/B builds: tools/build_variants.py)
 #define GD_NO_PAIRED_ADDS 1
+#endif
 #include "varbase_bodies.hpp"
 
 namespace gd {

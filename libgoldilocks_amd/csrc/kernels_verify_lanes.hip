@@ -4,7 +4,9 @@
 // additions of gf28.hpp: both live at the register limit (72 - 139 spilled registers), and the aligned register pairs
 // cost them more in spills than the additions save (same-box A/B, profiles/r05/ab_pairs.txt: verification of distinct
 // keys 33.6 ms without, 34.5 ms with).
+#if !defined(GD_PAIRS_EVERYWHERE)   // (A/B builds: tools/build_variants.py)
 #define GD_NO_PAIRED_ADDS 1
+#endif
 #include "varbase_bodies.hpp"
 
 namespace gd {

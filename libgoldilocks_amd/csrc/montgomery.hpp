@@ -25,12 +25,24 @@
 #include "point.hpp"
 #include "sc14.hpp"
 #include "gf28s.hpp"
+#include "tables_generated.h"
 
 namespace gd {
 
 constexpr uint32_t ML_C = 39081;            // 1 - d' ... the ladder's small constant: ((A - 2)/4)^-1
 constexpr uint32_t ML_2AC = 156332;         // 2 A * 39081
 constexpr int ML_BITS = 446;                // bits of q
+
+// u(B) of the curve's base point (tools/gen_tables.py; tests/test_tables.py re-derives it): what
+// goldilocks_448_direct_scalarmul multiplies when an encoding does not decode (src/goldilocks.c:898) -- a constant, so
+// that fallback needs no inversion of its own inside a divergent branch
+GD_CONST uint32_t ML_U_BASE28[16] = GD_POINT_BASE_U28_INIT;
+GD_FN fe ml_u_base() {
+    fe r;
+#pragma unroll
+    for (int i = 0; i < 16; i++) r.v[i] = ML_U_BASE28[i];
+    return r;
+}
 
 // What the ladder needs of the base point besides 1/(Y - Z): computed twice (once to learn the denominator
 // that goes into the lane's shared inversion, once when the ladder runs) rather than parked in memory.

@@ -213,7 +213,7 @@ __device__ __forceinline__ void direct_scalarmul_ladder_body(uint8_t *__restrict
         if (!ok && short_circuit) continue;         // the encoding is public: so is this branch
         if (!ok) {                                  // src/goldilocks.c:898: multiply the base point instead
             b = pt_load_abi(point_base_abi);
-            u = fe_mul(fe_add(b.y, b.z), fe_invert(ml_denominator(b)));
+            u = ml_u_base();
         }
         LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(scalar + 7 * (size_t)i)));
         const pt r = ml_scalarmul_u(b, u, bits);

@@ -313,6 +313,11 @@ int hs_direct_scalarmul_ladder(uint8_t *out, const uint8_t *in, const uint64_t *
     pt ref;
     const bool ok2 = pt_decode_words(ref, w, allow_identity != 0);
     if (ok != ok2 || (ok && !(fe_eq(b.x, ref.x) && fe_eq(b.y, ref.y)))) return 7;   // must be the plain decoder's point exactly
+    if (!ok) {                                  // src/goldilocks.c:898: the base point instead (varbase_bodies.hpp's fallback)
+        b = pt_from_abi(GD_POINT_BASE_LIMBS);
+        u = ml_u_base();
+        if (!fe_eq(u, fe_mul(fe_add(b.y, b.z), fe_invert(ml_denominator(b))))) return 8;   // the constant IS u(B)
+    }
     const sc r = sc_reduce(sc_from_abi(scalar));
     HostBits bits;
     for (int i = 0; i < 14; i++) bits.w[i] = r.w[i];

@@ -482,3 +482,22 @@ def test_table_free_ladder_matches_oracle_and_golden_f1(H, O):
         assert O.orc_point_decode(C.byref(p), buf(d["base"][i].tobytes()), 1) == -1
         fb[j] = np.frombuffer(bytes(p), np.uint64)
     assert (_gen.oracle_encode(run(fb, d["scalar"][idx])) == d["out"][idx]).all()
+
+
+def test_direct_scalarmul_through_the_ladder_and_its_base_point_fallback(H, O):
+    """goldilocks_448_direct_scalarmul (src/goldilocks.c:888-903) the way k_direct_scalarmul_ct computes it: the decoder
+    that also yields u(P), the table-free ladder, the encoder -- and, when the encoding does not decode and the call
+    does not short-circuit, the BASE POINT multiplied instead, from its constant u(B) (tools/gen_tables.py)."""
+    H.hs_direct_scalarmul_ladder.restype = C.c_int
+    n = 24
+    s = _gen.random_scalars(n, b"hs-direct-s")
+    base = _gen.oracle_encode(_gen.oracle_fixed(O, _gen.random_scalars(n, b"hs-direct-b")))
+    base[5] = 0                       # identity encoding
+    base[6] = 0xff                    # not a field element
+    base[7, 0] |= 1                   # negative s
+    for allow_id in (0, 1):
+        for i in range(n):
+            want, got = (C.c_uint8 * 56)(), (C.c_uint8 * 56)()
+            r = O.orc_direct_scalarmul(want, base[i].ctypes.data, C.cast(s[i].ctypes.data, C.POINTER(Scalar)), allow_id, 0)
+            r2 = H.hs_direct_scalarmul_ladder(got, base[i].ctypes.data_as(C.c_void_p), s[i].ctypes.data_as(C.c_void_p), allow_id)
+            assert r == r2 and bytes(want) == bytes(got), (i, allow_id, r, r2)
