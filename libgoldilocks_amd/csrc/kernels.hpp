@@ -409,6 +409,14 @@ constexpr int KEY_TEETH_BY_WAVE_MAX = 4096;   // up to so many keys a WAVE compu
 #define GD_KEY_COMB_SEG_MAX 64
 #endif
 constexpr int KEY_COMB_SEG = GD_KEY_COMB_SEG, KEY_COMB_SEG_MAX = GD_KEY_COMB_SEG_MAX;   // (a comb of 7 teeth has 64 entries)
+// ... doubled while the segments would be more than KEY_COMB_OCC_NUM / KEY_COMB_OCC_DEN of the resident lanes
+#ifndef GD_KEY_COMB_OCC_NUM
+#define GD_KEY_COMB_OCC_NUM 1
+#endif
+#ifndef GD_KEY_COMB_OCC_DEN
+#define GD_KEY_COMB_OCC_DEN 2
+#endif
+constexpr uint32_t KEY_COMB_OCC_NUM = GD_KEY_COMB_OCC_NUM, KEY_COMB_OCC_DEN = GD_KEY_COMB_OCC_DEN;
 static_assert(KEY_COMB_SEG >= 1 && KEY_COMB_SEG <= KEY_COMB_SEG_MAX && KEY_COMB_SEG_MAX <= 64 &&
               (KEY_COMB_SEG & (KEY_COMB_SEG - 1)) == 0 && (KEY_COMB_SEG_MAX & (KEY_COMB_SEG_MAX - 1)) == 0, "segments divide a comb");
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)

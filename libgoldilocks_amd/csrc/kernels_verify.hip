@@ -167,7 +167,7 @@ GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict_
                    entries = key_comb_entries(teeth_per);
     const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK;
     uint32_t SEG = (uint32_t)KEY_COMB_SEG;
-    while (SEG < (uint32_t)KEY_COMB_SEG_MAX && (uint64_t)combed * (entries / SEG) > stride / 2) SEG *= 2;
+    while (SEG < (uint32_t)KEY_COMB_SEG_MAX && (uint64_t)combed * (entries / SEG) * KEY_COMB_OCC_DEN > (uint64_t)stride * KEY_COMB_OCC_NUM) SEG *= 2;
     const uint32_t per_key = entries / SEG, total = combed * per_key;
     // wave-uniform rounds: the segments' shared inversions are ONE inversion per wave (inv_wave.hpp) -- an exponentiation
     // was two thirds of this kernel's instructions (95 K against 21 additions' 51 K per segment of 16)
