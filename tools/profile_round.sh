@@ -73,6 +73,8 @@ python3 "$ROOT/tools/trace_timeline.py" "$OUT/trace_verify" k_verify_dedupe > "$
 GOLDILOCKS_AMD_TRACE=1 python3 "$ROOT/tests/e2e_trace_probe.py" > "$DST/e2e_laps.txt" 2>&1
 for o in sequential scattered; do for s in none memcpy; do "$ROOT/tools/hostfeed" --log2n 22 --stage $s --order $o; done; done > "$DST/hostfeed.txt" 2>&1
 "$ROOT/tools/fieldbench" > "$DST/fieldbench.txt" 2>&1
+"$ROOT/tools/stepbench" > "$DST/stepbench.txt" 2>&1
+"$ROOT/tools/fp64gate" > "$DST/fp64gate.txt" 2>&1
 "$ROOT/tools/verifyphases" > "$DST/verifyphases.txt" 2>&1
 "$ROOT/tools/keycombphases_t8m0x1" > "$DST/keycombphases.txt" 2>&1   # 8 teeth, XCD-aware positions: the product's geometry for config 4
 python3 "$ROOT/tests/batch_sweep.py" > "$DST/batch_sweep.txt" 2>&1
