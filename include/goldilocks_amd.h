@@ -534,7 +534,11 @@ GOLDILOCKS_AMD_API int goldilocks_amd_x448_dev_ex(void *shared, void *status, co
  *            10 out = the 56 serialized bytes (limbs 0..6)   11 a = 56 bytes, out = limbs, status = value < p
  *            12 out = (ma*a)*(mb*b), 13 out = (ma*a)^2 with the multiples formed limb-wise without
  *               reduction, ma = (op >> 8) & 0xff, mb = (op >> 16) & 0xff: operands at the limits of the
- *               device arithmetic's magnitude contract. */
+ *               device arithmetic's magnitude contract.
+ *            14 out = (ka*a)*(kb*b), 15 out = (ka*a)^2 through the SIGNED, register-paired layer of the ladders
+ *               (csrc/gf28s.hpp): a multiplicity is 1 .. 3 copies added pair-wise, or with bit 7 set the limb-wise
+ *               negative of that many (a difference-like operand); 15 with (op >> 16) & 0xff != 0: the square of a sum
+ *               of products (its unsigned-offset columns). */
 GOLDILOCKS_AMD_API int goldilocks_amd_field_op_dev(void *out, void *status, const void *a, const void *b,
         int op, size_t n, void *stream);
 

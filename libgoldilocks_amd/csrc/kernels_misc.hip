@@ -1,5 +1,6 @@
 // kernels_misc.hip -- kernel definitions (see kernels.hpp for the memory plan and policies).
 #include "kernels.hpp"
+#include "gf28s.hpp"
 
 namespace gd {
 
@@ -141,6 +142,36 @@ GD_KERNEL k_field_op(uint64_t *__restrict__ out, int32_t *__restrict__ status, c
             fe x;
             ok = fe_deserialize_words(x, w);
             fe_store_limbs_raw(dst, x);
+        } else if (op == 14 || op == 15) {
+            // the signed, register-paired layer of the ladders (gf28s.hpp) through the DEVICE build -- its pair-wise
+            // additions are inline v_lshl_add_u64 there, which no host build runs.  A multiplicity k: k copies added
+            // pair-wise (1 .. 3), or, with bit 7 set, the limb-wise NEGATIVE of that many (a "signed" operand).
+            const auto operand = [&](const uint64_t *p, uint32_t k, auto use) {
+                const sfp x = sfe_from_fe(fe_load_abi(p));
+                const int m = (int)(k & 0x7f);
+                if (k & 0x80) {
+                    sfs xs = sfe_sub(sfe_from_fe(fe_zero()), x);
+                    for (int t = 1; t < m; t++) xs = sfe_sub(xs, x);
+                    use(xs);
+                } else {
+                    sfp xs = x;
+                    for (int t = 1; t < m; t++) xs = sfe_add(xs, x);
+                    use(xs);
+                }
+            };
+            const uint32_t ka = aux & 0xff, kb = aux >> 8;
+            if (op == 14) {
+                operand(pa, ka, [&](const auto &xs) {
+                    operand(pb, kb, [&](const auto &ys) { fe_store_abi(dst, sfe_to_fe(sfe_mul(xs, ys))); });
+                });
+            } else if (kb) {   // the square of a sum of products (columns 0 - 2 of the high half read as unsigned)
+                const sfp x = sfe_from_fe(fe_load_abi(pa));
+                sfp xs = x;
+                for (int t = 1; t < (int)(ka & 0x7f); t++) xs = sfe_add(xs, x);
+                fe_store_abi(dst, sfe_to_fe(sfe_sqr<true>(xs)));
+            } else {
+                operand(pa, ka, [&](const auto &xs) { fe_store_abi(dst, sfe_to_fe(sfe_sqr<false>(xs))); });
+            }
         } else {
             const int ma = (int)(aux & 0xff), mb = (int)(aux >> 8);
             fe x = fe_load_abi(pa), xs = fe_zero();

@@ -16,7 +16,7 @@ from _libs import Gf, P
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 MASK56 = (1 << 56) - 1
-OP = dict(mul=0, sqr=1, isr=2, strong=3, mulw=4, add=5, sub=6, weak=7, eq=8, lobit=9, ser=10, deser=11, mulmag=12, sqrmag=13)
+OP = dict(mul=0, sqr=1, isr=2, strong=3, mulw=4, add=5, sub=6, weak=7, eq=8, lobit=9, ser=10, deser=11, mulmag=12, sqrmag=13, smul=14, ssqr=15)
 
 
 def val(limbs):
@@ -169,7 +169,29 @@ def test_products_at_the_magnitude_limits(ga):
     with pytest.raises(ga.GoldilocksAmdError):
         run(ga, OP["mulmag"] | 9 << 8 | 1 << 16, a, b)
     with pytest.raises(ga.GoldilocksAmdError):
-        run(ga, 14, a, b)
+        run(ga, 16, a, b)
+
+
+def test_signed_paired_layer_at_its_limits_on_the_device(ga):
+    """csrc/gf28s.hpp -- the field layer of the ladders -- through the DEVICE build, where its pair-wise additions are
+    inline v_lshl_add_u64 (the host checker runs plain C for them): products and squares of pairable and of negated
+    operands at the documented limits (mag(a) * mag(b) <= 3, the square of a sum of two products), all-ones limbs
+    among them, every lane against exact integers."""
+    n = 512
+    a = sample(n, 41)
+    b = sample(n, 42)
+    a[9] = MASK56; b[9] = MASK56; a[10] = MASK56; b[11] = MASK56
+    sgn = lambda k: -(k & 0x7f) if k & 0x80 else k
+    for ka, kb in ((1, 1), (2, 1), (1, 2), (3, 1), (2, 0x81), (0x81, 2), (0x81, 0x81), (0x82, 1), (1, 0x82), (3, 0x81), (0x83, 1)):
+        out, _ = run(ga, OP["smul"] | ka << 8 | kb << 16, a, b)
+        for i in range(n):
+            assert val(out[i]) == val(a[i]) * val(b[i]) * sgn(ka) * sgn(kb) % P, ("smul", ka, kb, i)
+    for ka, sum2 in ((1, 0), (0x81, 0), (1, 1), (2, 1)):
+        out, _ = run(ga, OP["ssqr"] | ka << 8 | sum2 << 16, a)
+        for i in range(n):
+            assert val(out[i]) == (val(a[i]) * sgn(ka)) ** 2 % P, ("ssqr", ka, sum2, i)
+    with pytest.raises(ga.GoldilocksAmdError):
+        run(ga, OP["smul"] | 4 << 8 | 1 << 16, a, b)
 
 
 def test_half_size_pair_of_verification(ga):
