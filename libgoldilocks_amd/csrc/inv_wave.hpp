@@ -8,8 +8,10 @@
 // addition chain on 82-instruction vector multiplications), walks back (32 vector multiplications) and every lane reads
 // its own inverse: (16 + 32 + 463) x 82 = 42 K instructions per wave instead of 95 K.
 //
-// Every lane of the wave must call (the values of lanes without work are 1); no value may be zero (InvChain::push
-// replaces zeros by ones).  In: mag <= 2.  Out: limbs < 2^28 + 8 (mag 1).
+// Every lane of the wave must call (the values of lanes without work are 1).  A zero -- InvChain::push never hands one
+// over, but a lane's state may come from memory -- would annihilate the products of its whole row: it is replaced by 1
+// on the way in and comes back as 0, which is what fe_invert(0) gives (gf_invert(0) = 0, src/goldilocks.c:69-80).
+// In: mag <= 2.  Out: limbs < 2^28 + 8 (mag 1).
 #pragma once
 #include "wave_coop.hpp"
 
@@ -20,9 +22,11 @@ constexpr int INV_WAVE_LDS_WORDS = 64 * 16;   // per wave
 __device__ __forceinline__ fe wave_shared_invert(const fe &x, uint32_t *lds /* INV_WAVE_LDS_WORDS of this wave */) {
     const uint32_t l = threadIdx.x & 63u;
     const wc::Lane L = wc::make_lane();
+    const bool zero = fe_is_zero(x);
+    const fe xs = fe_select(x, fe_one(), zero);
     wave_sync();                                   // (whatever the region held before has been read)
 #pragma unroll
-    for (int i = 0; i < 16; i++) lds[l * 16 + i] = x.v[i];
+    for (int i = 0; i < 16; i++) lds[l * 16 + i] = xs.v[i];
     wave_sync();
     // row r takes the elements r, 4 + r, 8 + r, ...: prefix[k] = the product of its elements before the k-th
     wc::wfe prefix[16];
@@ -47,7 +51,7 @@ __device__ __forceinline__ fe wave_shared_invert(const fe &x, uint32_t *lds /* I
 #pragma unroll
     for (int i = 0; i < 16; i++) r.v[i] = lds[l * 16 + i];
     wave_sync();                                   // (before the caller reuses the region)
-    return r;
+    return fe_select(r, fe_zero(), zero);
 }
 
 }  // namespace gd
