@@ -131,3 +131,19 @@ def test_host_feed_probe_runs_without_a_device():
     rows = [l.split() for l in r.stdout.splitlines() if l.split() and l.split()[0].isdigit()]
     assert [int(x[0]) for x in rows] == [1, 2, 4, 8] and all(float(x[2]) > 1e5 for x in rows), r.stdout
     assert "cores usable by this process" in r.stdout
+
+
+def test_reference_tool_rows_of_the_cpu_baseline():
+    """bench.py's cpu_baseline.reference_tool: the reference's own test/bench_goldilocks.cxx, built by oracle/Makefile against
+    the reference library where /root/reference is, runs on the host and its Ed448 rows parse (seconds per operation)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rows = bench.reference_tool_rows("x86_64")
+    if rows is None:
+        pytest.skip("oracle/_ref/bench_goldilocks_x86_64 not built here (no /root/reference)")
+    assert "error" not in rows, rows
+    t = rows["seconds_per_op"]
+    assert 1e-5 < t["Point scalarmul"] < 1e-2 and 1e-5 < t["EdDSA verify"] < 1e-2
+    assert abs(rows["point_scalarmul_per_s"] * t["Point scalarmul"] - 1) < 1e-9
