@@ -3,7 +3,9 @@
 // Each lane walks N steps from the same start with the same swap bits; the two final states are compared
 // limb by limb in canonical form (every lane), then both loops are timed at two waves per SIMD.
 //
-//   hipcc -std=c++17 -O3 --offload-arch=gfx950 -Ilibgoldilocks_amd/csrc -o tools/stepbench tools/stepbench.hip
+//   hipcc -std=c++17 -O3 --offload-arch=gfx950 -Ilibgoldilocks_amd/csrc -DGD_NO_PAIRED_ADDS=1 -o tools/stepbench tools/stepbench.hip
+// (GD_NO_PAIRED_ADDS: the reference side is round 4's step as it was; with gf28.hpp's pair-wise additions the UNSIGNED step
+// measures 17 % slower -- 14 899 cycles -- which is one more reason the ladders' unit is built without them)
 #include <hip/hip_runtime.h>
 
 #include <stdio.h>
