@@ -683,8 +683,8 @@ def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_t
                     "frac": macs / VALU_MAC_PEAK, "macs_per_op": spec["macs"], "peaks": VALU_MAC_PEAKS}
     # ... and the ceiling all of it runs against: VALU issue, one wave-instruction per SIMD per four cycles.  The instruction
     # count is SQ_INSTS_VALU of a 2^20-operation launch from the stamped PMC passes (scaled to this launch's n); the time
-    # is this run's.  What is left below 1.0 is the clock the chip holds under this load (it runs the ladder at about
-    # 2.2 GHz, not 2.4) and a few percent of stalls; the lever is instructions per operation.
+    # is this run's.  What is left below 1.0 is the clock the chip holds under this load (2.30 - 2.32 GHz at 1.31 kW:
+    # power-limited, profiles/r05/clock_under_load.txt) and about five percent of stalls; the lever is instructions per operation.
     insts = pmc_valu_insts(traffic_kernels or kernel)
     if insts:
         per_s = insts * (n / float(1 << LOG2_BATCH)) / (avg_ms * 1e-3)
