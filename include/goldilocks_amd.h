@@ -406,8 +406,9 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_combs_xwide(size_t min_sig
  * signing, X448 key generation and the base point's precomputed_scalarmul.  A device builds it at the first call that
  * needs it (tens of milliseconds) and keeps it until goldilocks_amd_shutdown.  Wider digits trade device memory for
  * additions: 16 bits = 27 additions from 168 MiB (Infinity-Cache resident), 18 = 24 from 600 MiB, 20 = 22 from 2.2 GiB,
- * 22 = 20 from 7.9 GiB, 24 = 18 from 28.5 GiB of HBM (2^20 verifications of distinct signatures on 2^10 keys: 8.10 / - /
- * 7.86 / 7.72 / 7.59 ms; base-point multiplications with digit-addressed tables: 498 / 503 / 532 / 571 / 610 M/s).
+ * 22 = 20 from 7.9 GiB, 24 = 18 from 28.5 GiB of HBM (2^20 verifications of distinct signatures on 2^10 keys, one box,
+ * round 5: 7.63 / 7.54 / 7.44 / 7.32 / 7.24 ms at 16 / 18 / 20 / 22 / 24 bits; base-point multiplications with
+ * digit-addressed tables: 507 / 544 / 632 M/s at 16 / 20 / 24; profiles/r05/bench_verify_widths.txt).
  * bits = 0 (the default) is GOLDILOCKS_AMD_BASE_TABLE_BITS_DEFAULT = 20: 2.2 GiB whatever else the device holds -- the
  * wider tables buy 2 - 4 % for up to 26 GiB more and are the caller's decision.  GOLDILOCKS_AMD_BASE_TABLE_BITS_AUTO asks
  * for the widest whose table takes at most an eighth of the device memory free at that first call, never below 16 (24 bits
