@@ -33,7 +33,7 @@ using namespace gd;
         }                                                              \
     } while (0)
 
-enum Op { INT_MUL, INT_SQR, SGN_MUL, SGN_SQR, FP_A_81, FP_A_75, FP_B_108 };
+enum Op { INT_MUL, INT_SQR, SGN_MUL, SGN_SQR, FP_A_81, FP_A_75, FP_B_108, FP_B_108_READOUT };
 
 // (A): PRODUCTS exact limb products, three independent accumulation chains at a time (like the integer code's)
 template <int PRODUCTS>
@@ -60,6 +60,36 @@ __device__ __forceinline__ void fp_b(double (&a)[12], double (&b)[12], uint32_t 
         low[k % 3] += (uint64_t)al[k % 12] * bl[(k / 12 + k) % 12];
         asm("" : "+v"(acc[k % 3]), "+v"(low[k % 3]));
     }
+}
+
+// (B) again, plus what every one of its 24 columns and 12 result limbs needs at the very least before the next
+// multiplication can start -- still no Karatsuba combination, no mixed-radix doubling, no reduction by p:
+//   column:  H = acc - anchor (v_add_f64); its integer bits by a magic addition (v_add_f64); E = low word - H's low word
+//            (v_sub_u32); the column = H + E (v_lshl_add_u64 with E sign-extended: + v_ashrrev_i32); + carry in
+//            (v_lshl_add_u64); limb = low 38 bits (two v_and); carry out (v_lshrrev_b64)                      = 9
+//   result limb: back to a double (two v_cvt_f64_u32 + one v_fma_f64) and its low word (free)                  = 3
+__device__ __forceinline__ void fp_b_readout(double (&a)[12], uint32_t (&al)[12], double (&acc)[3], uint64_t (&low)[3]) {
+    uint64_t carry = 0;
+#pragma unroll
+    for (int c = 0; c < 24; c++) {
+        double h = acc[c % 3] - 0x1p84;
+        double m = h + 0x1.8p52;
+        asm("" : "+v"(h), "+v"(m));
+        const uint64_t hb = (uint64_t)__double_as_longlong(m) & 0xfffffffffffffull;
+        const int32_t e = (int32_t)((uint32_t)low[c % 3] - (uint32_t)hb);
+        uint64_t col = hb + (uint64_t)(int64_t)e + carry;
+        asm("" : "+v"(col));
+        const uint64_t limb = col & ((1ull << 38) - 1);
+        carry = col >> 38;
+        if (c < 12) {
+            const uint32_t lo = (uint32_t)limb, hi = (uint32_t)(limb >> 32);
+            a[c] = __builtin_fma((double)hi, 0x1p32, (double)lo);
+            al[c] = lo;
+        } else {
+            low[c % 3] += limb;   // (keeps the high columns' read-outs alive)
+        }
+    }
+    acc[0] += (double)(uint32_t)carry;
 }
 
 template <int OP>
@@ -94,7 +124,7 @@ __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
         }
         x.v[0] = (uint32_t)(sh[0] + sh[1] + sh[2]);
         x.v[1] = (uint32_t)(sl[0] + sl[1] + sl[2]);
-    } else {
+    } else {   // FP_B_108, FP_B_108_READOUT
         double a[12], b[12], acc[3] = {0x1p84, 0x1p84, 0x1p84};
         uint32_t al[12], bl[12];
         uint64_t low[3] = {0, 0, 0};
@@ -109,6 +139,7 @@ __global__ void __launch_bounds__(256, 2) k_chain(uint32_t *io, int n) {
 #pragma unroll
             for (int i = 0; i < 12; i++) asm("" : "+v"(a[i]), "+v"(b[i]), "+v"(al[i]), "+v"(bl[i]));
             fp_b<108>(a, b, al, bl, acc, low);
+            if (OP == FP_B_108_READOUT) fp_b_readout(a, al, acc, low);
 #pragma unroll
             for (int c = 0; c < 3; c++) acc[c] = acc[c] > 0x1p85 ? 0x1p84 : acc[c];   // (stay in the anchored binade)
         }
@@ -156,6 +187,7 @@ int main() {
         run<FP_A_81>("FP64 (A) 81 exact products, multiply instructions ONLY", d);
         run<FP_A_75>("FP64 (A) 75 exact products, multiply instructions ONLY", d);
         run<FP_B_108>("FP64+int (B) 108 products, multiply instructions ONLY", d);
+        run<FP_B_108_READOUT>("FP64+int (B) 108 products + column read-out + conversion", d);
     }
     return 0;
 }
