@@ -435,8 +435,9 @@ GD_FN KeycombPending ed448_verify_keycomb_begin(const Ed448Msg &m, const FB &fb,
     uint32_t w[29];
     shake256_114(w, m, m.total(), stage);
     const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));     // -h mod q
-    auto bits = mkbits(COMB::plan::recode(challenge), 0);
-    pt P = ladder_comb(bits, comb);                                           // -h*A, T included
+    // (public digits, a comb read by the digit: transposed once, the next entry requested an addition ahead)
+    auto dig = mkbits.template digits<typename COMB::plan>(COMB::plan::recode(challenge));
+    pt P = ladder_comb_digits(dig, comb);                                     // -h*A, T included
     if (q.have()) {
         pt_add_pniels(P, q.load(), false, true);                              // + S*B, computed ahead
     } else {
@@ -612,6 +613,17 @@ struct HostMkBits {
         for (int i = 0; i < 14; i++) b.w[i] = s.w[i];
         b.w[14] = 0;
         return b;
+    }
+    struct HostDigits {     // scalarmul.hpp comb_digits: two 16-bit digits per word
+        uint32_t w[32];
+        void put(int k, uint32_t two) { w[k] = two; }
+        uint32_t get(int t) const { return (w[t >> 1] >> (16 * (t & 1))) & 0xffffu; }
+    };
+    template <class PLAN>
+    HostDigits digits(const sc &recoded) const {
+        HostDigits d;
+        comb_digits<PLAN>::store(d, recoded);
+        return d;
     }
 };
 #endif

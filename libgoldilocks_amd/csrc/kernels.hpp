@@ -467,6 +467,7 @@ struct LdsMkBits {
 // Verification's three scalars in 16 words of LDS per lane: the two half-size ones of the joint ladder are 225
 // bits each (words 0..7 and 8..15), and the base point's full-size one is only made when they are dead (words 0..13
 // and a zero fifteenth).
+constexpr int VERIFY_LDS_WORDS = 32;   // per lane: 16 for the scalars' bits, 32 where a key's comb is walked by its digits
 struct LdsMkBitsVerify {
     uint32_t *slot0;
     __device__ __forceinline__ LdsBits operator()(const sc &s, int) const {
@@ -480,6 +481,31 @@ struct LdsMkBitsVerify {
 #pragma unroll
         for (int k = 0; k < 8; k++) slot[k * BLOCK] = w[k];
         return LdsBits{slot};
+    }
+    // the digits of a key's comb in the order its walk consumes them (scalarmul.hpp comb_digits): two per word, the
+    // same word-major slot -- VERIFY_LDS_WORDS per lane cover the widest plan's 64 digits
+    // (get() re-derives the lane's slot from the wave's first thread -- a scalar register -- and the lane number: kept in
+    // a vector register across the walk's loop, the slot's address was spilled and re-read from scratch, waited for,
+    // ahead of every digit)
+    struct Digits {
+        uint32_t *slot;
+        uint32_t wave_slot;     // LDS byte address of the slot of the wave's lane 0: uniform
+        __device__ __forceinline__ void put(int k, uint32_t two) const { slot[k * BLOCK] = two; }
+        __device__ __forceinline__ uint32_t get(int t) const {
+            uint32_t lane;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+            const uint32_t at = wave_slot + 4u * lane + (uint32_t)(t >> 1) * (4u * BLOCK) + 2u * (uint32_t)(t & 1);
+            return *(const __attribute__((address_space(3))) uint16_t *)(uintptr_t)at;
+        }
+    };
+    template <class PLAN>
+    __device__ __forceinline__ Digits digits(const sc &recoded) const {
+        static_assert(comb_digits<PLAN>::WORDS <= VERIFY_LDS_WORDS, "the lane's LDS slot holds the plan's digits");
+        const uint32_t in_wave = threadIdx.x & 63u;
+        Digits d{slot0, (uint32_t)__builtin_amdgcn_readfirstlane(
+                            (int)(uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(slot0 - in_wave))};
+        comb_digits<PLAN>::store(d, recoded);
+        return d;
     }
 };
 

@@ -338,7 +338,7 @@ __device__ __forceinline__ void verify_keycomb_body(const uint8_t *__restrict__ 
                                  uint4 *__restrict__ park, const uint32_t *__restrict__ order,
                                  uint4 *__restrict__ chain_state, uint32_t resume,
                                  const uint4 *__restrict__ qpark, uint32_t q_count) {
-    __shared__ uint32_t s_bits[16 * BLOCK];
+    __shared__ uint32_t s_bits[VERIFY_LDS_WORDS * BLOCK];
     if (ctrl[3] != (uint32_t)PLAN::TEETH) return;   // this batch's keys are served otherwise (k_ed448_verify, or the other comb)
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> b_tab{bwt_tab};

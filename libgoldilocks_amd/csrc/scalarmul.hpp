@@ -172,6 +172,66 @@ GD_FN pt ladder_comb(const BITS &bits, const COMB &comb) {
     return acc;
 }
 
+// ---- the same walk for PUBLIC digits and a comb that is READ BY THE DIGIT (a verification key's comb in global
+// memory, kernels_verify.hip).  ladder_comb above fetches a digit's T bits with T dependent LDS reads and only then
+// asks for the entry, N * S times per multiplication, each time waited for (round 5's counters: the key-comb kernel
+// spent 19 % of its wave cycles in s_waitcnt against the ladder kernel's 9 %).  Here the N * S digits are transposed out
+// of the recoded scalar ONCE (all bit positions are compile-time constants: two instructions per bit), kept as 16-bit
+// (index | sign << 15) in the order the walk consumes them, and the entry of digit t + 1 is requested BEFORE the
+// addition of digit t -- as ladder_bwt_onto does for the base point's table.
+// DIG: dig.put(word k, two digits) / dig.get(t) -> digit t.
+template <class PLAN>
+struct comb_digits {
+    static constexpr int COUNT = PLAN::COMBS * PLAN::SPACING, WORDS = (COUNT + 1) / 2;
+    // digit t of the walk: round i = S - 1 - t / N, comb j = t % N  (src/goldilocks.c:846-862 for N = T = 5, S = 18)
+    static GD_MFN uint32_t digit(const sc &r, int t) {
+        constexpr int T = PLAN::TEETH, N = PLAN::COMBS, S = PLAN::SPACING;
+        const int i = S - 1 - t / N, j = t % N;
+        uint32_t tab = 0;
+#pragma unroll
+        for (int k = 0; k < T; k++) {
+            const int bit = i + S * (k + T * j);
+            if (bit < 446) tab |= ((r.w[bit >> 5] >> (bit & 31)) & 1u) << k;
+        }
+        uint32_t idx;
+        bool neg;
+        signed_digit_w<T>(tab, idx, neg);
+        return idx | (neg ? 0x8000u : 0u);
+    }
+    template <class DIG>
+    static GD_MFN void store(DIG &dig, const sc &r) {
+#pragma unroll
+        for (int k = 0; k < WORDS; k++)
+            dig.put(k, digit(r, 2 * k) | (2 * k + 1 < COUNT ? digit(r, 2 * k + 1) << 16 : 0u));
+    }
+};
+template <class DIG, class COMB>
+GD_FN pt ladder_comb_digits(const DIG &dig, const COMB &comb) {
+    using PLAN = typename COMB::plan;
+    constexpr int N = PLAN::COMBS, COUNT = comb_digits<PLAN>::COUNT;
+    uint32_t d = dig.get(0);
+    pt acc = niels_to_pt(comb.load(0, d & 0x7fffu), (d & 0x8000u) != 0);
+    d = dig.get(1);
+    niels next = comb.load(1 % N, d & 0x7fffu);
+    int j = 1 % N;
+#pragma unroll 1
+    for (int t = 1; t < COUNT; t++) {
+        const niels e = next;
+        const bool neg = (d & 0x8000u) != 0, first = j == 0, last = j == N - 1;
+        j = last ? 0 : j + 1;
+        if (t + 1 < COUNT) {
+            d = dig.get(t + 1);
+            next = comb.load(j, d & 0x7fffu);
+        }
+        gd_keep_order();        // (the scheduler would otherwise sink the reads to right before their first use)
+        if (first) pt_double(acc, true);
+        // T feeds the next addition; a round's last addition is followed by a doubling (which ignores T) unless it
+        // is the very last one, whose caller wants a complete extended point
+        pt_add_niels(acc, e, neg, !(last && t + 1 < COUNT));
+    }
+    return acc;
+}
+
 // ---- the 4 x 7 x 16 comb of an ARBITRARY point P (a caller's table re-combed, kernels_fixed.hip; a verification
 // key that signed many of a batch's signatures, kernels_verify.hip).  Tooth m (m < 28) is 2^(16 m) * P; entry
 // e = 64 j + idx is T_(6+7j) + sum_{k<6} (+-) T_(k+7j), + iff bit k of idx, as an affine niels in our form.
