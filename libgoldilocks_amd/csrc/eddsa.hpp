@@ -151,11 +151,11 @@ struct shake256 {
 
 // ------------------------------------------------------------------ challenge hash
 // The hashed string is  "SigEd448" | ph | ctxlen | ctx | R(57) | A(57) | msg.
-// MSG policy: src.word(j) returns bytes j .. j+3 of that virtual string as a little-endian word, zero beyond
-// its end (j a multiple of 4).  A 136-byte block is absorbed as 34 such words with compile-time indices, so
-// the Keccak state stays in registers and the 34 reads of a block are in flight together (read byte by byte,
-// each read waiting for the one before, the two blocks of a verification cost 4 % of the kernel:
-// tools/verifyphases).  Returns the first 114 output bytes as 29 words (top 2 bytes of word 28 zero).
+// MSG policy: src.block(w, blk) fills w with bytes 136 blk .. 136 blk + 135 of that virtual string as 34 little-endian
+// words, zero beyond its end.  A block is absorbed as 34 such words with compile-time indices, so the Keccak state
+// stays in registers and the 34 reads of a block are in flight together (read byte by byte, each read waiting for
+// the one before, the two blocks of a verification cost 4 % of the kernel: tools/verifyphases).
+// Returns the first 114 output bytes as 29 words (top 2 bytes of word 28 zero).
 template <class MSG, class STAGE>
 GD_FN void shake256_114(uint32_t out[29], const MSG &src, uint32_t total, STAGE &stage) {
     (void)stage;
@@ -167,12 +167,16 @@ GD_FN void shake256_114(uint32_t out[29], const MSG &src, uint32_t total, STAGE 
     for (uint32_t blk = 0; blk < nblocks; blk++) {
         const uint32_t base = blk * SHAKE256_RATE;
         uint32_t w[SHAKE256_RATE / 4];
+        src.block(w, blk);
 #pragma unroll
         for (int i = 0; i < SHAKE256_RATE / 4; i++) {
             const uint32_t j = base + 4 * i;
-            uint32_t v = src.word(j);
-            if (total >= j && total < j + 4) v |= 0x1fu << (8 * (total - j));   // SHAKE's domain byte right behind the string
-            w[i] = v;
+            // SHAKE's domain byte right behind the string (by a mask, not under a branch: 34 branches per block)
+            uint32_t here = total - j < 4u ? ~0u : 0u;
+#if defined(__HIPCC__)
+            asm("" : "+v"(here));
+#endif
+            w[i] |= (0x1fu << ((8 * (total - j)) & 31u)) & here;
         }
         if (blk == nblocks - 1) w[SHAKE256_RATE / 4 - 1] ^= 0x80000000u;        // the last byte of the last block
 #pragma unroll
@@ -275,6 +279,56 @@ struct Ed448Msg {
         for (uint32_t k = 0; k < 4; k++)
             if (j + k < end) v |= byte(j + k) << (8 * k);
         return v;
+    }
+    // The string of a verification or a signature's challenge with an EMPTY context -- "SigEd448" | ph | 0 | R(57) |
+    // pk(57) | msg -- has one layout up to byte 124, where the message starts, word-aligned.  word() decides for each
+    // of a block's 34 words which piece it lies in, with offsets that are run-time values and lengths that may differ
+    // from lane to lane: 7 K instructions, a fifth of them reloads of spilled scalar registers, and 160 waits per
+    // signature in k_ed448_verify_keycomb (round 6's ISA count) for what is 31 reads at fixed offsets and a message.
+    GD_MFN bool fixed_head() const { return dom && ctxlen == 0 && alen == 57 && blen == 57; }
+    // bytes m .. m+3 of the message (m a multiple of 4), zero beyond its end, without a branch: a word that reaches
+    // beyond the end is cut out of the message's LAST four bytes; a message shorter than that is `shortw` (its bytes,
+    // read one by one by the caller) and the read goes to R instead, whose 57 bytes are always there.
+    GD_MFN uint32_t msg_word(uint32_t m, uint32_t shortw) const {
+        const bool longm = msglen >= 4;
+        const uint32_t last = longm ? msglen - 4 : 0u, at = m < last ? m : last;
+        const uint32_t v = load32((longm ? msg : a) + at);
+        const uint32_t cut = v >> ((8 * (m - at)) & 31u);
+        // (a mask the compiler cannot see through: as a selection it puts each read under a branch of its own and waits
+        // for it there, 37 times per signature)
+        uint32_t keep = longm && m < msglen ? ~0u : 0u;
+#if defined(__HIPCC__)
+        asm("" : "+v"(keep));
+#endif
+        return (cut & keep) | (!longm && m == 0 ? shortw : 0u);
+    }
+    GD_MFN void block(uint32_t (&w)[34], uint32_t blk) const {
+        if (!fixed_head()) {
+#pragma unroll
+            for (int i = 0; i < 34; i++) w[i] = word(blk * 136 + 4 * i);
+            return;
+        }
+        uint32_t shortw = 0;
+        if (msglen < 4) {
+#pragma unroll
+            for (uint32_t k = 0; k < 3; k++)
+                if (k < msglen) shortw |= (uint32_t)msg[k] << (8 * k);
+        }
+        if (blk == 0) {
+            w[0] = 0x45676953u;                                        // "SigE"
+            w[1] = 0x38343464u;                                        // "d448"
+            w[2] = ph | (uint32_t)a[0] << 16 | (uint32_t)a[1] << 24;   // ph, ctxlen = 0, R[0..1]
+#pragma unroll
+            for (int k = 0; k < 13; k++) w[3 + k] = load32(a + 2 + 4 * k);           // R[2..53]
+            w[16] = load32(a + 53) >> 8 | (uint32_t)b[0] << 24;                      // R[54..56], pk[0]
+#pragma unroll
+            for (int k = 0; k < 14; k++) w[17 + k] = load32(b + 1 + 4 * k);          // pk[1..56]
+#pragma unroll
+            for (int k = 0; k < 3; k++) w[31 + k] = msg_word(4 * k, shortw);         // the message starts at byte 124
+        } else {
+#pragma unroll
+            for (int i = 0; i < 34; i++) w[i] = msg_word(blk * 136 + 4 * i - 124, shortw);
+        }
     }
 };
 GD_FN Ed448Msg ed448_challenge_string(const uint8_t *r57, const uint8_t *pk57, const uint8_t *msg, uint32_t msglen,
