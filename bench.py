@@ -389,7 +389,7 @@ def end_to_end(cx, reps=5):
                                                            None, 0, n), 207, "goldilocks_ed448_verify_batch"),
     }
     # the link, measured here and now: 256 MiB from / to pageable host memory, the kind of memory the calls below get
-    # (best of three; tests/h2d_probe.py has the pinned figures beside them)
+    # (best of three; tools/probes/h2d_probe.py has the pinned figures beside them)
     torch = cx.torch
     probe_h = torch.from_numpy(np.ones(1 << 28, dtype=np.uint8))
     probe_d = torch.empty(1 << 28, dtype=torch.uint8, device="cuda")

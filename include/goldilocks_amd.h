@@ -215,6 +215,20 @@ GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_x448(uint8_t shared[GOLDILOCKS_
 GOLDILOCKS_AMD_API void goldilocks_x448_derive_public_key(uint8_t out[GOLDILOCKS_X448_PUBLIC_BYTES],
         const uint8_t scalar[GOLDILOCKS_X448_PRIVATE_BYTES]);
 GOLDILOCKS_AMD_API extern const uint8_t goldilocks_x448_base_point[GOLDILOCKS_X448_PUBLIC_BYTES]; /* ref: point_448.h:413 */
+/* out = (y / x)^2 of the internal point: the RFC 7748 encoding of GOLDILOCKS_X448_ENCODE_RATIO times the point (the base
+ * point gives that multiple of the X448 base point); 1/0 = 0.  ref: point_448.h:404-427, src/goldilocks.c:1104-1115 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_mul_by_ratio_and_encode_like_x448(uint8_t out[GOLDILOCKS_X448_PUBLIC_BYTES],
+        const goldilocks_448_point_p p);
+/* The secret scalar of an Ed448 private key -- clamp(SHAKE256(privkey)[0:57]) mod q, divided by the encode ratio -- and its
+ * X448 private key, SHAKE256(ed)[0:56].  ref: ed448.h:52-64, 250-263, src/eddsa.c:83-128 */
+GOLDILOCKS_AMD_API void goldilocks_ed448_derive_secret_scalar(goldilocks_448_scalar_p secret,
+        const uint8_t privkey[GOLDILOCKS_EDDSA_448_PRIVATE_BYTES]);
+GOLDILOCKS_AMD_API void goldilocks_ed448_convert_private_key_to_x448(uint8_t x[GOLDILOCKS_X448_PRIVATE_BYTES],
+        const uint8_t ed[GOLDILOCKS_EDDSA_448_PRIVATE_BYTES]);
+/* x = y^2 (1 - d y^2) / (1 - y^2) of an Ed448 public key's y (its sign byte is not read).
+ * ref: ed448.h:234-248, src/goldilocks.c:1079-1102 */
+GOLDILOCKS_AMD_API void goldilocks_ed448_convert_public_key_to_x448(uint8_t x[GOLDILOCKS_X448_PUBLIC_BYTES],
+        const uint8_t ed[GOLDILOCKS_EDDSA_448_PUBLIC_BYTES]);
 
 /* ------------------------------------------------------------------ (2) host-array batches
  * All return 0 on success, nonzero on a runtime (HIP) error -- see goldilocks_amd_last_error().
@@ -275,6 +289,15 @@ GOLDILOCKS_AMD_API int goldilocks_448_point_dual_scalarmul_batch(goldilocks_448_
 /* uniform == 0: n*56 bytes in; otherwise n*112 */
 GOLDILOCKS_AMD_API int goldilocks_448_point_from_hash_batch(goldilocks_448_point_s *pt,
         const uint8_t *hashed_data, int uniform, size_t n);
+/* out[i] = point_mul_by_ratio_and_encode_like_x448(pt[i]); x[i] = ed448_convert_public_key_to_x448(ed[i]) */
+GOLDILOCKS_AMD_API int goldilocks_448_point_mul_by_ratio_and_encode_like_x448_batch(uint8_t *out /* n*56 */,
+        const goldilocks_448_point_s *pt, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_ed448_convert_public_key_to_x448_batch(uint8_t *x /* n*56 */, const uint8_t *ed /* n*57 */,
+        size_t n);
+GOLDILOCKS_AMD_API int goldilocks_ed448_derive_secret_scalar_batch(goldilocks_448_scalar_s *secret,
+        const uint8_t *privkey /* n*57 */, size_t n);
+GOLDILOCKS_AMD_API int goldilocks_ed448_convert_private_key_to_x448_batch(uint8_t *x /* n*56 */, const uint8_t *ed /* n*57 */,
+        size_t n);
 /* status[i] = goldilocks_x448(shared[i], base[i], scalar[i]); base == NULL: the base point (derive_public_key) */
 GOLDILOCKS_AMD_API int goldilocks_x448_batch(uint8_t *shared /* n*56 */, goldilocks_error_t *status,
         const uint8_t *base /* n*56 or NULL */, const uint8_t *scalar /* n*56 */, size_t n);
@@ -354,7 +377,7 @@ GOLDILOCKS_AMD_API void goldilocks_amd_thread_mode_counts(uint64_t counts[2]);
 /* Small batches.  One lane's ladder takes 2.1-2.8 ms however few operations a call has, so batches of
  * up to `n` variable-base, double-base or dual multiplications -- 3n/4 fixed-base multiplications or X448
  * shared secrets, n/2 verifications, wire-format multiplications, key derivations, X448 key generations
- * or comb tables (precompute), n/4 signatures: the measured crossovers, tests/crossover_probe.py -- and
+ * or comb tables (precompute), n/4 signatures: the measured crossovers, tools/probes/crossover_probe.py -- and
  * up to 1024 encodings, decodings or hash-to-curve maps, the single-operation drop-in names included,
  * run ONE OPERATION PER WAVEFRONT instead: the 64 lanes share the operation (a field element spread
  * over the 16 lanes of a row, four field elements per register), 0.35 ms per multiplication call,
@@ -378,7 +401,7 @@ GOLDILOCKS_AMD_API void goldilocks_amd_set_verify_key_pool(size_t keys, size_t m
  * ladder and without R's decoding -- 0.3 of the arithmetic.  Used when the batch averages at least
  * `min_signatures_per_key` signatures per distinct key (twice that for batches below 2^18 signatures, four times below 2^17,
  * where the fixed latency of building the combs weighs more: 8 / 16 / 32 by default, the measured break-evens of
- * tests/key_pool_probe.py) and has at most `keys` distinct keys, in batches of more than 2^12
+ * tools/probes/key_pool_probe.py) and has at most `keys` distinct keys, in batches of more than 2^12
  * signatures (whatever the pool's min_batch); otherwise the pool's rules apply.  Verdicts do not change.  keys = 0 turns the
  * combs off; 2^17 is the most and the default.  `keys` is a CEILING: a batch can use at most n / min_signatures_per_key
  * combs, so that is what a call reserves workspace for -- 71 KiB of device memory per such key, never more than
@@ -438,7 +461,7 @@ GOLDILOCKS_AMD_API int goldilocks_amd_last_verify_key_counts(uint32_t counts[4])
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,
         size_t *workspace_bytes);
 /* Gives device memory of the calling thread's device back without ending the context: the library keeps its workspace
- * (sized by the largest batch so far: 10 GiB after 2^20 verifications), the staging buffers of the host-array entry points
+ * (sized by the largest batch so far: at most 7.5 GiB after 2^20 verifications), the staging buffers of the host-array entry points
  * and the base point's window table (2.2 GiB by default) from their first use until goldilocks_amd_shutdown, because
  * allocating them costs milliseconds per call.  A service that is done with a burst can release any of them; the next call
  * that needs one allocates (and, for the table, builds: 0.16 s) it again.  Waits for the device.  Returns 0 on success. */
@@ -500,6 +523,15 @@ GOLDILOCKS_AMD_API int goldilocks_amd_direct_scalarmul_dev(void *scaled /* n*56 
 GOLDILOCKS_AMD_API int goldilocks_amd_point_dual_scalarmul_dev(void *a1, void *a2, const void *base,
         const void *scalar1, const void *scalar2, size_t n, void *stream);
 GOLDILOCKS_AMD_API int goldilocks_amd_point_from_hash_dev(void *pt, const void *hashed_data, int uniform,
+        size_t n, void *stream);
+/* the two conversions above over device arrays */
+GOLDILOCKS_AMD_API int goldilocks_amd_point_encode_like_x448_dev(void *out /* n*56 */, const void *pt /* n*256 */, size_t n,
+        void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_ed448_convert_public_key_to_x448_dev(void *x /* n*56 */, const void *ed /* n*57 */,
+        size_t n, void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_ed448_derive_secret_scalar_dev(void *secret /* n*56 */, const void *privkey /* n*57 */,
+        size_t n, void *stream);
+GOLDILOCKS_AMD_API int goldilocks_amd_ed448_convert_private_key_to_x448_dev(void *x /* n*56 */, const void *ed /* n*57 */,
         size_t n, void *stream);
 /* base == NULL: x448_derive_public_key for every lane (status all success); status: int32[n] or NULL */
 GOLDILOCKS_AMD_API int goldilocks_amd_x448_dev(void *shared /* n*56 */, void *status, const void *base,

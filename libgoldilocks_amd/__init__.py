@@ -18,7 +18,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GOLDILOCKS_AMD_LIB selects an experimental build variant (tests/gpu_probe.py); default: the in-tree product.
+# GOLDILOCKS_AMD_LIB selects an experimental build variant (tools/probes/gpu_probe.py); default: the in-tree product.
 LIB_PATH = os.environ.get("GOLDILOCKS_AMD_LIB") or os.path.join(_HERE, "libgoldilocks_amd.so")
 
 GOLDILOCKS_SUCCESS = -1
@@ -73,6 +73,14 @@ FUNCTIONS = {
     "goldilocks_ed448_sign_batch": (C.c_int, "pppppBpBz"),
     "goldilocks_448_direct_scalarmul_batch": (C.c_int, "ppppQQz"),
     "goldilocks_x448_batch": (C.c_int, "ppppz"),
+    "goldilocks_448_point_mul_by_ratio_and_encode_like_x448_batch": (C.c_int, "ppz"),
+    "goldilocks_ed448_convert_public_key_to_x448_batch": (C.c_int, "ppz"),
+    "goldilocks_ed448_derive_secret_scalar_batch": (C.c_int, "ppz"),
+    "goldilocks_ed448_convert_private_key_to_x448_batch": (C.c_int, "ppz"),
+    "goldilocks_448_point_mul_by_ratio_and_encode_like_x448": (None, "pp"),
+    "goldilocks_ed448_convert_public_key_to_x448": (None, "pp"),
+    "goldilocks_ed448_derive_secret_scalar": (None, "pp"),
+    "goldilocks_ed448_convert_private_key_to_x448": (None, "pp"),
     "goldilocks_448_point_dual_scalarmul_batch": (C.c_int, "pppppz"),
     "goldilocks_448_point_from_hash_batch": (C.c_int, "ppiz"),
     # (3) device-array API
@@ -114,6 +122,10 @@ FUNCTIONS = {
     "goldilocks_amd_ed448_sign_dev": (C.c_int, "pppppzBpBzp"),
     "goldilocks_amd_direct_scalarmul_dev": (C.c_int, "ppppiizp"),
     "goldilocks_amd_x448_dev": (C.c_int, "ppppzp"),
+    "goldilocks_amd_point_encode_like_x448_dev": (C.c_int, "ppzp"),
+    "goldilocks_amd_ed448_convert_public_key_to_x448_dev": (C.c_int, "ppzp"),
+    "goldilocks_amd_ed448_derive_secret_scalar_dev": (C.c_int, "ppzp"),
+    "goldilocks_amd_ed448_convert_private_key_to_x448_dev": (C.c_int, "ppzp"),
     "goldilocks_amd_point_dual_scalarmul_dev": (C.c_int, "pppppzp"),
     "goldilocks_amd_point_from_hash_dev": (C.c_int, "ppizp"),
     # ... with the table access of the call (GOLDILOCKS_AMD_CALL_TABLES_*)
@@ -157,7 +169,14 @@ def lib():
             pass
         L = C.CDLL(LIB_PATH)
         for name, (res, sig) in FUNCTIONS.items():
-            f = getattr(L, name)
+            try:
+                f = getattr(L, name)
+            except AttributeError:
+                # an experimental build selected with GOLDILOCKS_AMD_LIB may predate an entry point (A/B runs against an
+                # older round's library); the product must export everything the header declares (tests/test_abi.py)
+                if "GOLDILOCKS_AMD_LIB" in os.environ:
+                    continue
+                raise
             f.restype = res
             f.argtypes = [_CT[ch] for ch in sig]
         _lib = L
@@ -370,6 +389,20 @@ def x448_batch(scalars56, bases56=None):
     b = None if bases56 is None else _ptr(_u8(bases56, 56))
     _check(lib().goldilocks_x448_batch(_ptr(out), _ptr(st), b, _ptr(scalars56), n))
     return out, st
+
+
+def x448_from_edwards_batch(kind, rows):
+    """The rest of the reference's X448 surface over host arrays, 56 bytes out per row.  kind: "point" (256-byte points ->
+    point_mul_by_ratio_and_encode_like_x448), "public" (57-byte Ed448 public keys -> convert_public_key_to_x448),
+    "private" (57-byte Ed448 private keys -> convert_private_key_to_x448), "scalar" (private keys -> derive_secret_scalar)."""
+    width, fn = {"point": (256, lib().goldilocks_448_point_mul_by_ratio_and_encode_like_x448_batch),
+                 "public": (57, lib().goldilocks_ed448_convert_public_key_to_x448_batch),
+                 "private": (57, lib().goldilocks_ed448_convert_private_key_to_x448_batch),
+                 "scalar": (57, lib().goldilocks_ed448_derive_secret_scalar_batch)}[kind]
+    rows = _u8(rows, width)
+    out = np.empty((len(rows), 56), dtype=np.uint8)
+    _check(fn(_ptr(out), _ptr(rows), len(rows)))
+    return out
 
 
 # ----------------------------------------------------------------------------- single ops (drop-in names)

@@ -56,16 +56,18 @@ struct sacc_t {
     GD_MFN sacc_t() : x(0) {}
     GD_MFN explicit sacc_t(int64_t v) : x(v) {}
     // v_mad_i64_i32 acc, a, b, acc; the empty asm pins the accumulation order (gf28.hpp acc_t::mac)
+    // (every sum is taken modulo 2^64: the three high-half columns that are read as unsigned numbers offset by 2^62 go
+    // past INT64_MAX on purpose, which a signed `+=` would make undefined)
     GD_MFN void mac(int32_t a, int32_t b) {
-        x += (int64_t)a * b;
+        x = (int64_t)((uint64_t)x + (uint64_t)((int64_t)a * b));
 #if defined(__HIP_DEVICE_COMPILE__)
         asm("" : "+v"(x));
 #endif
     }
-    GD_MFN void add(const sacc_t &o) { x += o.x; }
+    GD_MFN void add(const sacc_t &o) { x = (int64_t)((uint64_t)x + (uint64_t)o.x); }
     GD_MFN void add_doubled(const sacc_t &o) { x = (int64_t)(((uint64_t)o.x << 1) + (uint64_t)x); }   // one v_lshl_add_u64
-    GD_MFN void add32(int32_t o) { x += o; }
-    GD_MFN void sub(const sacc_t &o) { x -= o.x; }
+    GD_MFN void add32(int32_t o) { x = (int64_t)((uint64_t)x + (uint64_t)(int64_t)o); }
+    GD_MFN void sub(const sacc_t &o) { x = (int64_t)((uint64_t)x - (uint64_t)o.x); }
     // The mask's result is hidden from the compiler's known-bits analysis: a multiplicand it can prove non-negative
     // is zero-extended, and zext * sext is not a v_mad_i64_i32 but an expansion into two multiply-adds and two moves
     // (tools/fieldbench dbl_signed, round 2: 231 v_mov_b32 per doubling).

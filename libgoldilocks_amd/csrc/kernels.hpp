@@ -522,7 +522,7 @@ GD_KERNEL k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64
 // one operation per WAVE (wave_coop.hpp): the small-batch / single-call path
 extern "C" __global__ void k_point_scalarmul_wave(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
                                                   uint32_t n);
-extern "C" __global__ void k_double_scalarmul_wave(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+extern "C" __global__ void k_double_scalarmul_wave(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
                                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                                    const uint4 *__restrict__ bwt);
 extern "C" __global__ void k_x448_wave(uint8_t *__restrict__ shared, int32_t *__restrict__ status, const uint8_t *__restrict__ base,
@@ -559,7 +559,7 @@ GD_KERNEL k_precomputed_scalarmul(uint64_t *__restrict__ out, const uint4 *__res
                                   const uint64_t *__restrict__ scalar, uint32_t n);
 GD_KERNEL k_base_scalarmul(uint64_t *__restrict__ out, const uint4 *__restrict__ bwt,
                            const uint64_t *__restrict__ scalar, uint32_t n);
-GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
                              const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                              uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt);
 GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
@@ -660,7 +660,7 @@ GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__
 GD_KERNEL k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
                                 const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
                                 int allow_identity, int short_circuit, const uint64_t *__restrict__ point_base_abi);
-GD_KERNEL k_point_dual_scalarmul(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
+GD_KERNEL k_point_dual_scalarmul(uint64_t *out1, uint64_t *out2, const uint64_t *base,
                                  const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                  uint4 *__restrict__ workspace);
 GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *out2, const uint64_t *base,
@@ -671,6 +671,9 @@ GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, con
                  const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt,
                  uint4 *__restrict__ workspace);
 GD_KERNEL k_point_encode(uint8_t *__restrict__ ser, const uint64_t *__restrict__ pts, uint32_t n, int eddsa);
+GD_KERNEL k_ed448_expand_secret(uint8_t *__restrict__ out, const uint8_t *__restrict__ sk, uint32_t n, int as_scalar);
+GD_KERNEL k_x448_from_edwards(uint8_t *__restrict__ out, const uint8_t *__restrict__ ed, const uint64_t *__restrict__ pts,
+                              uint32_t n);
 GD_KERNEL k_point_decode(uint64_t *__restrict__ pts, int32_t *__restrict__ status,
                          const uint8_t *__restrict__ ser, uint32_t n, int eddsa, int allow_identity);
 GD_KERNEL k_point_op(uint64_t *out, const uint64_t *a, const uint64_t *__restrict__ b,

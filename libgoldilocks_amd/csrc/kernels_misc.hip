@@ -1,6 +1,7 @@
 // kernels_misc.hip -- kernel definitions (see kernels.hpp for the memory plan and policies).
 #include "kernels.hpp"
 #include "gf28s.hpp"
+#include "inv_wave.hpp"
 
 namespace gd {
 
@@ -21,6 +22,67 @@ GD_KERNEL k_point_encode(uint8_t *__restrict__ ser, const uint64_t *__restrict__
         } else {
             pt_encode_words(w, p);
             uint32_t *dst = reinterpret_cast<uint32_t *>(ser + 56 * (size_t)i);  // 56*i is 8-byte aligned
+#pragma unroll
+            for (int k = 0; k < 14; k++) dst[k] = w[k];
+        }
+    }
+}
+
+// The rest of the X448 surface ("next" row f3): Montgomery u-coordinates out of Edwards data, 56 bytes each.
+//   pts == nullptr: u = y^2 (1 - d y^2) / (1 - y^2) of an Ed448 public key (its 57th byte is not read, a y >= p is
+//                   taken as it stands: goldilocks_ed448_convert_public_key_to_x448, src/goldilocks.c:1079-1102)
+//   pts != nullptr: (y / x)^2 of a point (goldilocks_448_point_mul_by_ratio_and_encode_like_x448, src/goldilocks.c:1104-1115)
+// with 1 / 0 = 0 as gf_invert has it (src/goldilocks.c:69-80).  One inversion per WAVE (inv_wave.hpp): wave-uniform rounds.
+GD_KERNEL k_x448_from_edwards(uint8_t *__restrict__ out, const uint8_t *__restrict__ ed, const uint64_t *__restrict__ pts,
+                              uint32_t n) {
+    __shared__ uint32_t s_inv[(BLOCK / 64) * INV_WAVE_LDS_WORDS];
+    uint32_t *const region = s_inv + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS;
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i0 = blockIdx.x * BLOCK + threadIdx.x; i0 - (threadIdx.x & 63u) < n; i0 += stride) {
+        const bool live = i0 < n;
+        const uint32_t i = live ? i0 : n - 1;
+        fe num, den;
+        if (pts) {
+            const pt p = pt_load_abi(pts + 32 * (size_t)i);
+            num = p.y;
+            den = p.x;
+        } else {
+            uint32_t w[15];
+            load_bytes_as_words(w, ed + 57 * (size_t)i, 56, 14);
+            const fe y2 = fe_sqr(fe_unpack_words(w));
+            den = fe_weak(fe_sub<2>(fe_one(), y2));                                       // 1 - y^2
+            num = fe_mul(y2, fe_weak(fe_add(fe_one(), fe_mulw(y2, NEG_EDWARDS_D))));      // y^2 (1 - d y^2)
+        }
+        const fe q = fe_mul(num, wave_shared_invert(den, region));
+        uint32_t w[14];
+        fe_serialize_words(w, pts ? fe_sqr(q) : q);
+        if (live) store_bytes_from_words(out + 56 * (size_t)i, w, 56);
+    }
+}
+
+// What SHAKE256(sk) gives an Ed448 private key's owner besides the public key: 56 bytes each.
+//   as_scalar == 0: the X448 private key, SHAKE256(sk)[0:56] (goldilocks_ed448_convert_private_key_to_x448,
+//                   src/eddsa.c:83-95)
+//   as_scalar != 0: the secret scalar as a scalar_s -- clamp(SHAKE256(sk)[0:57]) mod q, halved twice for the encode ratio
+//                   (goldilocks_ed448_derive_secret_scalar, src/eddsa.c:97-128)
+// Secret data: nothing is staged in LDS (the word-granular absorb keeps the sponge in registers).
+GD_KERNEL k_ed448_expand_secret(uint8_t *__restrict__ out, const uint8_t *__restrict__ sk, uint32_t n, int as_scalar) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        const uint8_t *sk57 = sk + 57 * (size_t)i;
+        Ed448Msg m;
+        m.a = sk57; m.alen = 57; m.b = sk57; m.blen = 0; m.msg = sk57; m.msglen = 0;
+        m.ctx = sk57; m.ctxlen = 0; m.ph = 0; m.dom = false;
+        uint32_t w[29];
+        int unused = 0;
+        shake256_114(w, m, 57, unused);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out + 56 * (size_t)i);   // 56 i is 8-byte aligned
+        if (as_scalar) {
+            ed448_clamp_words(w);
+            const sc s = sc_halve(sc_halve(sc_decode_long_words<57>(w)));
+#pragma unroll
+            for (int k = 0; k < 14; k++) dst[k] = s.w[k];
+        } else {
 #pragma unroll
             for (int k = 0; k < 14; k++) dst[k] = w[k];
         }

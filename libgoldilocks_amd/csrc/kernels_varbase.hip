@@ -17,7 +17,7 @@ GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__
                                  point_base_abi);
 }
 
-GD_KERNEL k_point_dual_scalarmul(uint64_t *out1, uint64_t *__restrict__ out2, const uint64_t *base,
+GD_KERNEL k_point_dual_scalarmul(uint64_t *out1, uint64_t *out2, const uint64_t *base,
                                  const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                  uint4 *__restrict__ workspace) {
     point_dual_scalarmul_body(out1, out2, base, s1, s2, n, workspace);

@@ -85,7 +85,7 @@ GD_KERNEL k_verify_key_mode(uint32_t *__restrict__ ctrl, uint32_t n, uint32_t po
     ctrl[2] = combed;
     // teeth per comb: 9 (scalarmul.hpp comb_xwide, 5 combs) for keys that sign a thousand signatures each -- two
     // thousand when the keys are more than 1 024: then their 1 280 entries each are a matter of throughput, not of one
-    // lane's latency (tests/wide_comb_probe.py) --, 8 (comb_wide) for hundreds, else 7 (comb_big)
+    // lane's latency (tools/probes/wide_comb_probe.py) --, 8 (comb_wide) for hundreds, else 7 (comb_big)
     const uint64_t xwide_from = (uint64_t)xwide_min_per_key * (distinct > 1024u ? 2u : 1u);
     ctrl[3] = !combed ? 0u
               : xwide_min_per_key && (uint64_t)distinct * xwide_from <= n ? (uint32_t)comb_xwide::TEETH

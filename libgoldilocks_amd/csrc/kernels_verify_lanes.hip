@@ -12,7 +12,7 @@
 namespace gd {
 
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i]; b1 == nullptr: b1 is the base point (its 16-bit window table)
-GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *__restrict__ b1, const uint64_t *__restrict__ s1,
+GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
                              const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                              uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt) {
     double_scalarmul_body(out, b1, s1, b2, s2, n, workspace, bwt);

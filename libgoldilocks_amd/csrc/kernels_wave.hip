@@ -172,7 +172,7 @@ extern "C" __global__ void __launch_bounds__(BLOCK) k_point_dual_scalarmul_wave(
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i], one operation per wave; b1 == nullptr: b1 is the base point through
 // its window table (goldilocks_448_base_double_scalarmul_non_secret: public scalars by contract).
 // (ref: goldilocks_448_point_double_scalarmul, src/goldilocks.c:467-541, :1260-1330).  out may alias b2.
-extern "C" __global__ void __launch_bounds__(BLOCK) k_double_scalarmul_wave(uint64_t *out, const uint64_t *__restrict__ b1,
+extern "C" __global__ void __launch_bounds__(BLOCK) k_double_scalarmul_wave(uint64_t *out, const uint64_t *b1,
                                                                             const uint64_t *__restrict__ s1, const uint64_t *b2,
                                                                             const uint64_t *__restrict__ s2, uint32_t n,
                                                                             const uint4 *__restrict__ bwt) {

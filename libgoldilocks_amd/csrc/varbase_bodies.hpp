@@ -85,7 +85,7 @@ __device__ __forceinline__ void direct_scalarmul_body(uint8_t *__restrict__ scal
 
 // "next" row f4: (s1*B, s2*B) for one base   (ref: goldilocks_448_point_dual_scalarmul)
 // out1 may alias base.
-__device__ __forceinline__ void point_dual_scalarmul_body(uint64_t *out1, uint64_t *__restrict__ out2,
+__device__ __forceinline__ void point_dual_scalarmul_body(uint64_t *out1, uint64_t *out2,
                                                           const uint64_t *base, const uint64_t *__restrict__ s1,
                                                           const uint64_t *__restrict__ s2, uint32_t n,
                                                           uint4 *__restrict__ workspace) {
@@ -109,7 +109,7 @@ __device__ __forceinline__ void point_dual_scalarmul_body(uint64_t *out1, uint64
 // contract (src/goldilocks.c:1260-1330): s2*b2 by the one-table ladder, then s1*B as 28 additions from the base
 // point's 16-bit window table onto the same accumulator (no doublings for the base point's half).
 // out may alias b2.
-__device__ __forceinline__ void double_scalarmul_body(uint64_t *out, const uint64_t *__restrict__ b1,
+__device__ __forceinline__ void double_scalarmul_body(uint64_t *out, const uint64_t *b1,
                                                       const uint64_t *__restrict__ s1, const uint64_t *b2,
                                                       const uint64_t *__restrict__ s2, uint32_t n,
                                                       uint4 *__restrict__ workspace,

@@ -1034,6 +1034,26 @@ void orc_x448_derive_public_key(uint8_t out[56], const uint8_t scalar[56]) { /* 
     orc_gf_serialize(out, &sq);
 }
 
+void orc_point_encode_like_x448(uint8_t out[56], const orc_point *p) { /* goldilocks.c:1104-1115 */
+    orc_gf inv, r, sq;
+    fe_invert(&inv, &p->x);                  /* 1/x, 1/0 = 0 */
+    fe_mul(&r, &inv, &p->y);                 /* y/x */
+    fe_sqr(&sq, &r);                         /* (y/x)^2 */
+    orc_gf_serialize(out, &sq);
+}
+void orc_ed448_convert_public_key_to_x448(uint8_t x[56], const uint8_t ed[57]) { /* goldilocks.c:1079-1102 */
+    orc_gf y, n, d;
+    (void)orc_gf_deserialize(&y, ed, 0);     /* (uint8_t)(0xFE << 7) == 0: no bit of byte 55 is masked; failure ignored */
+    fe_sqr(&n, &y);                          /* y^2 */
+    orc_gf_sub(&d, &FE_ONE, &n);             /* 1 - y^2 */
+    fe_invert(&d, &d);                       /* 1/(1 - y^2) */
+    fe_mul_ip(&y, &n, &d);                   /* y^2 / (1 - y^2) */
+    fe_mulw_signed(&d, &n, EDWARDS_D);       /* d y^2 */
+    orc_gf_sub(&d, &FE_ONE, &d);             /* 1 - d y^2 */
+    fe_mul_ip(&n, &y, &d);
+    orc_gf_serialize(x, &n);
+}
+
 /* ---- constants regenerated by this file's own generator (gen_tables.c:21-23, 59-86) ---- */
 
 static pthread_once_t g_tables_once = PTHREAD_ONCE_INIT;
@@ -1140,6 +1160,10 @@ static void ed_secret_scalar(orc_scalar *s, const uint8_t sk[57]) { /* eddsa.c:9
     ed_clamp(ser);
     orc_scalar_decode_long(s, ser, 57);
     for (unsigned c = 1; c < 4; c <<= 1) orc_scalar_halve(s, s);
+}
+void orc_ed448_derive_secret_scalar(orc_scalar *s, const uint8_t sk[57]) { ed_secret_scalar(s, sk); } /* eddsa.c:97-128 */
+void orc_ed448_convert_private_key_to_x448(uint8_t x[56], const uint8_t ed[57]) { /* eddsa.c:83-95 */
+    orc_shake256(x, 56, ed, 57);
 }
 void orc_ed448_derive_public_key(uint8_t pk[57], const uint8_t sk[57]) { /* eddsa.c:131-147 */
     orc_scalar s;

@@ -97,6 +97,10 @@ ORC_API void orc_point_from_hash_uniform(orc_point *p, const uint8_t ser[112]);
 /* ---- X448 (RFC 7748) ---- */
 ORC_API int  orc_x448(uint8_t out[56], const uint8_t base[56], const uint8_t scalar[56]);
 ORC_API void orc_x448_derive_public_key(uint8_t out[56], const uint8_t scalar[56]);
+ORC_API void orc_point_encode_like_x448(uint8_t out[56], const orc_point *p);
+ORC_API void orc_ed448_convert_public_key_to_x448(uint8_t x[56], const uint8_t ed[57]);
+ORC_API void orc_ed448_derive_secret_scalar(orc_scalar *s, const uint8_t sk[57]);
+ORC_API void orc_ed448_convert_private_key_to_x448(uint8_t x[56], const uint8_t ed[57]);
 
 /* ---- SHAKE256 / EdDSA ---- */
 ORC_API void orc_shake256(uint8_t *out, size_t outlen, const uint8_t *in, size_t inlen);

@@ -125,6 +125,10 @@ def oracle():
         "orc_point_from_hash_uniform": (None, [pp, vp]),
         "orc_x448": (C.c_int, [vp, vp, vp]),
         "orc_x448_derive_public_key": (None, [vp, vp]),
+        "orc_point_encode_like_x448": (None, [vp, vp]),
+        "orc_ed448_convert_public_key_to_x448": (None, [vp, vp]),
+        "orc_ed448_derive_secret_scalar": (None, [vp, vp]),
+        "orc_ed448_convert_private_key_to_x448": (None, [vp, vp]),
         "orc_ed448_derive_public_key": (None, [vp, vp]),
         "orc_ed448_sign": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8]),
         "orc_ed448_verify": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8]),
@@ -192,6 +196,10 @@ def ref():
         "goldilocks_sha3_hash": (C.c_int, [vp, C.c_size_t, vp, C.c_size_t, vp]),
         "goldilocks_x448": (C.c_int, [vp, vp, vp]),
         "goldilocks_x448_derive_public_key": (None, [vp, vp]),
+        "goldilocks_448_point_mul_by_ratio_and_encode_like_x448": (None, [vp, vp]),
+        "goldilocks_ed448_convert_public_key_to_x448": (None, [vp, vp]),
+        "goldilocks_ed448_derive_secret_scalar": (None, [vp, vp]),
+        "goldilocks_ed448_convert_private_key_to_x448": (None, [vp, vp]),
     }
     for name, (res, args) in proto.items():
         f = getattr(L, name)

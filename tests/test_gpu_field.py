@@ -190,8 +190,10 @@ def test_signed_paired_layer_at_its_limits_on_the_device(ga):
         out, _ = run(ga, OP["ssqr"] | ka << 8 | sum2 << 16, a)
         for i in range(n):
             assert val(out[i]) == (val(a[i]) * sgn(ka)) ** 2 % P, ("ssqr", ka, sum2, i)
-    with pytest.raises(ga.GoldilocksAmdError):
-        run(ga, OP["smul"] | 4 << 8 | 1 << 16, a, b)
+    # beyond the contract (mag(b) <= 2, mag(a) * mag(b) <= 3) the hook refuses instead of returning a wrapped product
+    for ka, kb in ((4, 1), (1, 3), (0x81, 0x83), (2, 2), (3, 2), (3, 3)):
+        with pytest.raises(ga.GoldilocksAmdError):
+            run(ga, OP["smul"] | ka << 8 | kb << 16, a, b)
 
 
 def test_half_size_pair_of_verification(ga):

@@ -617,6 +617,45 @@ def test_x448_vs_oracle_and_rfc7748(ga, O):
     assert (s1 == s2).all()
 
 
+def test_x448_conversions_vs_oracle(ga, O):
+    """The rest of the X448 surface (src/goldilocks.c:1079-1115, src/eddsa.c:83-128): Ed448 public / private keys to X448,
+    the secret scalar, points encoded like X448 -- against the oracle (pinned to the reference by
+    test_oracle_vs_ref.py::test_x448_conversions_differential), over a ragged batch and through the single-call names;
+    and the reference's own check (test_goldilocks.cxx:625-655): converting a public key == deriving from the converted
+    private key."""
+    from _libs import Point, Scalar
+    n = 700                                    # ragged: 10 full waves + 60 lanes
+    sk = np.frombuffer(_gen.stream(b"t-conv-sk", 57 * n), np.uint8).reshape(n, 57).copy()
+    pk = ga.ed448_derive_public_key_batch(sk)
+    ed = pk.copy()
+    for row, val in zip(range(6), (0, 1, P - 1, P, P + 1, 2**448 - 1)):     # 1/(1 - y^2) = 1/0; y >= p taken as it stands
+        ed[row, :56] = np.frombuffer(val.to_bytes(56, "little"), np.uint8)
+    xpub, xpriv, secret = (ga.x448_from_edwards_batch(k, a) for k, a in (("public", ed), ("private", sk), ("scalar", sk)))
+    pts = ga.point_from_hash_batch(np.frombuffer(_gen.stream(b"t-conv-pt", 112 * n), np.uint8).reshape(n, 112), uniform=True).view(np.uint8).reshape(n, 256)
+    pts[0] = np.frombuffer(bytes(Point.in_dll(ga.lib(), "goldilocks_448_point_identity")), np.uint8)   # x = 0
+    like = ga.x448_from_edwards_batch("point", pts)
+    w, s = (C.c_uint8 * 56)(), Scalar()
+    for i in range(n):
+        O.orc_ed448_convert_public_key_to_x448(w, ed[i].ctypes.data)
+        assert bytes(w) == xpub[i].tobytes(), i
+        O.orc_ed448_convert_private_key_to_x448(w, sk[i].ctypes.data)
+        assert bytes(w) == xpriv[i].tobytes(), i
+        O.orc_ed448_derive_secret_scalar(C.byref(s), sk[i].ctypes.data)
+        assert bytes(s) == secret[i].tobytes(), i
+        O.orc_point_encode_like_x448(w, pts[i].ctypes.data)
+        assert bytes(w) == like[i].tobytes(), i
+    derived, _ = ga.x448_batch(xpriv[6:])
+    assert (derived == xpub[6:]).all()
+    L = ga.lib()
+    one = np.empty(56, np.uint8)
+    for name, src, want in (("goldilocks_ed448_convert_public_key_to_x448", ed[9], xpub[9]),
+                            ("goldilocks_ed448_convert_private_key_to_x448", sk[9], xpriv[9]),
+                            ("goldilocks_ed448_derive_secret_scalar", sk[9], secret[9]),
+                            ("goldilocks_448_point_mul_by_ratio_and_encode_like_x448", pts[9], like[9])):
+        getattr(L, name)(one.ctypes.data, src.ctypes.data)
+        assert (one == want).all(), name
+
+
 def test_elligator_and_dual_scalarmul(ga, O):
     from _libs import Point
     kats = json.load(open(os.path.join(GOLD, "kats.json")))["elligator_nonuniform"]

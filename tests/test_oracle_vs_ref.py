@@ -163,6 +163,45 @@ def test_x448_differential(O):
         assert bytes(o1) == bytes(o2)
 
 
+def test_x448_conversions_differential(O):
+    """goldilocks_ed448_convert_public_key_to_x448 / _private_key_to_x448 / _derive_secret_scalar and
+    goldilocks_448_point_mul_by_ratio_and_encode_like_x448 (src/goldilocks.c:1079-1115, src/eddsa.c:83-128): the oracle's
+    restatements against the reference compiled here; and the reference's own test of them (test_goldilocks.cxx:625-655:
+    the public key converted == the X448 public key of the private key converted)."""
+    from _libs import P
+    R = ref()
+    rnd = random.Random(14)
+    special = [x.to_bytes(56, "little") + b"\x80" for x in (0, 1, P - 1, P, P + 1, 2**448 - 1)]   # y = +-1: 1/(1 - y^2) = 1/0; y >= p
+    for it in range(100):
+        sk = bytes(rnd.getrandbits(8) for _ in range(57))
+        pk = (C.c_uint8 * 57)()
+        R.goldilocks_ed448_derive_public_key(pk, buf(sk))
+        ed = special[it] if it < len(special) else bytes(pk)
+        o1, o2 = (C.c_uint8 * 56)(), (C.c_uint8 * 56)()
+        R.goldilocks_ed448_convert_public_key_to_x448(o1, buf(ed)); O.orc_ed448_convert_public_key_to_x448(o2, buf(ed))
+        assert bytes(o1) == bytes(o2), it
+        x1, x2 = (C.c_uint8 * 56)(), (C.c_uint8 * 56)()
+        R.goldilocks_ed448_convert_private_key_to_x448(x1, buf(sk)); O.orc_ed448_convert_private_key_to_x448(x2, buf(sk))
+        assert bytes(x1) == bytes(x2)
+        if it >= len(special):
+            R.goldilocks_x448_derive_public_key(x2, x1)
+            assert bytes(x2) == bytes(o1)
+        s1, s2 = Scalar(), Scalar()
+        R.goldilocks_ed448_derive_secret_scalar(C.byref(s1), buf(sk)); O.orc_ed448_derive_secret_scalar(C.byref(s2), buf(sk))
+        assert bytes(s1) == bytes(s2)
+        p = Point()
+        if it == 0:
+            C.memmove(C.byref(p), R_identity(R), 256)          # x = 0: 1/x = 0
+        else:
+            R.goldilocks_448_point_from_hash_uniform(C.byref(p), buf(bytes(rnd.getrandbits(8) for _ in range(112))))
+        R.goldilocks_448_point_mul_by_ratio_and_encode_like_x448(o1, C.byref(p)); O.orc_point_encode_like_x448(o2, C.byref(p))
+        assert bytes(o1) == bytes(o2), it
+
+
+def R_identity(R):
+    return C.addressof(Point.in_dll(R, "goldilocks_448_point_identity"))
+
+
 def test_elligator_differential(O):
     R = ref()
     rnd = random.Random(13)

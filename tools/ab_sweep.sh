@@ -7,7 +7,7 @@ mkdir -p "$(dirname "$OUT")"
 : > "$OUT"
 for pass in 1 2; do
     for wl in "$@"; do
-        python tests/variant_sweep.py "--workload $wl" >> "$OUT" 2>&1
+        python tools/probes/variant_sweep.py "--workload $wl" >> "$OUT" 2>&1
     done
 done
 cat "$OUT"

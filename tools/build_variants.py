@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build experimental variants of the library into variants/ (git-ignored .so files that travel to the
-GPU box):   python tools/build_variants.py name1:-DX=1,-DY=2 name2:...     (see tests/variant_sweep.py)"""
+GPU box):   python tools/build_variants.py name1:-DX=1,-DY=2 name2:...     (see tools/probes/variant_sweep.py)"""
 import os
 import sys
 

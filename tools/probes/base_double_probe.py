@@ -1,6 +1,6 @@
-"""Timing probe: goldilocks_448_base_double_scalarmul_non_secret at 2^20.   python tests/base_double_probe.py"""
+"""Timing probe: goldilocks_448_base_double_scalarmul_non_secret at 2^20.   python tools/probes/base_double_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libgoldilocks_amd as ga, _gen

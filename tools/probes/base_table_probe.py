@@ -1,7 +1,7 @@
 """Manual probe: the base point's window table at every width -- time to build it (the first call that needs it), its
-size, and the base point's multiplication through it.   python tests/base_table_probe.py"""
+size, and the base point's multiplication through it.   python tools/probes/base_table_probe.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np

@@ -1,7 +1,7 @@
 """Throughput and latency of the three headline kernels against the batch size (device-resident data),
-for profiles/<round>/batch_sweep.txt.  python tests/batch_sweep.py"""
+for profiles/<round>/batch_sweep.txt.  python tools/probes/batch_sweep.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libgoldilocks_amd as ga, _gen

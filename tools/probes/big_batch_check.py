@@ -1,4 +1,4 @@
-"""Manual check (not collected by pytest): 2^23+12345 operations through the device API, and 3 000 000\nthrough the sharded, pipelined host API, against the oracle on a sample.  python tests/big_batch_check.py"""
+"""Manual check (not collected by pytest): 2^23+12345 operations through the device API, and 3 000 000\nthrough the sharded, pipelined host API, against the oracle on a sample.  python tools/probes/big_batch_check.py"""
 import sys, os
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, torch, libgoldilocks_amd as ga, _gen

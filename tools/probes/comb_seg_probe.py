@@ -1,7 +1,7 @@
 """Timing probe: 2^20 signatures of 2^10 ... 2^16 keys with library defaults (combs): what the entries kernel's segment
-size costs where the keys are few (latency) and many (throughput).  python tests/comb_seg_probe.py"""
+size costs where the keys are few (latency) and many (throughput).  python tools/probes/comb_seg_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make, timeit

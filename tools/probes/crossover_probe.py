@@ -1,7 +1,7 @@
 """Timing probe: one-operation-per-wave against lane kernels around the dispatch thresholds (device-resident).
-python tests/crossover_probe.py"""
+python tools/probes/crossover_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libgoldilocks_amd as ga, _gen

@@ -1,7 +1,7 @@
 """Timing probe: the base-point operations with index-independent table access (the library default) at 2^20:
-base-point multiplication, key derivation, signing, X448 key generation.   python tests/ct_base_probe.py"""
+base-point multiplication, key derivation, signing, X448 key generation.   python tools/probes/ct_base_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libgoldilocks_amd as ga, _gen

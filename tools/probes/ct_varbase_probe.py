@@ -1,7 +1,7 @@
 """Timing probe: the variable-base entry points at 2^20 in both table-access modes (per-call flags), for
-profiles/<round>/.  python tests/ct_varbase_probe.py"""
+profiles/<round>/.  python tools/probes/ct_varbase_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libgoldilocks_amd as ga, _gen

@@ -1,7 +1,7 @@
 """Diagnostic: goldilocks_448_direct_scalarmul batch outputs of the loaded library (GOLDILOCKS_AMD_LIB) against the
-oracle, every lane, both identity rules; prints the lanes that differ.  python tests/direct_diff_probe.py"""
+oracle, every lane, both identity rules; prints the lanes that differ.  python tools/probes/direct_diff_probe.py"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import libgoldilocks_amd as ga, _gen

@@ -1,6 +1,6 @@
-"""Timing probe: goldilocks_amd_direct_scalarmul_dev for small batches (one operation per wave).   python tests/direct_probe.py"""
+"""Timing probe: goldilocks_amd_direct_scalarmul_dev for small batches (one operation per wave).   python tools/probes/direct_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libgoldilocks_amd as ga, _gen

@@ -1,7 +1,7 @@
 """Probe (with a library built -DGD_TRACE_E2E=1, GOLDILOCKS_AMD_LIB=...): the host-array verification call by call, the
-library printing its own laps.  python tests/e2e_trace_probe.py"""
+library printing its own laps.  python tools/probes/e2e_trace_probe.py"""
 import os, sys, time, ctypes as C
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make

@@ -1,5 +1,5 @@
 """Manual probe: goldilocks_448_point_scalarmul_batch from host arrays, 2^20 operations, seven calls (profiles/r04/experiments.md N).
-   python tests/e2e_varbase_probe.py"""
+   python tools/probes/e2e_varbase_probe.py"""
 import os, sys, time, ctypes as C
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.getcwd())
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

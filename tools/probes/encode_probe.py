@@ -1,6 +1,6 @@
-"""Timing probe: the encode / decode kernels at 2^20 points (device-resident).   python tests/encode_probe.py"""
+"""Timing probe: the encode / decode kernels at 2^20 points (device-resident).   python tools/probes/encode_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libgoldilocks_amd as ga, _gen

@@ -1,6 +1,6 @@
 """First-contact probe for the GPU box: time the three batch kernels device-resident."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # a test-side script: it checks against the oracle
 import numpy as np, torch
 import libgoldilocks_amd as ga, _gen

@@ -1,6 +1,6 @@
 """Timing probe: host <-> device copies of 221 MiB (the input of 2^20 verifications) from pageable and pinned host memory,
 and one core's memcpy: what bounds the host-array entry points is not the transfers (52 - 57 GB/s either way).
-python tests/h2d_probe.py"""
+python tools/probes/h2d_probe.py"""
 import torch, numpy as np, time
 n = 221 * 1024 * 1024
 a = np.random.default_rng(0).integers(0, 255, n, dtype=np.uint8)

@@ -1,8 +1,8 @@
 """Manual probe: does a verification step that follows an idle device run slower than one that follows another step?
 (The host-array pipeline's first passes run their rounds a fifth slower than the resident launch's: profiles/r04/experiments.md
-G reads that as clocks that came down while the keys were uploaded.)   python tests/idle_gap_probe.py"""
+G reads that as clocks that came down while the keys were uploaded.)   python tools/probes/idle_gap_probe.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make

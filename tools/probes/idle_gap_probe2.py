@@ -1,8 +1,8 @@
 """Manual probe, second part: what keeps the clocks up across a gap?  The gap before a verification step is filled with
 (a) nothing, (b) a stream of tiny kernels (a 4-KiB fill, back to back), (c) one block per CU of dependent arithmetic
-(a small matmul chain).   python tests/idle_gap_probe2.py"""
+(a small matmul chain).   python tools/probes/idle_gap_probe2.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make

@@ -1,6 +1,6 @@
-"""Manual check: how long does the first call (context + table build) take?  python tests/init_time.py"""
+"""Manual check: how long does the first call (context + table build) take?  python tools/probes/init_time.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch
 torch.cuda.init(); torch.zeros(1, device="cuda"); torch.cuda.synchronize()

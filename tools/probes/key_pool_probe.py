@@ -1,7 +1,7 @@
 """Timing probe: verification with every lane for itself, with the pool of per-key window tables, and with per-key combs,
-batch sizes 2^16 .. 2^20, 16 keys .. one key per signature (sampled with replacement).  python tests/key_pool_probe.py"""
+batch sizes 2^16 .. 2^20, 16 keys .. one key per signature (sampled with replacement).  python tools/probes/key_pool_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make, timeit

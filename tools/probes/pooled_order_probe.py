@@ -1,7 +1,7 @@
 """Timing probe: pooled window tables (combs off) with the batch's signatures in random key order and sorted by key.
-python tests/pooled_order_probe.py"""
+python tools/probes/pooled_order_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import timeit

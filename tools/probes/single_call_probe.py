@@ -1,6 +1,6 @@
-"""Wall clock of the remaining single-operation entry points (host call, copies included).   python tests/single_call_probe.py"""
+"""Wall clock of the remaining single-operation entry points (host call, copies included).   python tools/probes/single_call_probe.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import libgoldilocks_amd as ga, _gen

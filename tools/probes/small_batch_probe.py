@@ -1,7 +1,7 @@
 """Timing probe: verification of 2^13 .. 2^15 signatures of few keys with every lane for itself and with per-key combs
-(the pool's minimum batch lowered for the occasion).  python tests/small_batch_probe.py"""
+(the pool's minimum batch lowered for the occasion).  python tools/probes/small_batch_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make, timeit

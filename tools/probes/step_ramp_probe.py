@@ -1,7 +1,7 @@
 """Manual probe: the first verification steps of a process, one by one (the base table is built inside the first; how
-long until the step time settles?).   python tests/step_ramp_probe.py"""
+long until the step time settles?).   python tools/probes/step_ramp_probe.py"""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make

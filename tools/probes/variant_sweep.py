@@ -1,5 +1,5 @@
 """Time bench workloads over experimental library builds (variants/*.so, tools/build_variants.py) on the GPU box:
-    python tests/variant_sweep.py "<bench args>" [variant names...]      (no names: every variant + the product)
+    python tools/probes/variant_sweep.py "<bench args>" [variant names...]      (no names: every variant + the product)
 One bench.py subprocess per (variant); prints value and kernel_ms_avg."""
 import glob
 import json
@@ -7,7 +7,7 @@ import os
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 args = sys.argv[1].split()
 names = sys.argv[2:]
 libs = {"product": os.path.join(ROOT, "libgoldilocks_amd", "libgoldilocks_amd.so")}

@@ -1,6 +1,6 @@
 """Quick check + timing of the one-operation-per-wave kernel (tests/test_gpu_wave.py is the real test)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import libgoldilocks_amd as ga

@@ -1,8 +1,8 @@
 """Timing probe: verification through per-key combs of 7, 8 and 9 teeth (4 x 7 x 16, 4 x 8 x 14, 5 x 9 x 10), 2^18 .. 2^21
 signatures of 2^8 .. 2^13 keys.
-python tests/wide_comb_probe.py"""
+python tools/probes/wide_comb_probe.py"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch, libgoldilocks_amd as ga, _gen
 from key_pool_probe_lib import make, timeit

@@ -63,20 +63,20 @@ pmc SQ2FAST varbase $FAST -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_I
 pmc GRBM varbase -- GRBM_GUI_ACTIVE
 
 for probe in gpu_probe h2d_probe wave_probe key_pool_probe wide_comb_probe small_batch_probe ct_varbase_probe base_double_probe ct_base_probe direct_probe single_call_probe encode_probe crossover_probe; do
-    python3 "$ROOT/tests/$probe.py" > "$DST/$probe.txt" 2>&1
+    python3 "$ROOT/tools/probes/$probe.py" > "$DST/$probe.txt" 2>&1
 done
 # round 4: which kernels of a verification step overlap (S*B beside the combs' build); the host-array verification's laps;
 # the host feed rate of the 8-shard host-array call without a device
 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_verify" -- \
     python3 "$BENCH" --workload verify --steps 4 --warmup 2 $Q > "$OUT/trace_verify.log" 2>&1
 python3 "$ROOT/tools/trace_timeline.py" "$OUT/trace_verify" k_verify_dedupe > "$DST/timeline_verify.txt" 2>&1
-GOLDILOCKS_AMD_TRACE=1 python3 "$ROOT/tests/e2e_trace_probe.py" > "$DST/e2e_laps.txt" 2>&1
+GOLDILOCKS_AMD_TRACE=1 python3 "$ROOT/tools/probes/e2e_trace_probe.py" > "$DST/e2e_laps.txt" 2>&1
 for o in sequential scattered; do for s in none memcpy; do "$ROOT/tools/hostfeed" --log2n 22 --stage $s --order $o; done; done > "$DST/hostfeed.txt" 2>&1
 "$ROOT/tools/fieldbench" > "$DST/fieldbench.txt" 2>&1
 "$ROOT/tools/stepbench" > "$DST/stepbench.txt" 2>&1
 "$ROOT/tools/fp64gate" > "$DST/fp64gate.txt" 2>&1
 "$ROOT/tools/verifyphases" > "$DST/verifyphases.txt" 2>&1
 "$ROOT/tools/keycombphases_t8m0x1" > "$DST/keycombphases.txt" 2>&1   # 8 teeth, XCD-aware positions: the product's geometry for config 4
-python3 "$ROOT/tests/batch_sweep.py" > "$DST/batch_sweep.txt" 2>&1
+python3 "$ROOT/tools/probes/batch_sweep.py" > "$DST/batch_sweep.txt" 2>&1
 python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$DST"
 ls -la "$DST"
