@@ -71,8 +71,8 @@ VALU_MAC_PEAKS = {"used": "best_issue_rate_measured", "best_issue_rate_measured"
 # accumulates per op, counted by the host checker build of the same lane code
 # (tests/test_hostsim.py::test_mac_counts_match_bench keeps these in step with the code).
 WORKLOADS = {
-    # fast (digit-addressed 5-bit window table): 2175 M x 192 + 1785 S x 136 + 17 mulw x 16.
-    # index-independent (the default; csrc/montgomery.hpp): 446 ladder steps of 5M + 4S + mulw, the y-recovery,
+    # macs: the reference's 5-bit window algorithm (2175 M x 192 + 1785 S x 136 + 17 mulw x 16), which the library ran for
+    # public scalars until round 6; macs_index_independent: what it runs in both table-access modes (csrc/montgomery.hpp): 446 ladder steps of 5M + 4S + mulw, the y-recovery,
     # the shared-inversion chain (3 M) and an eighth of an inversion (8 operations per lane at 2^20)
     "varbase": dict(metric="Ed448 variable-base scalarmuls/sec", unit="scalarmuls/s", bytes=568, macs=660_632,
                     macs_index_independent=681_344 + 576 + 63_616 // 8, macs_ladder=681_344, macs_inversion=63_616,
@@ -205,7 +205,7 @@ def make_workload(name, cx, access):
             m = min(n, SAMPLE)
             return dict(kind="varbase", bases=host(bases[:m]).view(np.uint64), scalars=host(scalars[:m]).view(np.uint64),
                         got=ga.point_encode_batch(host(out[:m]).view(np.uint64)))
-        return dict(step=step, kernel="k_point_scalarmul_ct" if ct else "k_point_scalarmul", check=check, sample=sample)
+        return dict(step=step, kernel="k_point_scalarmul_ct", check=check, sample=sample)   # (the ladder in both table-access modes since round 6)
     if name in ("fixed", "base"):
         _, scalars = cx.pairs()
         out = torch.empty((n, 32), dtype=torch.int64, device="cuda")
@@ -254,7 +254,7 @@ def make_workload(name, cx, access):
             ga.dev("point_encode", ref_enc.data_ptr(), ref.data_ptr(), n, None)
             ok = bool((ref_enc == enc_out).all()) and int((st_direct == -1).sum()) == n
             return ok, "every output equals encode(point_scalarmul(decode(input))) computed by the separate kernels", {}
-        return dict(step=step, kernel="k_direct_scalarmul_ct" if ct else "k_direct_scalarmul", check=check)
+        return dict(step=step, kernel="k_direct_scalarmul_ct", check=check)
     import _gen
     if name in ("sign", "x448"):
         nb = 57 if name == "sign" else 56
@@ -653,7 +653,8 @@ def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_t
     spec = dict(WORKLOADS[name])
     if macs:                # (verification: the multiply-accumulates of the comb geometry the batch's keys really got)
         spec["macs"] = macs
-    if table_access == "index-independent" and spec.get("macs_index_independent"):
+    # (one scalar times a variable base runs the table-free ladder in BOTH table-access modes since round 6)
+    if (table_access == "index-independent" or name in ("varbase", "direct")) and spec.get("macs_index_independent"):
         spec["macs"] = spec["macs_index_independent"]
     elif spec.get("macs") and spec.get("base_table_additions") and base_table_bits:
         # the figures are priced for 16-bit digits (28 of them); the device's table may be wider: a mixed addition
@@ -725,7 +726,6 @@ CONFIGS = (("fixed", "fixed", "index-independent", 0),          # config 3: a ca
            ("base", "base", "index-independent", 0),            # ... the built-in base point, library default
            ("verify", "verify", "index-independent", 0),        # config 4 (public data: the mode changes nothing)
            ("verify_distinct_keys", "verify_distinct", "index-independent", 0),   # ... when no key repeats
-           ("varbase_fast", "varbase", "fast", 0),              # the opt-in for public scalars
            ("base_fast", "base", "fast", 0),
            ("verify_table24", "verify", "index-independent", 24))   # config 4 with the opt-in 24-bit table (28.5 GiB)
 

@@ -348,7 +348,11 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  *     condition and no memory address depends on the scalar (tests/test_isa_audit.py).
  *   GOLDILOCKS_AMD_TABLES_FAST (opt-in, for PUBLIC scalars only)
  *     - each lookup reads only the digit's entry (the address depends on the digit): the base point's
- *       window table in global memory (goldilocks_amd_set_base_table_bits), 5-bit windows for a variable base.
+ *       window table in global memory (goldilocks_amd_set_base_table_bits); 5-bit windows per lane for the TWO-scalar
+ *       variable-base entry points (point_double_scalarmul, point_dual_scalarmul: one doubling chain instead of two
+ *       ladders, 44 against 64 ms per 2^20).  goldilocks_448_point_scalarmul and goldilocks_448_direct_scalarmul run the
+ *       table-free ladder in THIS mode too since round 6: it is the faster one (32.8 against 32.4 M/s) and holds no
+ *       544-MiB table workspace.
  *
  * Not affected: verification and base_double_scalarmul_non_secret (public by contract: always the
  * fast tables), goldilocks_x448 with a peer's point (a Montgomery ladder with selects, no table),

@@ -515,8 +515,6 @@ struct LdsMkBitsVerify {
 // Definitions live in kernels_{varbase,verify,fixed,misc}.hip (separate translation units so the
 // build compiles them in parallel); the host runtime (goldilocks_amd.hip) launches them.
 // (no __restrict__ on an output the host runtime aliases with an input: out/base, out/b2, out1/base, out/a)
-GD_KERNEL k_point_scalarmul(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar, uint32_t n,
-                            uint4 *__restrict__ workspace);
 GD_KERNEL k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
                                   uint32_t n, uint4 *__restrict__ workspace);
 // one operation per WAVE (wave_coop.hpp): the small-batch / single-call path
@@ -653,10 +651,6 @@ GD_KERNEL k_ed448_sign_ct(uint8_t *__restrict__ sig, const uint8_t *__restrict__
                           uint32_t n, const uint4 *__restrict__ comb, uint4 *__restrict__ workspace);
 GD_KERNEL k_x448_derive_ct(uint8_t *__restrict__ shared, const uint8_t *__restrict__ scalar, uint32_t n,
                            const uint4 *__restrict__ comb, uint4 *__restrict__ workspace);
-GD_KERNEL k_direct_scalarmul(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
-                             const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
-                             int allow_identity, int short_circuit, uint4 *__restrict__ workspace,
-                             const uint64_t *__restrict__ point_base_abi);
 GD_KERNEL k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
                                 const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
                                 int allow_identity, int short_circuit, const uint64_t *__restrict__ point_base_abi);

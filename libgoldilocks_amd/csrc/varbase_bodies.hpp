@@ -22,66 +22,11 @@ __device__ __forceinline__ LaneTable lane_table_at(uint4 *ws, int which, int nta
 
 // ================================================================== digit-addressed tables (public scalars)
 
-// config 2: scaled[i] = scalar[i] * base[i]   (ref: goldilocks_448_point_scalarmul).
-// out may alias base (the host-array path multiplies in place): no __restrict__ on that pair.
-__device__ __forceinline__ void point_scalarmul_body(uint64_t *out, const uint64_t *base,
-                                                     const uint64_t *__restrict__ scalar, uint32_t n,
-                                                     uint4 *__restrict__ workspace) {
-    __shared__ uint32_t s_bits[15 * BLOCK];
-    // 16 KiB per wave: the table build's step (LdsStepTable, piece rows of 64 lanes) and, between operations, the
-    // wave's I/O staging (its first 8 KiB) -- never in use together
-    __shared__ uint4 s_wave[(BLOCK / 64) * 16 * 64];
-    static_assert(WAVE_STAGE_U4 <= 16 * 64, "the I/O staging fits the wave's step region");
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    const uint32_t l = threadIdx.x & 63u;
-    uint4 *stage = s_wave + (threadIdx.x >> 6) * 16 * 64;
-    LdsStepTable<64> tab{lane_table_at(workspace, 0, 1).p, stage + l};
-    // wave-uniform loop: the 64 lanes of a wave own 64 consecutive operations per round
-    for (uint32_t i0 = lane - l; i0 < n; i0 += stride) {
-        const uint32_t m = n - i0 < 64u ? n - i0 : 64u;
-        pt b = wave_load_points(stage, base, i0, m, l);
-        const sc k = wave_load_scalars(stage, scalar, i0, m, l);
-        pt r = b;
-        if (l < m) {
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(k));
-            build_window_table(tab, b);
-            r = ladder_varbase(bits, tab);
-        }
-        wave_store_points(stage, out, i0, m, l, r);
-    }
-}
-
-// "next" row f2: wire-format scalarmul, 56 bytes in / 56 bytes out   (ref: goldilocks_448_direct_scalarmul)
-__device__ __forceinline__ void direct_scalarmul_body(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
-                                                      const uint8_t *__restrict__ base,
-                                                      const uint64_t *__restrict__ scalar, uint32_t n,
-                                                      int allow_identity, int short_circuit,
-                                                      uint4 *__restrict__ workspace,
-                                                      const uint64_t *__restrict__ point_base_abi) {
-    __shared__ uint32_t s_bits[15 * BLOCK];
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    LaneTable tab = lane_table_at(workspace, 0, 1);
-    for (uint32_t i = lane; i < n; i += stride) {
-        uint32_t w[14];
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(base + 56 * (size_t)i);
-#pragma unroll
-        for (int k = 0; k < 14; k++) w[k] = src[k];
-        pt b;
-        bool ok = pt_decode_words(b, w, allow_identity != 0);
-        status[i] = ok ? -1 : 0;
-        if (!ok && short_circuit) continue;         // the encoding is public: so is this branch
-        if (!ok) b = pt_load_abi(point_base_abi);   // src/goldilocks.c:898: multiply the base point instead
-        LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(scalar + 7 * (size_t)i)));
-        build_window_table(tab, b);
-        pt r = ladder_varbase(bits, tab);
-        pt_encode_words(w, r);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(scaled + 56 * (size_t)i);
-#pragma unroll
-        for (int k = 0; k < 14; k++) dst[k] = w[k];
-    }
-}
+// (One scalar times a variable base -- goldilocks_448_point_scalarmul, goldilocks_448_direct_scalarmul -- had a
+// digit-addressed form here until round 6: a 16-entry table per resident lane in HBM, 544 MiB of workspace and 46 x the
+// algorithmic traffic, for 32.4 M/s against the table-free ladder's 32.8 (direct_scalarmul: 26.6 against 28.5).  Both
+// table-access modes now run the ladder (kernels_varbase_ct.hip); the per-lane tables stay where they win: two scalars
+// on one doubling chain, and verification.)
 
 // "next" row f4: (s1*B, s2*B) for one base   (ref: goldilocks_448_point_dual_scalarmul)
 // out1 may alias base.

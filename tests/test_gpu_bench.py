@@ -52,7 +52,7 @@ def test_default_line_carries_configs_end_to_end_and_cpu_baseline():
     assert line["n_gpus"] == 1 and line["config"]["parity_spot_check"] == "ok"
     assert line["roofline"]["kernel"] == "k_point_scalarmul_ct" and line["config"]["table_access"] == "index-independent"
     assert "oracle's goldilocks_448_point_scalarmul" in line["config"]["check"]
-    assert set(line["configs"]) == {"fixed", "base", "verify", "verify_distinct_keys", "varbase_fast", "base_fast", "verify_table24"}
+    assert set(line["configs"]) == {"fixed", "base", "verify", "verify_distinct_keys", "base_fast", "verify_table24"}
     for c in line["configs"].values():
         assert c["parity_spot_check"] == "ok" and c["value"] > 0 and c["kernel_ms_avg"] > 0
         assert "equal the oracle's" in c["check"]                        # not a self-comparison
@@ -64,7 +64,6 @@ def test_default_line_carries_configs_end_to_end_and_cpu_baseline():
     peaks = line["roofline"]["mac"]["peaks"]
     assert line["roofline"]["mac"]["peak"] == peaks[peaks["used"]] == 38.4
     assert "rejects among them" in line["configs"]["verify"]["check"]
-    assert line["configs"]["varbase_fast"]["kernel"] == "k_point_scalarmul"
     assert line["configs"]["base"]["kernel"] == "k_base_scalarmul_ct" and line["configs"]["base_fast"]["kernel"] == "k_base_scalarmul"
     assert set(line["end_to_end"]) == {"varbase", "fixed", "verify", "link_gbs"}
     assert line["end_to_end"]["link_gbs"]["h2d"] > 1 and line["end_to_end"]["link_gbs"]["d2h"] > 1    # the link, measured in the same run

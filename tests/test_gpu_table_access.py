@@ -164,8 +164,11 @@ def test_index_independent_scan_on_a_full_residency(ga, O):
     try:
         ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
         ga.dev("point_scalarmul", out_ct.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None)
+        # (one scalar times a variable base runs the ladder in both modes since round 6: the every-lane cross-check is the
+        # two-scalar kernel with its digit-addressed tables, s*P + 0*P)
         ga.set_table_access(ga.TABLES_FAST)
-        ga.dev("point_scalarmul", out_fast.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None)
+        zero = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+        ga.dev("point_double_scalarmul", out_fast.data_ptr(), bases.data_ptr(), s.data_ptr(), bases.data_ptr(), zero.data_ptr(), n, None)
     finally:
         ga.set_table_access(ga.TABLES_INDEX_INDEPENDENT)
     st = torch.empty(n, dtype=torch.int32, device="cuda")
@@ -194,7 +197,9 @@ def test_ladder_kernels_over_several_launches_of_one_call(ga, O):
     inplace = bases.clone()
     out_fast = torch.empty_like(bases)
     ga.dev("point_scalarmul", inplace.data_ptr(), inplace.data_ptr(), s.data_ptr(), n, None, flags=ga.CALL_TABLES_INDEX_INDEPENDENT)
-    ga.dev("point_scalarmul", out_fast.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None, flags=ga.CALL_TABLES_FAST)
+    zero = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+    ga.dev("point_double_scalarmul", out_fast.data_ptr(), bases.data_ptr(), s.data_ptr(), bases.data_ptr(), zero.data_ptr(), n, None,
+           flags=ga.CALL_TABLES_FAST)           # s*P + 0*P through the digit-addressed two-scalar kernel
     st = torch.empty(n, dtype=torch.int32, device="cuda")
     ga.dev("point_pred", st.data_ptr(), inplace.data_ptr(), out_fast.data_ptr(), 0, n, None)
     assert int((st == -1).sum()) == n
@@ -268,3 +273,32 @@ def test_two_scalar_device_entries_with_every_output_aliasing(ga, O, mode):
     x, y = torch.empty_like(b1), b1.clone()                  # a2 == base
     ga.dev("point_dual_scalarmul", x.data_ptr(), y.data_ptr(), y.data_ptr(), s1.data_ptr(), s2.data_ptr(), n, None, flags=flags)
     assert same(x, r1) and same(y, r2)
+
+
+def test_one_scalar_times_a_variable_base_holds_no_tables_in_either_mode(ga, O):
+    """Round 6 retired the digit-addressed per-lane tables of goldilocks_448_point_scalarmul / _direct_scalarmul (544 MiB
+    of workspace, 46 x the algorithmic traffic, no faster than the ladder): a call with GOLDILOCKS_AMD_CALL_TABLES_FAST
+    runs the ladder too -- the workspace after 2^20 multiplications stays at the ladder's 128 MiB and the results are
+    the oracle's."""
+    import torch
+    ga.release_memory()
+    n = 1 << 20
+    k = torch.from_numpy(_gen.stream_scalars(n, b"ta/retired/base").view(np.int64)).cuda()
+    s = torch.from_numpy(_gen.stream_scalars(n, b"ta/retired/scalar").view(np.int64)).cuda()
+    bases = torch.empty((n, 32), dtype=torch.int64, device="cuda")
+    ga.dev("precomputed_scalarmul", bases.data_ptr(), None, k.data_ptr(), n, None)
+    ga.release_memory()
+    out = torch.empty_like(bases)
+    ga.dev("point_scalarmul", out.data_ptr(), bases.data_ptr(), s.data_ptr(), n, None, flags=ga.CALL_TABLES_FAST)
+    torch.cuda.synchronize()
+    assert 0 < ga.device_info()["workspace_bytes"] <= 128 << 20
+    enc_in = torch.empty((n, 56), dtype=torch.uint8, device="cuda")
+    enc_out, st = torch.empty_like(enc_in), torch.empty(n, dtype=torch.int32, device="cuda")
+    ga.dev("point_encode", enc_in.data_ptr(), bases.data_ptr(), n, None)
+    ga.dev("direct_scalarmul", enc_out.data_ptr(), st.data_ptr(), enc_in.data_ptr(), s.data_ptr(), 0, 0, n, None, flags=ga.CALL_TABLES_FAST)
+    torch.cuda.synchronize()
+    assert ga.device_info()["workspace_bytes"] <= 128 << 20 and int((st == -1).sum()) == n
+    idx = np.unique(np.concatenate([np.arange(0, n, 9973), [0, 63, 64, n - 1]]))
+    want = _gen.oracle_encode(_gen.oracle_varbase(O, bases.cpu().numpy().view(np.uint64)[idx], s.cpu().numpy().view(np.uint64)[idx]))
+    assert (ga.point_encode_batch(out.cpu().numpy().view(np.uint64)[idx]) == want).all()
+    assert (enc_out.cpu().numpy()[idx] == want).all()

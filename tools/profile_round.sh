@@ -32,11 +32,9 @@ for wl in varbase fixed base verify verify_distinct sign x448 direct; do
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- \
         python3 "$BENCH" --workload $wl --steps 5 --warmup 1 $Q > "$OUT/stats_$wl.log" 2>&1
 done
-for wl in varbase base sign direct; do   # the opt-in mode: digit-addressed tables
+for wl in base sign; do   # the opt-in mode: digit-addressed tables (one scalar times a variable base runs the ladder in both modes)
     python3 "$BENCH" --workload $wl $FAST $Q > "$DST/bench_${wl}_fast.json" 2> "$OUT/bench_${wl}_fast.err"
 done
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_varbasefast" -- \
-    python3 "$BENCH" --workload varbase $FAST --steps 5 --warmup 1 $Q > "$OUT/stats_varbasefast.log" 2>&1
 
 pmc() {   # pmc <tag> <workload> <extra bench args...> -- <counters...>
     local tag=$1 wl=$2; shift 2
@@ -50,16 +48,12 @@ for wl in varbase fixed base verify verify_distinct; do
     pmc FETCH $wl -- FETCH_SIZE
     pmc WRITE $wl -- WRITE_SIZE
 done
-pmc FETCHFAST varbase $FAST -- FETCH_SIZE
-pmc WRITEFAST varbase $FAST -- WRITE_SIZE
 pmc FETCHFAST base $FAST -- FETCH_SIZE
 pmc WRITEFAST base $FAST -- WRITE_SIZE
 for wl in varbase verify verify_distinct; do
     pmc SQ1 $wl -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES
     pmc SQ2 $wl -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 done
-pmc SQ1FAST varbase $FAST -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES
-pmc SQ2FAST varbase $FAST -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 pmc GRBM varbase -- GRBM_GUI_ACTIVE
 
 for probe in gpu_probe h2d_probe wave_probe key_pool_probe wide_comb_probe small_batch_probe ct_varbase_probe base_double_probe ct_base_probe direct_probe single_call_probe encode_probe crossover_probe; do
