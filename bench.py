@@ -584,13 +584,68 @@ def cpu_baseline_leg(np, bases_h, scalars_h, samples, budget_s=9.0):
     return res, checks
 
 
+# ---------------------------------------------------------------------------------------- the clock the chip holds
+
+class ClockSampler:
+    """The shader clock of one device while a timed region runs: /sys/class/drm/card*/device/pp_dpm_sclk (the level marked
+    '*'), read every 25 ms on a thread.  The VALU-issue ceiling is quoted against the nominal 2.4 GHz AND against what the
+    part sustained under this very load (it is power-limited: 2.30 - 2.32 GHz on the headline, profiles/r05/clock_under_load.txt)."""
+
+    def __init__(self, pci=None):
+        import glob
+        self.path, self.samples, self._stop, self._thread = None, [], False, None
+        for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
+            real = os.path.realpath(os.path.dirname(f))
+            if pci is None or pci.lower() in real.lower():
+                self.path = f
+                break
+
+    def _read(self):
+        try:
+            for l in open(self.path):
+                if "*" in l:
+                    return float(l.split(":")[1].lower().replace("mhz", "").replace("*", "").strip())
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def __enter__(self):
+        if self.path:
+            import threading
+
+            def run():
+                while not self._stop:
+                    v = self._read()
+                    if v:
+                        self.samples.append(v)
+                    time.sleep(0.025)
+            self._thread = threading.Thread(target=run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread:
+            self._thread.join()
+
+    def sustained_mhz(self):
+        """median of the samples taken under load (idle levels -- below 1 GHz -- dropped); None if the file is not there"""
+        v = sorted(x for x in self.samples if x >= 1000)
+        return v[len(v) // 2] if v else None
+
+
 # ---------------------------------------------------------------------------------------- one rank
 
-def time_workload(torch, shard, w, steps, warmup, dist, backend):
-    """-> (seconds of this rank, MAX over ranks, per-step kernel ms from HIP events on the launch stream)."""
+def time_workload(torch, shard, w, steps, warmup, dist, backend, clock=None):
+    """-> (seconds of this rank, MAX over ranks, per-step kernel ms from HIP events on the launch stream).
+    clock: a ClockSampler that runs while the warm-up and the timed steps do."""
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
-    mine, worst = shard.timed_region(w["step"], steps, warmup, torch.cuda.synchronize, dist, backend,
-                                     after_step=lambda i: ev[i + 1].record())
+    if clock is None:
+        clock = ClockSampler.__new__(ClockSampler)
+        clock.path, clock.samples, clock._stop, clock._thread = None, [], False, None
+    with clock:
+        mine, worst = shard.timed_region(w["step"], steps, warmup, torch.cuda.synchronize, dist, backend,
+                                         after_step=lambda i: ev[i + 1].record())
     return mine, worst, [ev[i].elapsed_time(ev[i + 1]) for i in range(steps)]
 
 
@@ -605,7 +660,7 @@ def kernel_source_sha16():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, bench=None):
     """HBM bytes per launch (kernel: a name, or the names of the kernels that make up a step: their sum) from the PMC passes of tools/profile_round.sh (profiles/pmc_traffic.json) -- a measurement of
     another run, so it says which kernels it was taken on: the figure is only reported as `traffic` when the kernels'
     sources are still the ones it was measured on; otherwise traffic is null and the stale figure goes to traffic_stale."""
@@ -616,13 +671,20 @@ def pmc_traffic(kernel):
     stamp = d.get("_measured_on") or {}
     current = stamp.get("kernel_source_sha16") == kernel_source_sha16()
     info = dict(stamp, current=current, file="profiles/pmc_traffic.json")
+    # a kernel's traffic depends on the configuration it ran in (config 4 at the 20-bit and at the 24-bit base table gathers
+    # from 2.2 and from 28.5 GiB): the passes are kept per bench run, and a figure is only reported for the run it was taken on
+    if bench is not None and "_by_bench" in d:          # (a file from before round 6 has the one flat table only)
+        d = d["_by_bench"].get(bench)
+        if d is None:
+            return None, dict(info, bench=bench, missing="no PMC pass for this configuration")
+        info = dict(info, bench=bench)
     if isinstance(kernel, (tuple, list)):
         parts = [d.get(k) for k in kernel]
         return (sum(parts) if all(x is not None for x in parts) else None), dict(info, kernels=list(kernel))
     return d.get(kernel), info
 
 
-def pmc_valu_insts(kernel):
+def pmc_valu_insts(kernel, bench=None):
     """VALU wave-instructions per 2^20-operation launch of `kernel` (or of the kernels of a step: their sum) from the same
     stamped PMC passes (SQ_INSTS_VALU); None when they were not taken on the current kernel sources."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -632,6 +694,8 @@ def pmc_valu_insts(kernel):
     if (d.get("_measured_on") or {}).get("kernel_source_sha16") != kernel_source_sha16():
         return None
     v = d.get("_valu_insts") or {}
+    if bench is not None and "_valu_by_bench" in d:
+        v = d["_valu_by_bench"].get(bench) or {}
     if isinstance(kernel, (tuple, list)):
         parts = [v.get(k) for k in kernel]
         return sum(parts) if all(x is not None for x in parts) else None
@@ -649,8 +713,17 @@ def table_access_uses_base_table(name, table_access):
     return name.startswith("verify") or table_access != "index-independent"
 
 
-def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_table_bits=0, macs=None):
+def pmc_bench_key(name, table_access, base_table_bits):
+    """the run of tools/profile_round.sh whose counters belong to this configuration"""
+    key = name + ("_fast" if table_access != "index-independent" and name in ("base", "sign") else "")
+    if name.startswith("verify") and base_table_bits not in (0, 20):
+        key += "%d" % base_table_bits
+    return key
+
+
+def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_table_bits=0, macs=None, sustained_mhz=None):
     spec = dict(WORKLOADS[name])
+    bench_key = pmc_bench_key(name, table_access, base_table_bits)
     if macs:                # (verification: the multiply-accumulates of the comb geometry the batch's keys really got)
         spec["macs"] = macs
     # (one scalar times a variable base runs the table-free ladder in BOTH table-access modes since round 6)
@@ -663,7 +736,7 @@ def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_t
     if n < spec.get("recomb_min", 0):
         spec["macs"] = spec["macs_reference_comb"]
     achieved = spec["bytes"] * n / (avg_ms * 1e-3) / 1e9
-    traffic, measured_on = pmc_traffic(traffic_kernels or kernel)
+    traffic, measured_on = pmc_traffic(traffic_kernels or kernel, bench_key)
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "traffic": traffic if measured_on and measured_on["current"] else None, "kernel": kernel, "kernel_ms_avg": avg_ms,
          "bytes_per_op": spec["bytes"],
@@ -686,12 +759,18 @@ def roofline(name, kernel, n, avg_ms, table_access, traffic_kernels=None, base_t
     # count is SQ_INSTS_VALU of a 2^20-operation launch from the stamped PMC passes (scaled to this launch's n); the time
     # is this run's.  What is left below 1.0 is the clock the chip holds under this load (2.30 - 2.32 GHz at 1.31 kW:
     # power-limited, profiles/r05/clock_under_load.txt) and about five percent of stalls; the lever is instructions per operation.
-    insts = pmc_valu_insts(traffic_kernels or kernel)
+    insts = pmc_valu_insts(traffic_kernels or kernel, bench_key)
     if insts:
         per_s = insts * (n / float(1 << LOG2_BATCH)) / (avg_ms * 1e-3)
         r["valu_issue"] = {"achieved": per_s / 1e9, "peak": VALU_ISSUE_PEAK / 1e9, "unit": "G wave-instructions/s",
                            "frac": per_s / VALU_ISSUE_PEAK, "valu_instructions_per_op": insts * 64 / float(1 << LOG2_BATCH),
-                           "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json (same kernel sources); peak = 1024 SIMDs x 2.4 GHz / 4"}
+                           "source": "SQ_INSTS_VALU of run '%s', profiles/pmc_traffic.json (same kernel sources); peak = 1024 SIMDs x 2.4 GHz / 4" % bench_key}
+        if sustained_mhz:   # ... and against the clock the part held under THIS load (ClockSampler: pp_dpm_sclk, sampled through the timed steps)
+            peak_now = 1024 * sustained_mhz * 1e6 / 4
+            r["valu_issue"].update({"sustained_mhz": sustained_mhz, "peak_at_sustained_clock": peak_now / 1e9,
+                                    "frac_at_sustained_clock": per_s / peak_now})
+    elif sustained_mhz:
+        r["sustained_mhz"] = sustained_mhz
     return r
 
 
@@ -756,7 +835,10 @@ def run_rank(args):
     spec = WORKLOADS[name]
     cx = Ctx(ga, np, torch, n, rank)
     w = make_workload(name, cx, args.table_access)
-    mine, worst, kernel_ms = time_workload(torch, shard, w, args.steps, args.warmup, dist, backend)
+    pci_of = torch.cuda.get_device_properties(torch.cuda.current_device())
+    pci_txt = "%04x:%02x:%02x" % (getattr(pci_of, "pci_domain_id", 0), getattr(pci_of, "pci_bus_id", 0), getattr(pci_of, "pci_device_id", 0))
+    clock = ClockSampler(pci_txt if torch.cuda.device_count() > 1 else None)
+    mine, worst, kernel_ms = time_workload(torch, shard, w, args.steps, args.warmup, dist, backend, clock)
     if "kernels_after" in w:
         w["kernel"], w["traffic_kernels"], w["macs"] = w["kernels_after"]()
     avg_ms = sum(kernel_ms) / len(kernel_ms)
@@ -790,11 +872,14 @@ def run_rank(args):
                        # what the library holds on the device after the timed steps (workspace + staging + tables)
                        "device_memory_bytes": ga.device_info()["workspace_bytes"],
                        "parity_spot_check": "ok" if ok else "FAILED", "check": check},
+            # the code object this line was measured on and what compiled it (parity evidence is tied to both)
+            "build": ga.build_info(),
             "per_gpu": [dict({"rank": int(r[0]), "device": int(r[1]), "value": r[2], "unit": spec["unit"],
                               "kernel_ms_avg": r[3], "batch": int(r[4]),
                               "pci": "%04x:%02x:%02x" % (int(r[6]), int(r[7]), int(r[8])) if r[6] >= 0 else None},
                              **({"slice": [int(r[5]), int(r[5]) + int(r[4])]} if scaling == "strong" else {})) for r in rows],
-            "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels"), ga.get_base_table_bits(), w.get("macs")),
+            "roofline": roofline(name, w["kernel"], n, avg_ms, args.table_access, w.get("traffic_kernels"), ga.get_base_table_bits(), w.get("macs"),
+                                 clock.sustained_mhz()),
         }
         line["roofline"]["kernel_ms_every_step"] = [round(x, 3) for x in kernel_ms]   # (rank 0's; HIP events on the launch stream)
         line.update(extra)
@@ -819,17 +904,21 @@ def run_rank(args):
             t_probe = max(time.perf_counter() - t_probe, 1e-4)
             cwarm = max(3, min(100, int(0.15 / t_probe)))
             csteps = 8 if t_probe > 0.02 else 12
-            _, cworst, cms = time_workload(torch, shard, cw, csteps, cwarm, None, None)
+            cclock = ClockSampler(pci_txt if torch.cuda.device_count() > 1 else None)
+            _, cworst, cms = time_workload(torch, shard, cw, csteps, cwarm, None, None, cclock)
             if "kernels_after" in cw:
                 cw["kernel"], cw["traffic_kernels"], cw["macs"] = cw["kernels_after"]()
             cok, ctext, _ = cw["check"]()
             cavg = sum(cms) / len(cms)
-            r = roofline(cname, cw["kernel"], n, cavg, access, cw.get("traffic_kernels"), ga.get_base_table_bits(), cw.get("macs"))
+            r = roofline(cname, cw["kernel"], n, cavg, access, cw.get("traffic_kernels"), ga.get_base_table_bits(), cw.get("macs"),
+                         cclock.sustained_mhz())
             configs[key] = {"value": n * csteps / cworst, "unit": WORKLOADS[cname]["unit"], "workload": WORKLOADS[cname]["desc"],
                             "table_access": access, "steps": csteps, "warmup": cwarm, "kernel": cw["kernel"], "kernel_ms_avg": cavg,
                             "roofline": {k: r[k] for k in ("achieved", "frac", "traffic", "unit", "traffic_measured_on", "traffic_stale",
                                                                "traffic_of_base_table_gathers", "traffic_note") if k in r},
                             "mac_frac": r["mac"]["frac"] if "mac" in r else None, "macs_per_op": r["mac"]["macs_per_op"] if "mac" in r else None,
+                            # the ceiling that binds, for every config: VALU issue at the nominal and at the sustained clock
+                            "valu_issue": r.get("valu_issue"), "sustained_mhz": cclock.sustained_mhz(),
                             "base_table_bits": ga.get_base_table_bits(), "base_table_bits_is_library_default": table_bits == 0,
                             # what the library holds on the device now (workspace + staging + the base point's table)
                             "device_memory_bytes": ga.device_info()["workspace_bytes"], "check": ctext,

@@ -314,6 +314,8 @@ GOLDILOCKS_AMD_API int goldilocks_x448_batch(uint8_t *shared /* n*56 */, goldilo
 GOLDILOCKS_AMD_API int goldilocks_amd_init(int device);
 GOLDILOCKS_AMD_API void goldilocks_amd_shutdown(void);
 GOLDILOCKS_AMD_API const char *goldilocks_amd_last_error(void);
+/* the toolchain that compiled this library ("clang <version>; HIP <version>; <flags>"): a static string */
+GOLDILOCKS_AMD_API const char *goldilocks_amd_build_info(void);
 /* Multi-GPU for the host-array batches (independent operations, contiguous slice
  * [g*n/G, (g+1)*n/G) per GPU, one host thread per GPU, no cross-device traffic): after this call
  * goldilocks_448_point_scalarmul_batch, goldilocks_448_precomputed_scalarmul_batch and
@@ -348,11 +350,11 @@ GOLDILOCKS_AMD_API int goldilocks_amd_use_devices(const int *devices, int count)
  *     condition and no memory address depends on the scalar (tests/test_isa_audit.py).
  *   GOLDILOCKS_AMD_TABLES_FAST (opt-in, for PUBLIC scalars only)
  *     - each lookup reads only the digit's entry (the address depends on the digit): the base point's
- *       window table in global memory (goldilocks_amd_set_base_table_bits); 5-bit windows per lane for the TWO-scalar
- *       variable-base entry points (point_double_scalarmul, point_dual_scalarmul: one doubling chain instead of two
- *       ladders, 44 against 64 ms per 2^20).  goldilocks_448_point_scalarmul and goldilocks_448_direct_scalarmul run the
- *       table-free ladder in THIS mode too since round 6: it is the faster one (32.8 against 32.4 M/s) and holds no
- *       544-MiB table workspace.
+ *       window table in global memory (goldilocks_amd_set_base_table_bits); 5-bit windows per lane for
+ *       goldilocks_448_point_double_scalarmul (two tables on ONE doubling chain instead of two ladders: 42 against
+ *       62 ms per 2^20).  goldilocks_448_point_scalarmul, _direct_scalarmul and _point_dual_scalarmul run the
+ *       table-free ladder(s) in THIS mode too since round 6: the ladder is the faster way to multiply one variable base
+ *       (32.8 against 32.4 M/s; dual: 61.7 against 62.7 ms) and holds no 544-MiB table workspace.
  *
  * Not affected: verification and base_double_scalarmul_non_secret (public by contract: always the
  * fast tables), goldilocks_x448 with a peer's point (a Montgomery ladder with selects, no table),
@@ -460,6 +462,10 @@ GOLDILOCKS_AMD_API int goldilocks_amd_get_base_table_bits(void);
  * two is non-zero; all zero if the batch was too small for either), counts[3] the combs' teeth (7, 8 or 9; 0 without
  * combs).  Waits for the device. */
 GOLDILOCKS_AMD_API int goldilocks_amd_last_verify_key_counts(uint32_t counts[4]);
+/* Test hook: entries [first, first + count) of the base point's window table on the calling thread's device (built at the
+ * width in force if it is not there yet) as canonical bytes -- a, b, cn of each affine niels, 3 x 56 bytes -- into host
+ * memory: the every-entry check of the table's build (tests/test_gpu_every_lane.py).  Waits for the device. */
+GOLDILOCKS_AMD_API int goldilocks_amd_base_table_export(uint8_t *dst /* count*168 */, uint64_t first, size_t count);
 /* "gfx950", number of CUs, device memory the library currently holds on the calling thread's device besides its small
  * tables: workspace + staging + the base point's window table */
 GOLDILOCKS_AMD_API int goldilocks_amd_device_info(char *arch, size_t arch_len, int *compute_units,

@@ -87,12 +87,14 @@ FUNCTIONS = {
     "goldilocks_amd_init": (C.c_int, "i"),
     "goldilocks_amd_shutdown": (None, ""),
     "goldilocks_amd_last_error": (C.c_char_p, ""),
+    "goldilocks_amd_build_info": (C.c_char_p, ""),
     "goldilocks_amd_device_info": (C.c_int, "pzpp"),
     "goldilocks_amd_use_devices": (C.c_int, "pi"),
     "goldilocks_amd_set_table_access": (C.c_int, "i"),
     "goldilocks_amd_get_table_access": (C.c_int, ""),
     "goldilocks_amd_thread_mode_counts": (None, "p"),
     "goldilocks_amd_last_verify_key_counts": (C.c_int, "p"),
+    "goldilocks_amd_base_table_export": (C.c_int, "pQz"),
     "goldilocks_amd_set_wave_batch_max": (None, "z"),
     "goldilocks_amd_get_wave_batch_max": (C.c_size_t, ""),
     "goldilocks_amd_set_verify_key_pool": (None, "zz"),
@@ -562,6 +564,15 @@ def last_verify_key_counts(teeth=False):
     c = (C.c_uint32 * 4)()
     _check(lib().goldilocks_amd_last_verify_key_counts(C.addressof(c)))
     return (int(c[0]), int(c[1]), int(c[2]), int(c[3])) if teeth else (int(c[0]), int(c[1]), int(c[2]))
+
+
+def build_info():
+    """{"toolchain": what compiled the loaded library, "library_sha256": the digest of the file that was loaded}: the stamp
+    that bench lines, GPU test logs and soak logs carry (parity evidence belongs to one code object of one toolchain)."""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()
+    return {"toolchain": lib().goldilocks_amd_build_info().decode(), "library_sha256": digest}
 
 
 def device_info():

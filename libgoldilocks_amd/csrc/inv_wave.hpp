@@ -54,4 +54,8 @@ __device__ __forceinline__ fe wave_shared_invert(const fe &x, uint32_t *lds /* I
     return fe_select(r, fe_zero(), zero);
 }
 
+// (One inversion per BLOCK -- the waves' row totals meeting in LDS, wave 0 inverting for all four -- was built and measured in
+// round 6: config 4 and signing within the noise, the headline 1.3 % SLOWER (32.0 against 31.6 ms: two more barriers in a
+// kernel whose waves otherwise never wait for each other).  Not adopted: profiles/r06/ab_block_invert.txt.)
+
 }  // namespace gd

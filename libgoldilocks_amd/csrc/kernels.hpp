@@ -654,9 +654,6 @@ GD_KERNEL k_x448_derive_ct(uint8_t *__restrict__ shared, const uint8_t *__restri
 GD_KERNEL k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
                                 const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
                                 int allow_identity, int short_circuit, const uint64_t *__restrict__ point_base_abi);
-GD_KERNEL k_point_dual_scalarmul(uint64_t *out1, uint64_t *out2, const uint64_t *base,
-                                 const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
-                                 uint4 *__restrict__ workspace);
 GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *out2, const uint64_t *base,
                                        const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                        uint4 *__restrict__ workspace);
@@ -665,6 +662,7 @@ GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, con
                  const uint8_t *__restrict__ scalar, uint32_t n, const uint4 *__restrict__ bwt,
                  uint4 *__restrict__ workspace);
 GD_KERNEL k_point_encode(uint8_t *__restrict__ ser, const uint64_t *__restrict__ pts, uint32_t n, int eddsa);
+GD_KERNEL k_bwt_export(uint8_t *__restrict__ out, const uint4 *__restrict__ bwt, uint64_t first, uint32_t count);
 GD_KERNEL k_ed448_expand_secret(uint8_t *__restrict__ out, const uint8_t *__restrict__ sk, uint32_t n, int as_scalar);
 GD_KERNEL k_x448_from_edwards(uint8_t *__restrict__ out, const uint8_t *__restrict__ ed, const uint64_t *__restrict__ pts,
                               uint32_t n);

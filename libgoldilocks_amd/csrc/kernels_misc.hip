@@ -60,6 +60,23 @@ GD_KERNEL k_x448_from_edwards(uint8_t *__restrict__ out, const uint8_t *__restri
     }
 }
 
+// Test hook: entries [first, first + count) of the base point's window table as canonical bytes -- a, b, cn of each affine
+// niels serialized (3 x 56 bytes) -- for the every-entry check of k_build_bwt against the oracle (tests/test_gpu_every_lane.py).
+GD_KERNEL k_bwt_export(uint8_t *__restrict__ out, const uint4 *__restrict__ bwt, uint64_t first, uint32_t count) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < count; i += stride) {
+        const uint4 *q = bwt + BWT_HEADER_U4 + 12 * (first + i);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(out + 168 * (size_t)i);      // 168 i is 8-byte aligned
+#pragma unroll 1
+        for (int f = 0; f < 3; f++) {
+            uint32_t w[14];
+            fe_serialize_words(w, fe_load(q + 4 * f));
+#pragma unroll
+            for (int k = 0; k < 14; k++) dst[14 * f + k] = w[k];
+        }
+    }
+}
+
 // What SHAKE256(sk) gives an Ed448 private key's owner besides the public key: 56 bytes each.
 //   as_scalar == 0: the X448 private key, SHAKE256(sk)[0:56] (goldilocks_ed448_convert_private_key_to_x448,
 //                   src/eddsa.c:83-95)

@@ -12,24 +12,31 @@
 
 namespace gd {
 
+// (A/B: GD_TWO_LADDER_WAVES=1 gives the two-ladder and the decode-ladder-encode kernels 512 registers per lane -- their
+// spills land in AGPRs instead of scratch -- at one wave per SIMD; round 6 measured it, profiles/r06/ab_launch_bounds.txt)
+#ifndef GD_TWO_LADDER_WAVES
+#define GD_TWO_LADDER_WAVES WAVES_PER_SIMD
+#endif
+#define GD_KERNEL_2L extern "C" __global__ void __launch_bounds__(BLOCK, GD_TWO_LADDER_WAVES)
+
 GD_KERNEL k_point_scalarmul_ct(uint64_t *out, const uint64_t *base, const uint64_t *__restrict__ scalar,
                                uint32_t n, uint4 *__restrict__ workspace) {
     point_scalarmul_ladder_body(out, base, scalar, n, workspace);
 }
 
-GD_KERNEL k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
+GD_KERNEL_2L k_direct_scalarmul_ct(uint8_t *__restrict__ scaled, int32_t *__restrict__ status,
                                 const uint8_t *__restrict__ base, const uint64_t *__restrict__ scalar, uint32_t n,
                                 int allow_identity, int short_circuit, const uint64_t *__restrict__ point_base_abi) {
     direct_scalarmul_ladder_body(scaled, status, base, scalar, n, allow_identity, short_circuit, point_base_abi);
 }
 
-GD_KERNEL k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *out2, const uint64_t *base,
+GD_KERNEL_2L k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *out2, const uint64_t *base,
                                     const uint64_t *__restrict__ s1, const uint64_t *__restrict__ s2, uint32_t n,
                                     uint4 *__restrict__ workspace) {
     point_dual_scalarmul_ladder_body(out1, out2, base, s1, s2, n, workspace);
 }
 
-GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
+GD_KERNEL_2L k_double_scalarmul_ct(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
                                 const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
                                 uint4 *__restrict__ workspace) {
     double_scalarmul_ladder_body(out, b1, s1, b2, s2, n, workspace);

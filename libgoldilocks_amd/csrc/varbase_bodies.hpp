@@ -1,7 +1,7 @@
 // varbase_bodies.hpp -- bodies of the kernels that multiply a caller's point by a scalar, in two families:
 //   * digit-addressed window tables (5-bit signed windows, the digit picks the address of its entry in the
 //     lane's table): public scalars -- verification, base_double_scalarmul_non_secret, or a caller who asked for
-//     GOLDILOCKS_AMD_TABLES_FAST.  Instantiated by kernels_varbase.hip / kernels_verify.hip.
+//     GOLDILOCKS_AMD_TABLES_FAST in goldilocks_448_point_double_scalarmul.  Instantiated by kernels_verify_lanes.hip.
 //   * NO table at all (montgomery.hpp: a Montgomery ladder of selects): the library's default for every entry
 //     point whose scalar may be secret -- the counterpart of the reference's constant_time_lookup
 //     (src/include/constant_time.h:134-183), which goldilocks_448_point_scalarmul / _double_scalarmul /
@@ -25,29 +25,9 @@ __device__ __forceinline__ LaneTable lane_table_at(uint4 *ws, int which, int nta
 // (One scalar times a variable base -- goldilocks_448_point_scalarmul, goldilocks_448_direct_scalarmul -- had a
 // digit-addressed form here until round 6: a 16-entry table per resident lane in HBM, 544 MiB of workspace and 46 x the
 // algorithmic traffic, for 32.4 M/s against the table-free ladder's 32.8 (direct_scalarmul: 26.6 against 28.5).  Both
-// table-access modes now run the ladder (kernels_varbase_ct.hip); the per-lane tables stay where they win: two scalars
-// on one doubling chain, and verification.)
-
-// "next" row f4: (s1*B, s2*B) for one base   (ref: goldilocks_448_point_dual_scalarmul)
-// out1 may alias base.
-__device__ __forceinline__ void point_dual_scalarmul_body(uint64_t *out1, uint64_t *out2,
-                                                          const uint64_t *base, const uint64_t *__restrict__ s1,
-                                                          const uint64_t *__restrict__ s2, uint32_t n,
-                                                          uint4 *__restrict__ workspace) {
-    __shared__ uint32_t s_bits[30 * BLOCK];
-    const uint32_t lane = blockIdx.x * BLOCK + threadIdx.x;
-    const uint32_t stride = gridDim.x * BLOCK;
-    LaneTable tab = lane_table_at(workspace, 0, 1);
-    for (uint32_t i = lane; i < n; i += stride) {
-        LdsBits b1 = lds_put_bits(s_bits + threadIdx.x, sc_recode_signed(sc_load_abi(s1 + 7 * (size_t)i)));
-        LdsBits b2 = lds_put_bits(s_bits + 15 * BLOCK + threadIdx.x, sc_recode_signed(sc_load_abi(s2 + 7 * (size_t)i)));
-        build_window_table(tab, pt_load_abi(base + 32 * (size_t)i));
-        pt r1, r2;
-        ladder_dual(r1, r2, b1, b2, tab);
-        pt_store_abi(out1 + 32 * (size_t)i, r1);
-        pt_store_abi(out2 + 32 * (size_t)i, r2);
-    }
-}
+// table-access modes now run the ladder (kernels_varbase_ct.hip), and so does goldilocks_448_point_dual_scalarmul, whose
+// one table walked twice was no faster than two ladders either (62.7 against 61.7 ms); the per-lane tables stay where
+// they win: two scalars on ONE doubling chain (point_double_scalarmul: 42 against 62 ms), and verification.)
 
 // combo[i] = s1[i]*b1[i] + s2[i]*b2[i]   (ref: goldilocks_448_point_double_scalarmul, src/goldilocks.c:467-541).
 // b1 == nullptr: b1 is the base point -- goldilocks_448_base_double_scalarmul_non_secret, public scalars by
@@ -158,7 +138,13 @@ __device__ __forceinline__ void direct_scalarmul_ladder_body(uint8_t *__restrict
         if (!ok && short_circuit) continue;         // the encoding is public: so is this branch
         if (!ok) {                                  // src/goldilocks.c:898: multiply the base point instead
             b = pt_load_abi(point_base_abi);
+#if defined(GD_REPRO_R05_DIVERGENT_INVERSION)
+            // Round 5's miscompiled shape, kept for tools/probes/miscompile_r05_repro.py ONLY: the field inversion inside
+            // this divergent block came out wrong in the no-pairs build of this unit (docs/history/r05.md H).
+            u = fe_mul(fe_add(b.y, b.z), fe_invert(ml_denominator(b)));
+#else
             u = ml_u_base();
+#endif
         }
         LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(scalar + 7 * (size_t)i)));
         const pt r = ml_scalarmul_u(b, u, bits);

@@ -1267,6 +1267,79 @@ void orc_precomputed_scalarmul_batch(orc_point *out, const orc_precomputed *tab,
     run_ranges(psm_range, &a, n, nt);
 }
 
+/* ---- every-lane checkers of the spill-heavy kernels (tests/test_gpu_every_lane.py): the reference's functions, one
+ * call per operation, spread over threads */
+struct dbl_args { orc_point *out, *out2; const orc_point *b1, *b2; const orc_scalar *s1, *s2; };
+static void dbl_range(void *a, size_t lo, size_t hi) {
+    struct dbl_args *x = (struct dbl_args *)a;
+    for (size_t i = lo; i < hi; i++) orc_point_double_scalarmul(&x->out[i], &x->b1[i], &x->s1[i], &x->b2[i], &x->s2[i]);
+}
+void orc_point_double_scalarmul_batch(orc_point *out, const orc_point *b1, const orc_scalar *s1, const orc_point *b2,
+                                      const orc_scalar *s2, size_t n, int nt) {
+    struct dbl_args a = {out, NULL, b1, b2, s1, s2};
+    run_ranges(dbl_range, &a, n, nt);
+}
+static void dual_range(void *a, size_t lo, size_t hi) {   /* goldilocks.c:543-642: (s1*b, s2*b) */
+    struct dbl_args *x = (struct dbl_args *)a;
+    for (size_t i = lo; i < hi; i++) {
+        orc_point_scalarmul(&x->out[i], &x->b1[i], &x->s1[i]);
+        orc_point_scalarmul(&x->out2[i], &x->b1[i], &x->s2[i]);
+    }
+}
+void orc_point_dual_scalarmul_batch(orc_point *out1, orc_point *out2, const orc_point *b, const orc_scalar *s1,
+                                    const orc_scalar *s2, size_t n, int nt) {
+    struct dbl_args a = {out1, out2, b, NULL, s1, s2};
+    run_ranges(dual_range, &a, n, nt);
+}
+struct dir_args { uint8_t *out; int32_t *status; const uint8_t *base; const orc_scalar *s; int allow_identity, short_circuit; };
+static void dir_range(void *a, size_t lo, size_t hi) {
+    struct dir_args *x = (struct dir_args *)a;
+    for (size_t i = lo; i < hi; i++)
+        x->status[i] = orc_direct_scalarmul(x->out + 56 * i, x->base + 56 * i, &x->s[i], x->allow_identity, x->short_circuit);
+}
+void orc_direct_scalarmul_batch(uint8_t *out56, int32_t *status, const uint8_t *base56, const orc_scalar *s, int allow_identity,
+                                int short_circuit, size_t n, int nt) {
+    struct dir_args a = {out56, status, base56, s, allow_identity, short_circuit};
+    run_ranges(dir_range, &a, n, nt);
+}
+/* Entry e = i * 2^(bits-1) + k of the base point's window table of `bits`-bit digits -- a structure of the BUILD, not of
+ * the reference (libgoldilocks_amd/csrc/scalarmul.hpp ladder_bwt) -- is ((2k+1) * 2^(bits i) mod q) * B as an affine niels
+ * in the build's convention: (Y-X)/(2Z), (Y+X)/(2Z), 78164 T/(2Z), each serialized canonically (3 x 56 bytes).  Computed
+ * with the reference's own pieces: scalar_mul, precomputed_scalarmul on the base comb, gf_invert. */
+struct bwt_args { uint8_t *out; unsigned bits; size_t first; };
+static void bwt_range(void *a, size_t lo, size_t hi) {
+    struct bwt_args *x = (struct bwt_args *)a;
+    for (size_t idx = lo; idx < hi; idx++) {
+        const size_t e = x->first + idx, i = e >> (x->bits - 1), k = e & (((size_t)1 << (x->bits - 1)) - 1);
+        const unsigned pos = x->bits * (unsigned)i;          /* < 446 for every width the build supports */
+        orc_scalar pw, sm, sc;
+        memset(&pw, 0, sizeof pw);
+        memset(&sm, 0, sizeof sm);
+        pw.limb[pos / 64] = (uint64_t)1 << (pos % 64);
+        sm.limb[0] = 2 * (uint64_t)k + 1;
+        orc_scalar_mul(&sc, &pw, &sm);
+        orc_point p;
+        orc_precomputed_scalarmul(&p, orc_precomputed_base(), &sc);
+        orc_gf z2, zi, t, r;
+        orc_gf_add(&z2, &p.z, &p.z);
+        fe_invert(&zi, &z2);
+        orc_gf_sub(&t, &p.y, &p.x);
+        fe_mul(&r, &t, &zi);
+        orc_gf_serialize(x->out + 168 * idx, &r);
+        orc_gf_add(&t, &p.y, &p.x);
+        fe_mul(&r, &t, &zi);
+        orc_gf_serialize(x->out + 168 * idx + 56, &r);
+        orc_gf_mulw(&t, &p.t, 78164);
+        fe_mul(&r, &t, &zi);
+        orc_gf_serialize(x->out + 168 * idx + 112, &r);
+    }
+}
+void orc_base_table_entries(uint8_t *out168, unsigned bits, size_t first, size_t count, int nt) {
+    struct bwt_args a = {out168, bits, first};
+    (void)orc_point_base();
+    run_ranges(bwt_range, &a, count, nt);
+}
+
 struct enc_args { uint8_t *out; const orc_point *p; };
 static void enc_range(void *a, size_t lo, size_t hi) {
     struct enc_args *x = (struct enc_args *)a;

@@ -133,6 +133,13 @@ ORC_API void orc_ed448_sign_batch(uint8_t *sig114, const uint8_t *sk57, const ui
                                   const uint8_t *msgs, size_t msglen, uint8_t prehashed,
                                   const uint8_t *ctx, uint8_t ctxlen, size_t n, int nthreads);
 ORC_API void orc_ed448_derive_public_key_batch(uint8_t *pk57, const uint8_t *sk57, size_t n, int nthreads);
+ORC_API void orc_point_double_scalarmul_batch(orc_point *out, const orc_point *b1, const orc_scalar *s1, const orc_point *b2,
+                                              const orc_scalar *s2, size_t n, int nthreads);
+ORC_API void orc_point_dual_scalarmul_batch(orc_point *out1, orc_point *out2, const orc_point *b, const orc_scalar *s1,
+                                            const orc_scalar *s2, size_t n, int nthreads);
+ORC_API void orc_direct_scalarmul_batch(uint8_t *out56, int32_t *status, const uint8_t *base56, const orc_scalar *s,
+                                        int allow_identity, int short_circuit, size_t n, int nthreads);
+ORC_API void orc_base_table_entries(uint8_t *out168, unsigned bits, size_t first, size_t count, int nthreads);
 
 #ifdef __cplusplus
 }

@@ -142,6 +142,10 @@ def oracle():
         "orc_ed448_sign_batch": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8,
                                         C.c_size_t, C.c_int]),
         "orc_ed448_derive_public_key_batch": (None, [vp, vp, C.c_size_t, C.c_int]),
+        "orc_point_double_scalarmul_batch": (None, [vp, vp, vp, vp, vp, C.c_size_t, C.c_int]),
+        "orc_point_dual_scalarmul_batch": (None, [vp, vp, vp, vp, vp, C.c_size_t, C.c_int]),
+        "orc_direct_scalarmul_batch": (None, [vp, vp, vp, vp, C.c_int, C.c_int, C.c_size_t, C.c_int]),
+        "orc_base_table_entries": (None, [vp, C.c_uint, C.c_size_t, C.c_size_t, C.c_int]),
     }
     for name, (res, args) in proto.items():
         f = getattr(L, name)

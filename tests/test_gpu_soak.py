@@ -212,3 +212,22 @@ def test_soak_wave_path(ga, O, table_mode):
             else:
                 O.orc_point_from_hash_nonuniform(C.cast(_p(w[i]), C.POINTER(Point)), _p(np.ascontiguousarray(h[i, :56])))
         assert (enc(ga, hp[sel]) == _gen.oracle_encode(w[sel])).all()
+
+
+def test_soak_logs_belong_to_this_toolchain(ga):
+    """Parity evidence is tied to the toolchain that produced the code: round 5 found a block the compiler got wrong next to
+    the product (docs/history/r05.md H; tools/probes/miscompile_r05_repro.py asks a toolchain whether it still does).  The
+    newest extended-soak log under profiles/ that carries a stamp (tools/soak.sh writes `toolchain:` and `library_sha256:`)
+    must have been taken with the compiler that built the library under test -- after a toolchain update the soaks are to
+    be taken again before their figures are quoted."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    stamped = []
+    for f in sorted(glob.glob(os.path.join(root, "profiles", "r*", "soak_*.txt"))):
+        m = re.search(r"^toolchain: (.*)$", open(f).read(), re.M)
+        if m:
+            stamped.append((f, m.group(1).strip()))
+    assert stamped, "no stamped soak log under profiles/ (run tools/soak.sh on the GPU box and commit its summary)"
+    newest = max(stamped, key=lambda t: (int(re.search(r"profiles/r(\d+)/", t[0]).group(1)), t[0]))
+    assert newest[1] == ga.build_info()["toolchain"], (newest, ga.build_info()["toolchain"])

@@ -82,9 +82,10 @@ def test_per_call_table_access_from_two_threads(ga, O):
             before = ga.thread_mode_counts()
             out = torch.empty((n, 32), dtype=torch.int64, device="cuda")
             st = torch.cuda.Stream()
-            for _ in range(rounds):
-                ga.dev("point_scalarmul", out.data_ptr(), d_b.data_ptr(), d_s.data_ptr(), n, st.cuda_stream,
-                       flags=ga.CALL_TABLES_FAST)
+            zero = torch.zeros((n, 7), dtype=torch.int64, device="cuda")
+            for _ in range(rounds):     # s*b + 0*b through the two-scalar entry point: the one whose FAST is digit-addressed tables
+                ga.dev("point_double_scalarmul", out.data_ptr(), d_b.data_ptr(), d_s.data_ptr(), d_b.data_ptr(), zero.data_ptr(), n,
+                       st.cuda_stream, flags=ga.CALL_TABLES_FAST)
             st.synchronize()
             after = ga.thread_mode_counts()
             counts["public"] = (after[0] - before[0], after[1] - before[1])

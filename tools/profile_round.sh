@@ -54,6 +54,17 @@ for wl in varbase verify verify_distinct; do
     pmc SQ1 $wl -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES
     pmc SQ2 $wl -- SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY
 done
+# config 4 at the opt-in 24-bit base table (28.5 GiB): its own passes, kept as run "verify24" (the table's width comes from the
+# environment, which the profiled python inherits: no env hop behind rocprofv3)
+export GOLDILOCKS_AMD_BASE_TABLE_BITS=24
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_FETCH_verify24" -- python3 "$BENCH" --workload verify --steps 2 --warmup 1 $Q > "$OUT/pmc_FETCH_verify24.log" 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_WRITE_verify24" -- python3 "$BENCH" --workload verify --steps 2 --warmup 1 $Q > "$OUT/pmc_WRITE_verify24.log" 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES --output-format csv -d "$OUT/pmc_SQ1_verify24" -- python3 "$BENCH" --workload verify --steps 2 --warmup 1 $Q > "$OUT/pmc_SQ1_verify24.log" 2>&1
+unset GOLDILOCKS_AMD_BASE_TABLE_BITS
+for wl in fixed base sign x448 direct; do       # the ceiling that binds, for every workload of the line
+    pmc SQ1 $wl -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES
+done
+pmc SQ1FAST base $FAST -- SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_WAVES
 pmc GRBM varbase -- GRBM_GUI_ACTIVE
 
 for probe in gpu_probe h2d_probe wave_probe key_pool_probe wide_comb_probe small_batch_probe ct_varbase_probe base_double_probe ct_base_probe direct_probe single_call_probe encode_probe crossover_probe; do
