@@ -481,7 +481,7 @@ template <class FB, class MKBITS>
 GD_FN pniels ed448_verify_base_part(const uint8_t *sig114, const FB &fb, MKBITS &mkbits) {
     uint32_t w[15];
     load_bytes_as_words(w, sig114 + 57, 57, 15);
-    return pt_to_pniels(fb.mul(sc_decode_long_words<57>(w), mkbits));
+    return pt_to_pniels(fb.mul_ahead(sc_decode_long_words<57>(w), mkbits));
 }
 template <class FB, class COMB, class STAGE, class MKBITS, class QSRC>
 GD_FN KeycombPending ed448_verify_keycomb_begin(const Ed448Msg &m, const FB &fb, const COMB &comb, STAGE &stage, MKBITS &mkbits,

@@ -325,6 +325,31 @@ GD_FN void ladder_bwt_onto(pt &acc, const BITS &bits, const BWT &bwt) {
         pt_add_niels(acc, e, neg_e, true);
     }
 }
+// ladder_bwt with the next digit's entry requested an addition ahead (as ladder_bwt_onto): for a kernel with registers to
+// spare -- k_verify_base_part: 230 of 256, nothing spilled, where ladder_bwt itself spilled 15 and waited for each of its
+// 23 gathers (config 4: 7.14 against 7.18 - 7.23 ms, profiles/r06/ab_split_walk_and_base_prefetch.txt); at the register
+// limit the 48 registers of the entry in flight are spilled instead (k_base_scalarmul + 77, k_x448 + 44, k_ed448_sign + 39).
+template <class BITS, class BWT>
+GD_FN pt ladder_bwt_ahead(const BITS &bits, const BWT &bwt) {
+    const BwtGeom g = bwt.geom();
+    uint32_t idx;
+    bool neg;
+    signed_digit_bwt(window_bwt(bits, g.windows - 1, g.bits), g.bits, idx, neg);
+    pt acc = niels_to_pt(bwt.load(g, g.windows - 1, idx), neg);
+    signed_digit_bwt(window_bwt(bits, g.windows - 2, g.bits), g.bits, idx, neg);
+    niels next = bwt.load(g, g.windows - 2, idx);
+#pragma unroll 1
+    for (uint32_t i = g.windows - 1; i-- > 0;) {
+        const niels e = next;
+        const bool neg_e = neg;
+        if (i > 0) {
+            signed_digit_bwt(window_bwt(bits, i - 1, g.bits), g.bits, idx, neg);
+            next = bwt.load(g, i - 1, idx);
+        }
+        pt_add_niels(acc, e, neg_e, true);
+    }
+    return acc;
+}
 template <class BITS, class BWT>
 GD_FN pt ladder_bwt(const BITS &bits, const BWT &bwt) {
     const BwtGeom g = bwt.geom();
@@ -351,6 +376,8 @@ struct FixedComb {
         return ladder_comb(bits, comb);
     }
     template <class MK>
+    GD_MFN pt mul_ahead(const sc &s, MK &mk) const { return mul(s, mk); }
+    template <class MK>
     GD_MFN void add_to(pt &acc, const sc &s, MK &mk) const { acc = pt_add(acc, mul(s, mk), false); }
 };
 template <class BWT>
@@ -360,6 +387,11 @@ struct FixedBwt {
     GD_MFN pt mul(const sc &s, MK &mk) const {
         auto bits = mk(sc_recode_bwt(s, bwt), 0);
         return ladder_bwt(bits, bwt);
+    }
+    template <class MK>
+    GD_MFN pt mul_ahead(const sc &s, MK &mk) const {      // (public scalars, registers to spare: ladder_bwt_ahead)
+        auto bits = mk(sc_recode_bwt(s, bwt), 0);
+        return ladder_bwt_ahead(bits, bwt);
     }
     template <class MK>
     GD_MFN void add_to(pt &acc, const sc &s, MK &mk) const {
