@@ -40,7 +40,7 @@ constexpr int ML_SLOT_U4 = 8;   // the table-free variable-base ladder: denomina
 // the two-ladder kernels park the FIRST product of an operation in its slots (free once the chain has been popped) until
 // every input of the operation has been read: any output may then alias any input, as in the reference
 constexpr int ML_DUAL_SLOT_U4 = 16;     // point_dual_scalarmul: chain slot, later s2 * P (one point = 16 uint4)
-constexpr int ML_DOUBLE_SLOT_U4 = 24;   // point_double_scalarmul: two chain slots, later s2 * b2 | 1/(Y1 - Z1)
+constexpr int ML_DOUBLE_SLOT_U4 = 76;   // point_double_scalarmul: four chain slots | four numerators | p1 | a, b, c (varbase_bodies.hpp)
 constexpr int SHARED_INV_OPS_PER_LANE = 8;   // a launch covers at most this many operations per resident lane
 constexpr uint64_t MAX_MESSAGE_BYTES = 0x7fffff00ull;   // GOLDILOCKS_AMD_MAX_MESSAGE_BYTES: byte counters are 32-bit
 
@@ -562,7 +562,7 @@ GD_KERNEL k_double_scalarmul(uint64_t *out, const uint64_t *b1, const uint64_t *
                              uint4 *__restrict__ workspace, const uint4 *__restrict__ bwt);
 GD_KERNEL k_double_scalarmul_ct(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
                                    const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
-                                   uint4 *__restrict__ workspace);
+                                   uint4 *__restrict__ workspace, const uint64_t *__restrict__ point_base_abi);
 GD_KERNEL k_point_encode_eddsa_shared(uint8_t *__restrict__ enc, const uint64_t *__restrict__ pts, uint32_t n,
                                       uint4 *__restrict__ ws);
 GD_KERNEL k_build_comb_big(uint4 *__restrict__ dst, const uint4 *__restrict__ comb);

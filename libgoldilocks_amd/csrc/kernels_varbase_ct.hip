@@ -38,8 +38,8 @@ GD_KERNEL_2L k_point_dual_scalarmul_ct(uint64_t *out1, uint64_t *out2, const uin
 
 GD_KERNEL_2L k_double_scalarmul_ct(uint64_t *out, const uint64_t *b1, const uint64_t *__restrict__ s1,
                                 const uint64_t *b2, const uint64_t *__restrict__ s2, uint32_t n,
-                                uint4 *__restrict__ workspace) {
-    double_scalarmul_ladder_body(out, b1, s1, b2, s2, n, workspace);
+                                uint4 *__restrict__ workspace, const uint64_t *__restrict__ point_base_abi) {
+    double_scalarmul_ladder_body(out, b1, s1, b2, s2, n, workspace, point_base_abi);
 }
 
 }  // namespace gd

@@ -94,37 +94,12 @@ GD_FN void ml_step_sel_s(MlStateS &st, const smultiplier &m1, bool sw) {
     st.z2 = sfe_mul(sfe_add(caa, e), e);                                        // z2 = E (39081 AA + E)   2 x 1
 }
 
-// bits.word(k): k-th 32-bit word of the scalar, already reduced mod q (446 bits).
-// b: the base point; x1 = u(P) = (Y + Z)/(Y - Z) in affine form (anything if P is the identity or (0,-1)).
-template <class BITS>
-GD_FN pt ml_scalarmul_u(const pt &b, const fe &x1, const BITS &bits) {
+// R = the point with u(R) = X1 / Z1, given u(R + P) = X2 / Z2 and P = b with x1 = u(P) in affine form: the y-coordinate by
+// Okeya and Sakurai's formula, the result in extended coordinates (src/goldilocks.c has no counterpart: the reference
+// multiplies with tables).  Exceptional cases by selects: R trivial (the identity or (0, -1)) or P trivial: the identity;
+// R + P trivial: R = -P.
+GD_FN pt ml_recover(const pt &b, const fe &x1, const fe &X1, const fe &Z1, const fe &X2, const fe &Z2) {
     const fe yz = fe_add(b.y, b.z);                 // Y + Z                  mag 2
-    // the ladder's state lives in the signed, register-paired form of gf28s.hpp for all 446 steps
-    MlStateS st;
-    st.x2 = sfe_from_fe(fe_one());
-    st.z2 = sfe_from_fe(fe_zero());
-    st.x3 = sfe_from_fe(x1);
-    st.z3 = sfe_from_fe(fe_one());
-    const smultiplier m1 = s_multiplier(st.x3);     // x1's half sums are loop-invariant
-    bool swap = false;
-    // one read of the scalar per 32 steps: the word's next bit is kept in the sign position
-#pragma unroll 1
-    for (int wi = (ML_BITS - 1) >> 5; wi >= 0; wi--) {
-        const int top = wi == ((ML_BITS - 1) >> 5) ? ((ML_BITS - 1) & 31) : 31;
-        uint32_t w = bits.word(wi) << (31 - top);
-#pragma unroll 1
-        for (int j = top; j >= 0; j--) {
-            const bool k_t = (int32_t)w < 0;
-            w <<= 1;
-            const bool sw = swap != k_t;
-            swap = k_t;
-            ml_step_sel_s(st, m1, sw);
-        }
-    }
-    // (X1 : Z1) = u(sP), (X2 : Z2) = u((s+1)P), back in the unsigned form (mag 1)
-    const fe x2 = sfe_to_fe(st.x2), z2 = sfe_to_fe(st.z2), x3 = sfe_to_fe(st.x3), z3 = sfe_to_fe(st.z3);
-    const fe X1 = fe_select(x2, x3, swap), Z1 = fe_select(z2, z3, swap);
-    const fe X2 = fe_select(x3, x2, swap), Z2 = fe_select(z3, z2, swap);
     const bool q_trivial = fe_is_zero(X1) | fe_is_zero(Z1);     // '|', not '||': no branch on the scalar
     const bool qp_trivial = fe_is_zero(X2) | fe_is_zero(Z2);
     const bool base_trivial = fe_is_zero(b.x);
@@ -163,6 +138,39 @@ GD_FN pt ml_scalarmul_u(const pt &b, const fe &x1, const BITS &bits) {
     r.z = fe_select(r.z, id.z, ident);
     r.t = fe_select(r.t, id.t, ident);
     return r;
+}
+
+// bits.word(k): k-th 32-bit word of the scalar, already reduced mod q (446 bits).
+// b: the base point; x1 = u(P) = (Y + Z)/(Y - Z) in affine form (anything if P is the identity or (0,-1)).
+template <class BITS>
+GD_FN pt ml_scalarmul_u(const pt &b, const fe &x1, const BITS &bits) {
+    // the ladder's state lives in the signed, register-paired form of gf28s.hpp for all 446 steps
+    MlStateS st;
+    st.x2 = sfe_from_fe(fe_one());
+    st.z2 = sfe_from_fe(fe_zero());
+    st.x3 = sfe_from_fe(x1);
+    st.z3 = sfe_from_fe(fe_one());
+    const smultiplier m1 = s_multiplier(st.x3);     // x1's half sums are loop-invariant
+    bool swap = false;
+    // one read of the scalar per 32 steps: the word's next bit is kept in the sign position
+#pragma unroll 1
+    for (int wi = (ML_BITS - 1) >> 5; wi >= 0; wi--) {
+        const int top = wi == ((ML_BITS - 1) >> 5) ? ((ML_BITS - 1) & 31) : 31;
+        uint32_t w = bits.word(wi) << (31 - top);
+#pragma unroll 1
+        for (int j = top; j >= 0; j--) {
+            const bool k_t = (int32_t)w < 0;
+            w <<= 1;
+            const bool sw = swap != k_t;
+            swap = k_t;
+            ml_step_sel_s(st, m1, sw);
+        }
+    }
+    // (X1 : Z1) = u(sP), (X2 : Z2) = u((s+1)P), back in the unsigned form (mag 1)
+    const fe x2 = sfe_to_fe(st.x2), z2 = sfe_to_fe(st.z2), x3 = sfe_to_fe(st.x3), z3 = sfe_to_fe(st.z3);
+    const fe X1 = fe_select(x2, x3, swap), Z1 = fe_select(z2, z3, swap);
+    const fe X2 = fe_select(x3, x2, swap), Z2 = fe_select(z3, z2, swap);
+    return ml_recover(b, x1, X1, Z1, X2, Z2);
 }
 // ... given di = 1/(Y - Z) (anything if Y = Z): what a kernel that shares its inversions has at hand
 template <class BITS>

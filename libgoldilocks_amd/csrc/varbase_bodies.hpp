@@ -10,6 +10,7 @@
 #pragma once
 #include "kernels.hpp"
 #include "fixed_bodies.hpp"
+#include "montgomery2d.hpp"
 #include "montgomery.hpp"
 
 namespace gd {
@@ -195,46 +196,115 @@ __device__ __forceinline__ void point_dual_scalarmul_ladder_body(uint64_t *out1,
     lds_wipe_lane(s_bits + threadIdx.x, 15);
 }
 
-// combo[i] = s1[i]*b1[i] + s2[i]*b2[i], index-independent: two ladders and one addition; both denominators of an
-// operation go into the lane's chain.  ML_DOUBLE_SLOT_U4 uint4 of workspace per operation: the two chain slots, which --
-// popped -- hold s2 * b2, and 1/(Y1 - Z1) behind them.  out is written when both base points have been read: it may
-// alias either (the reference computes into temporaries, src/goldilocks.c:467-541).
+// combo[i] = s1[i]*b1[i] + s2[i]*b2[i], index-independent: ONE two-dimensional differential ladder (montgomery2d.hpp: a
+// doubling and two differential additions per bit instead of two ladders' two and two -- 0.82 x the instructions; until
+// round 6 this was two ladders and an addition).  First pass: the exceptional inputs are substituted (ml2_effective) and
+// the denominators of u(p1), u(p2), u(p1 + p2), u(p1 - p2) go into the lane's chain; one inversion per wave; second pass:
+// the four affine differences into LDS (pair-interleaved: both candidates of a selection are one 64-bit read), the
+// scalars and their control stream into the operation's workspace slot (read a word per 32 steps; wiped afterwards),
+// the chain, the recovery.  ML_DOUBLE_SLOT_U4 uint4 of workspace per operation: four chain slots | a, b, c.
+// out is written when both base points have been read for the last time: it may alias either (the reference computes
+// into temporaries, src/goldilocks.c:467-541).
+struct LdsDiffs {
+    uint32_t *mine;     // s_diff + 2 * threadIdx.x: word ((k * 16 + limb) * BLOCK + tid) * 2 + which
+    __device__ __forceinline__ void put(int k, int which, const fe &v) const {
+#pragma unroll
+        for (int i = 0; i < 16; i++) mine[((k * 16 + i) * BLOCK) * 2 + which] = v.v[i];
+    }
+    __device__ __forceinline__ sfp pair(int k, bool second) const {      // both read, one kept: no address depends on `second`
+        // (read HERE, every time: left to itself the compiler reads the 64 words once, ahead of the chain's loop, finds no
+        // registers for them and re-reads them from SCRATCH in every step -- 33 reads and 11 waits per step, round 6)
+        uint32_t at = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)mine;
+        asm volatile("" : "+v"(at));
+        sfp r;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const uint64_t both = *(const __attribute__((address_space(3))) uint64_t *)(uintptr_t)(at + 8u * (uint32_t)((k * 16 + i) * BLOCK));
+            r.v[i] = (int32_t)(second ? (uint32_t)(both >> 32) : (uint32_t)both);
+            asm("" : "+v"(r.v[i]));     // opaque, like sfe_from_fe: no zero-extended multiplicands
+        }
+        return r;
+    }
+};
+struct GlobalWords {    // a scalar's words in the operation's workspace slot
+    const uint32_t *p;
+    __device__ __forceinline__ uint32_t word(int k) const { return p[k]; }
+};
+__device__ __forceinline__ fe ml_u_numerator(const pt &b) { return fe_weak(fe_add(b.y, b.z)); }      // u = (Y + Z) / (Y - Z)
+// The operation's workspace slot (ML_DOUBLE_SLOT_U4 uint4): everything that depends on the POINTS is decided in the first
+// pass and parked, so that the second pass is the chain and little else (with the points' logic inlined there as well
+// the kernel spilled 1 400 registers):
+//   [0, 32)   four chain slots: the denominators Y - Z of p1, p2, p1 + p2, p1 - p2 (ml2_effective's points)
+//   [32, 48)  the numerators Y + Z of the same four
+//   [48, 64)  p1 (for the recovery)
+//   [64, 76)  the scalars a, b and -- second pass -- their control stream c: 3 x 14 words; wiped when the operation is done
+constexpr int ML2_NUM_AT = 4 * ML_SLOT_U4, ML2_P1_AT = ML2_NUM_AT + 16, ML2_WORDS_AT = ML2_P1_AT + 16;
+static_assert(ML2_WORDS_AT + 12 == ML_DOUBLE_SLOT_U4, "the slot's layout");
 __device__ __forceinline__ void double_scalarmul_ladder_body(uint64_t *out, const uint64_t *b1,
                                                              const uint64_t *__restrict__ s1, const uint64_t *b2,
                                                              const uint64_t *__restrict__ s2, uint32_t n,
-                                                             uint4 *__restrict__ workspace) {
-    __shared__ uint32_t s_bits[15 * BLOCK];
+                                                             uint4 *__restrict__ workspace,
+                                                             const uint64_t *__restrict__ point_base_abi) {
+    // the differences' 64 KiB double as the wave inversions' staging between the passes
+    __shared__ uint32_t s_diff[64 * BLOCK];
+    static_assert(64 * BLOCK >= (BLOCK / 64) * INV_WAVE_LDS_WORDS, "the inversions fit the differences' region");
     InvChain ch;
     ch.begin();
     for_each_op<true>(n, [&](uint32_t i, bool live) GD_LAMBDA_INLINE {
+        const Ml2Inputs in = ml2_effective(pt_load_abi(b1 + 32 * (size_t)i), pt_load_abi(b2 + 32 * (size_t)i),
+                                           sc_reduce(sc_load_abi(s1 + 7 * (size_t)i)), sc_reduce(sc_load_abi(s2 + 7 * (size_t)i)),
+                                           pt_load_abi(point_base_abi));
         uint4 *slot = workspace + (size_t)ML_DOUBLE_SLOT_U4 * i;
-        ch.push(slot, ml_denominator(pt_load_abi(b1 + 32 * (size_t)i)), live);
-        ch.push(slot + ML_SLOT_U4, ml_denominator(pt_load_abi(b2 + 32 * (size_t)i)), live);
-    });
-    __shared__ uint32_t s_inv[(BLOCK / 64) * INV_WAVE_LDS_WORDS];
-    ch.invert_wave(s_inv + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS, false);
-    // one copy of the ladder, walked twice (see point_dual_scalarmul_ladder_body): s2*b2 first -- its chain slot is
-    // the one pushed last -- parked in the operation's slots, then s1*b1 and the addition.
-    for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
-        uint4 *slot = workspace + (size_t)ML_DOUBLE_SLOT_U4 * i;
-        fe di = ch.pop(slot + ML_SLOT_U4);
-        fe_store(slot + 2 * ML_SLOT_U4, ch.pop(slot));
-#pragma unroll 1
-        for (int which = 1; which >= 0; which--) {
-            const pt b = pt_load_abi((which ? b2 : b1) + 32 * (size_t)i);
-            const uint64_t *k = (which ? s2 : s1) + 7 * (size_t)i;
-            LdsBits bits = lds_put_bits(s_bits + threadIdx.x, sc_reduce(sc_load_abi(k)));
-            pt r = ml_scalarmul(b, di, bits);
-            if (which) {
-                pt_store_u4(slot, r);
-                di = fe_load(slot + 2 * ML_SLOT_U4);
-            } else {
-                r = pt_add(r, pt_load_u4(slot), false);
-                pt_store_abi(out + 32 * (size_t)i, r);
+        const pt sum = pt_add(in.p1, in.p2, false), dif = pt_add(in.p1, in.p2, true);
+        if (live) {
+            fe_store(slot + ML2_NUM_AT, ml_u_numerator(in.p1));
+            fe_store(slot + ML2_NUM_AT + 4, ml_u_numerator(in.p2));
+            fe_store(slot + ML2_NUM_AT + 8, ml_u_numerator(sum));
+            fe_store(slot + ML2_NUM_AT + 12, ml_u_numerator(dif));
+            pt_store_u4(slot + ML2_P1_AT, in.p1);
+            uint32_t *words = reinterpret_cast<uint32_t *>(slot + ML2_WORDS_AT);
+#pragma unroll
+            for (int k = 0; k < 14; k++) {
+                words[k] = in.a.w[k];
+                words[14 + k] = in.b.w[k];
             }
         }
+        ch.push(slot, ml_denominator(in.p1), live);
+        ch.push(slot + ML_SLOT_U4, ml_denominator(in.p2), live);
+        ch.push(slot + 2 * ML_SLOT_U4, ml_denominator(sum), live);
+        ch.push(slot + 3 * ML_SLOT_U4, ml_denominator(dif), live);
     });
-    lds_wipe_lane(s_bits + threadIdx.x, 15);
+    __syncthreads();
+    ch.invert_wave(s_diff + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS, false);
+    __syncthreads();
+    const LdsDiffs diffs{s_diff + 2 * threadIdx.x};
+    for_each_op_reverse(n, [&](uint32_t i) GD_LAMBDA_INLINE {
+        uint4 *slot = workspace + (size_t)ML_DOUBLE_SLOT_U4 * i;
+        uint32_t *words = reinterpret_cast<uint32_t *>(slot + ML2_WORDS_AT);       // a | b | c, 14 words each
+        // the chain pops in the reverse order of its pushes
+        diffs.put(1, 1, fe_mul(fe_load(slot + ML2_NUM_AT + 12), ch.pop(slot + 3 * ML_SLOT_U4)));
+        diffs.put(1, 0, fe_mul(fe_load(slot + ML2_NUM_AT + 8), ch.pop(slot + 2 * ML_SLOT_U4)));
+        diffs.put(0, 1, fe_mul(fe_load(slot + ML2_NUM_AT + 4), ch.pop(slot + ML_SLOT_U4)));
+        const fe u1 = fe_mul(fe_load(slot + ML2_NUM_AT), ch.pop(slot));
+        diffs.put(0, 0, u1);
+        {
+            sc a, b;
+            uint32_t c[14];
+#pragma unroll
+            for (int k = 0; k < 14; k++) {
+                a.w[k] = words[k];
+                b.w[k] = words[14 + k];
+            }
+            ml2_control(c, a, b);
+#pragma unroll
+            for (int k = 0; k < 14; k++) words[28 + k] = c[k];
+        }
+        const GlobalWords wa{words}, wb{words + 14}, wc{words + 28};
+        const pt r = ml2_double_scalarmul_core(u1, wa, wb, wc, diffs, [&]() GD_LAMBDA_INLINE { return pt_load_u4(slot + ML2_P1_AT); });
+#pragma unroll
+        for (int k = 0; k < 42; k++) words[k] = 0;      // the scalars do not stay behind in the workspace
+        pt_store_abi(out + 32 * (size_t)i, r);
+    });
 }
 
 }  // namespace gd

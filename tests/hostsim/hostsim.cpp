@@ -11,6 +11,7 @@
 #include "../../libgoldilocks_amd/csrc/eddsa.hpp"
 #include "../../libgoldilocks_amd/csrc/x448.hpp"
 #include "../../libgoldilocks_amd/csrc/montgomery.hpp"
+#include "../../libgoldilocks_amd/csrc/montgomery2d.hpp"
 
 #include <string.h>
 
@@ -609,6 +610,38 @@ void hs_bwt_scalarmul(uint64_t *out, const uint64_t *comb_table, const uint64_t 
         b.w[14] = 0;
         pt_to_abi(out + 32 * j, ladder_bwt(b, bwt));
     }
+}
+
+// s1*b1 + s2*b2 through the two-dimensional differential ladder (montgomery2d.hpp), as the device's k_double_scalarmul_ct
+// runs it: substitution of exceptional inputs, the four affine differences, the control stream, the chain, the recovery.
+// g: the curve's base point.  Returns what ml2_effective decided (bit 0: a != s1, bit 1: b != s2, bit 2: p1 replaced,
+// bit 3: p2 replaced) so that the test can see its exceptional inputs take the substitution's paths.
+struct HostDiffs {
+    fe d[4];        // u(p1), u(p2), u(p1 + p2), u(p1 - p2)
+    sfp pair(int k, bool second) const { return sfe_from_fe(d[2 * k + (second ? 1 : 0)]); }
+};
+int hs_double_scalarmul_2d(uint64_t *out, const uint64_t *b1, const uint64_t *s1, const uint64_t *b2, const uint64_t *s2,
+                           const uint64_t *g) {
+    const pt P1 = pt_from_abi(b1), P2 = pt_from_abi(b2);
+    const sc k1 = sc_reduce(sc_from_abi(s1)), k2 = sc_reduce(sc_from_abi(s2));
+    const Ml2Inputs in = ml2_effective(P1, P2, k1, k2, pt_from_abi(g));
+    const pt sum = pt_add(in.p1, in.p2, false), dif = pt_add(in.p1, in.p2, true);
+    HostDiffs diffs;
+    const pt *four[4] = {&in.p1, &in.p2, &sum, &dif};
+    for (int k = 0; k < 4; k++) diffs.d[k] = fe_mul(fe_add(four[k]->y, four[k]->z), fe_invert(ml_denominator(*four[k])));
+    HostBits ba, bb, bc;
+    for (int i = 0; i < 14; i++) {
+        ba.w[i] = in.a.w[i];
+        bb.w[i] = in.b.w[i];
+    }
+    ba.w[14] = bb.w[14] = bc.w[14] = 0;
+    ml2_control(bc.w, in.a, in.b);
+    pt_to_abi(out, ml2_double_scalarmul(in.p1, diffs.d[0], ba, bb, bc, diffs));
+    int what = 0;
+    for (int i = 0; i < 14; i++) what |= (in.a.w[i] != k1.w[i] ? 1 : 0) | (in.b.w[i] != k2.w[i] ? 2 : 0);
+    what |= fe_eq(fe_mul(in.p1.x, P1.z), fe_mul(P1.x, in.p1.z)) && fe_eq(fe_mul(in.p1.y, P1.z), fe_mul(P1.y, in.p1.z)) ? 0 : 4;
+    what |= fe_eq(fe_mul(in.p2.x, P2.z), fe_mul(P2.x, in.p2.z)) && fe_eq(fe_mul(in.p2.y, P2.z), fe_mul(P2.y, in.p2.z)) ? 0 : 8;
+    return what;
 }
 
 void hs_point_from_hash(uint64_t *out, const uint8_t *hash, int uniform) {

@@ -501,3 +501,77 @@ def test_direct_scalarmul_through_the_ladder_and_its_base_point_fallback(H, O):
             r = O.orc_direct_scalarmul(want, base[i].ctypes.data, C.cast(s[i].ctypes.data, C.POINTER(Scalar)), allow_id, 0)
             r2 = H.hs_direct_scalarmul_ladder(got, base[i].ctypes.data_as(C.c_void_p), s[i].ctypes.data_as(C.c_void_p), allow_id)
             assert r == r2 and bytes(want) == bytes(got), (i, allow_id, r, r2)
+
+
+def test_two_dimensional_ladder_matches_oracle(H, O):
+    """montgomery2d.hpp: s1*P1 + s2*P2 on ONE chain of a doubling and two differential additions per bit (the table-free
+    counterpart of the reference's shared doubling chain, src/goldilocks.c:467-541), on the checker build: random points
+    and scalars; every pair of the scalars 0, 1, 2, q-1, 2^445 and the all-ones pattern; scalars >= q; and the exceptional
+    inputs its substitution exists for -- the identity and the 2-torsion point as either base, P2 = +-P1 (also with a
+    2-torsion component), either base equal to +-B or +-2B beside a trivial partner -- each of which must be seen to take
+    the substitution's path and still produce the oracle's group element."""
+    from _libs import Point
+    H.hs_double_scalarmul_2d.restype = C.c_int
+    g = np.frombuffer(bytes(O.orc_point_base().contents), np.uint64).copy()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def run(b1, s1, b2, s2):
+        out, what = np.empty((len(s1), 32), dtype=np.uint64), []
+        for i in range(len(s1)):
+            what.append(H.hs_double_scalarmul_2d(p(out[i]), p(b1[i]), p(s1[i]), p(b2[i]), p(s2[i]), p(g)))
+            assert H.hs_point_valid(p(out[i])) == -1, i
+        return out, what
+
+    def neg(pt):      # -P: X and T negated limb-wise mod p
+        o = pt.copy()
+        for fld in (0, 24):
+            v = sum(int(o[fld + k]) << (56 * k) for k in range(8)) % P
+            o[fld:fld + 8] = np.frombuffer(Gf.from_int((P - v) % P), np.uint64)
+        return o
+
+    def shift(pt):    # P + (0, -1) = (-x, -y): the same class
+        o = pt.copy()
+        for fld in (0, 8):
+            v = sum(int(o[fld + k]) << (56 * k) for k in range(8)) % P
+            o[fld:fld + 8] = np.frombuffer(Gf.from_int((P - v) % P), np.uint64)
+        return o
+
+    n = 48
+    b1 = _gen.oracle_fixed(O, _gen.stream_scalars(n, b"ml2/b1"))
+    b2 = _gen.oracle_fixed(O, _gen.stream_scalars(n, b"ml2/b2"))
+    s1, s2 = _gen.stream_scalars(n, b"ml2/s1"), _gen.stream_scalars(n, b"ml2/s2")
+    got, what = run(b1, s1, b2, s2)
+    assert (_gen.oracle_encode(got) == _gen.oracle_encode(_gen.oracle_double(O, b1, s1, b2, s2))).all() and not any(what)
+    # every pair of edge scalars on one pair of points
+    vals = [0, 1, 2, Q - 1, Q - 2, 2**445, 2**446 - 1 - Q, (Q - 1) // 2, int("01" * 223, 2), int("0011" * 111, 2)]
+    pairs = [(x, y) for x in vals for y in vals]
+    es1, es2 = _gen.scalars_from_ints([x for x, _ in pairs]), _gen.scalars_from_ints([y for _, y in pairs])
+    eb1, eb2 = np.repeat(b1[:1], len(pairs), axis=0), np.repeat(b2[:1], len(pairs), axis=0)
+    got, what = run(eb1, es1, eb2, es2)
+    assert (_gen.oracle_encode(got) == _gen.oracle_encode(_gen.oracle_double(O, eb1, es1, eb2, es2))).all() and not any(what)
+    # scalars that are not reduced (the entry point takes any 448-bit value)
+    raw = np.frombuffer(_gen.stream(b"ml2/raw", 56 * 8), np.uint64).reshape(8, 7).copy()
+    got, _ = run(b1[:8], raw, b2[:8], raw[::-1].copy())
+    assert (_gen.oracle_encode(got) == _gen.oracle_encode(_gen.oracle_double(O, b1[:8], raw, b2[:8], raw[::-1].copy()))).all()
+    # exceptional inputs: (P1, P2, what ml2_effective must report)
+    ident = np.zeros(32, np.uint64); ident[8] = 1; ident[16] = 1
+    t2 = ident.copy(); t2[8:16] = np.frombuffer(Gf.from_int(P - 1), np.uint64)
+    two_g = np.empty(32, np.uint64)
+    O.orc_point_double(C.cast(p(two_g), C.POINTER(Point)), C.cast(p(g), C.POINTER(Point)))
+    A, B_ = b1[3], b2[3]
+    cases = [(ident, B_, 1 | 4), (t2, B_, 1 | 4), (A, ident, 2 | 8), (A, t2, 2 | 8), (ident, t2, 1 | 2 | 4 | 8),
+             (A, A, 1 | 2 | 8), (A, neg(A), 1 | 2 | 8), (A, shift(A), 1 | 2 | 8), (shift(A), neg(A), 1 | 2 | 8),
+             (ident, g, 1 | 4), (ident, neg(g), 1 | 4), (ident, two_g, 1 | 4), (g, ident, 2 | 8), (two_g, t2, 2 | 8),
+             (g, g, 1 | 2 | 8), (two_g, neg(two_g), 1 | 2 | 8), (g, two_g, 0), (g, A, 0)]
+    cb1 = np.array([c[0] for c in cases]); cb2 = np.array([c[1] for c in cases])
+    cs1, cs2 = s1[:len(cases)].copy(), s2[:len(cases)].copy()
+    got, what = run(cb1, cs1, cb2, cs2)
+    assert (_gen.oracle_encode(got) == _gen.oracle_encode(_gen.oracle_double(O, cb1, cs1, cb2, cs2))).all()
+    for i, c in enumerate(cases):
+        assert what[i] & c[2] == c[2] and (c[2] != 0 or what[i] == 0), (i, what[i], c[2])
+    # ... and with the scalars that make the substituted sums degenerate: s1 + s2 = 0, s1 - s2 = 0
+    z1 = _gen.scalars_from_ints([5, 5, Q - 5, 7])
+    z2 = _gen.scalars_from_ints([Q - 5, 5, Q - 5, 0])
+    zb1 = np.array([A, A, A, A]); zb2 = np.array([A, neg(A), A, A])
+    got, _ = run(zb1, z1, zb2, z2)
+    assert (_gen.oracle_encode(got) == _gen.oracle_encode(_gen.oracle_double(O, zb1, z1, zb2, z2))).all()

@@ -356,7 +356,9 @@ class Audit:
             at, ap = combine(st.get(r) for r in base + off_regs)
             if at:
                 violate("address", "scalar load from a secret-dependent address", ap)
-            if base == ["s0", "s1"] and not off_regs and not ap:       # the kernarg segment
+            # the kernarg segment: s[0:1] at entry, or a copy of it (a kernel with many arguments moves the pointer aside
+            # before s0 is reused: the copy carries the provenance "kernarg")
+            if not off_regs and ((base == ["s0", "s1"] and not ap) or ap == frozenset(["kernarg"])):
                 imm = int(ops[2], 0) if len(ops) > 2 else 0
                 for k, r in enumerate(dst):
                     a = self.argument_of(imm + 4 * k)
@@ -557,6 +559,8 @@ class Audit:
             self.changed = False
             entry = [None] * n
             entry[0] = State()
+            entry[0].set("s0", (False, frozenset(["kernarg"])))
+            entry[0].set("s1", (False, frozenset(["kernarg"])))
             work = [0]
             while work:
                 i = work.pop()
@@ -661,6 +665,8 @@ def explain(kernel, line, reg=None, depth=40, exec_predication=True):
     n = len(a.ins)
     entry = [None] * n
     entry[0] = State()
+    entry[0].set("s0", (False, frozenset(["kernarg"])))
+    entry[0].set("s1", (False, frozenset(["kernarg"])))
     work = [0]
     while work:
         i = work.pop()
