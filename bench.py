@@ -594,6 +594,7 @@ class ClockSampler:
     def __init__(self, pci=None):
         import glob
         self.path, self.samples, self._stop, self._thread = None, [], False, None
+        # (a box shows every GPU of its host in sysfs, whichever one the process was given: the device is found by its PCI address)
         for f in sorted(glob.glob("/sys/class/drm/card*/device/pp_dpm_sclk")):
             real = os.path.realpath(os.path.dirname(f))
             if pci is None or pci.lower() in real.lower():
@@ -837,7 +838,7 @@ def run_rank(args):
     w = make_workload(name, cx, args.table_access)
     pci_of = torch.cuda.get_device_properties(torch.cuda.current_device())
     pci_txt = "%04x:%02x:%02x" % (getattr(pci_of, "pci_domain_id", 0), getattr(pci_of, "pci_bus_id", 0), getattr(pci_of, "pci_device_id", 0))
-    clock = ClockSampler(pci_txt if torch.cuda.device_count() > 1 else None)
+    clock = ClockSampler(pci_txt)
     mine, worst, kernel_ms = time_workload(torch, shard, w, args.steps, args.warmup, dist, backend, clock)
     if "kernels_after" in w:
         w["kernel"], w["traffic_kernels"], w["macs"] = w["kernels_after"]()
@@ -904,7 +905,7 @@ def run_rank(args):
             t_probe = max(time.perf_counter() - t_probe, 1e-4)
             cwarm = max(3, min(100, int(0.15 / t_probe)))
             csteps = 8 if t_probe > 0.02 else 12
-            cclock = ClockSampler(pci_txt if torch.cuda.device_count() > 1 else None)
+            cclock = ClockSampler(pci_txt)
             _, cworst, cms = time_workload(torch, shard, cw, csteps, cwarm, None, None, cclock)
             if "kernels_after" in cw:
                 cw["kernel"], cw["traffic_kernels"], cw["macs"] = cw["kernels_after"]()

@@ -572,7 +572,11 @@ def build_info():
     import hashlib
     with open(LIB_PATH, "rb") as f:
         digest = hashlib.sha256(f.read()).hexdigest()
-    return {"toolchain": lib().goldilocks_amd_build_info().decode(), "library_sha256": digest}
+    try:
+        toolchain = lib().goldilocks_amd_build_info().decode()
+    except AttributeError:      # an older library loaded as an A/B variant (GOLDILOCKS_AMD_LIB)
+        toolchain = None
+    return {"toolchain": toolchain, "library_sha256": digest}
 
 
 def device_info():

@@ -43,16 +43,21 @@ using namespace gd;
 #ifndef KC_XCD
 #define KC_XCD 0
 #endif
-#if KC_TEETH == 8
+#if KC_TEETH == 9
+using kc_plan = comb_xwide;     // 5 x 9 x 10: what 2^20 signatures of 2^10 keys run (BASELINE config 4)
+#elif KC_TEETH == 8
 using kc_plan = comb_wide;
 #else
 using kc_plan = comb_big;
 #endif
+#ifndef KC_BWT_BITS
+#define KC_BWT_BITS 20          // the library's default base table
+#endif
 static_assert(KC_MODE != 2 || KC_TEETH == 7, "only the 48-KiB comb fits LDS twice per CU");
 constexpr int NPH = 7;
-static const char *PHASE[NPH] = {"hash + scalar decoding", "the key's comb: doublings + adds", "28 base-point adds",
+static const char *PHASE[NPH] = {"hash + scalar decoding", "the key's comb: doublings + adds", "the base point's adds (one per digit)",
                                  "R's test (L, K, L^2 v == K^2 u)", "park + chain", "the lane's inversion", "second pass"};
-static const double MACS[NPH] = {0, (kc_plan::SPACING - 1) * 1312.0 + (kc_plan::SPACING * kc_plan::COMBS - 1) * 1344 + 576, 28 * 1344.0,
+static const double MACS[NPH] = {0, (kc_plan::SPACING - 1) * 1312.0 + (kc_plan::SPACING * kc_plan::COMBS - 1) * 1344 + 576, bwt_windows(KC_BWT_BITS) * 1344.0,
                                  3 * 136 + 8 * 192.0 + 16, 192, 63616.0 / 8, 3 * 192};
 
 // KC_MODE 1: lane 0's entry for the whole wave
@@ -90,7 +95,7 @@ extern "C" __global__ void __launch_bounds__(BLOCK, WAVES_PER_SIMD)
 k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const uint8_t *__restrict__ pk,
          const uint8_t *__restrict__ msgs, uint32_t msg_len, uint32_t n, const uint4 *__restrict__ bwt,
          const uint4 *__restrict__ combs, uint4 *__restrict__ park, unsigned long long *__restrict__ totals) {
-    __shared__ uint32_t s_bits[16 * BLOCK];
+    __shared__ uint32_t s_bits[VERIFY_LDS_WORDS * BLOCK];
 #if KC_MODE == 2
     __shared__ uint4 s_comb[KC_LDS_STRIDE * kc_plan::ENTRIES];
 #endif
@@ -136,9 +141,15 @@ k_phases(int32_t *__restrict__ status, const uint8_t *__restrict__ sig, const ui
         const sc challenge = sc_sub(sc_zero(), sc_decode_long_words<114>(w));
         load_bytes_as_words(w, m.a + 57, 57, 15);
         const sc response = sc_decode_long_words<57>(w);
+#if KC_MODE == 0      // the product's walk: digits transposed once, the next entry requested an addition ahead
+        auto dig = mkbits.template digits<kc_plan>(kc_plan::recode(challenge));
+        MARK(0);
+        pt P = ladder_comb_digits(dig, comb);
+#else
         auto bits = mkbits(kc_plan::recode(challenge), 0);
         MARK(0);
         pt P = ladder_comb(bits, comb);
+#endif
         MARK(1);
         fb.add_to(P, response, mkbits);
         MARK(2);
@@ -192,7 +203,7 @@ int main() {
     int32_t *status;
     uint4 *bwt, *combs, *park;
     unsigned long long *totals;
-    const uint32_t bwt_bits = 16;   // the table's digits (timing only: random entries behind a valid header)
+    const uint32_t bwt_bits = KC_BWT_BITS;   // the table's digits (timing only: random entries behind a valid header)
     const size_t bwt_bytes = ((size_t)bwt_entries(bwt_bits) * 12 + BWT_HEADER_U4) * sizeof(uint4), comb_bytes = (size_t)nkeys * kc_plan::ENTRIES * 12 * sizeof(uint4);
     CHECK(hipMalloc(&sig, 114 * (size_t)n));
     CHECK(hipMalloc(&pk, 57 * (size_t)n));

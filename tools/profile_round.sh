@@ -7,7 +7,7 @@
 # committed are written to gpurun_out/profiles_<round>/ by tools/summarize_prof.py (copy them to
 # profiles/<round>/).  The program after `--` is always python3 itself (no env/bash hop).
 set -u
-ROUND=${1:-r05}
+ROUND=${1:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof
 DST=$ROOT/gpurun_out/profiles_$ROUND
@@ -80,8 +80,8 @@ for o in sequential scattered; do for s in none memcpy; do "$ROOT/tools/hostfeed
 "$ROOT/tools/fieldbench" > "$DST/fieldbench.txt" 2>&1
 "$ROOT/tools/stepbench" > "$DST/stepbench.txt" 2>&1
 "$ROOT/tools/fp64gate" > "$DST/fp64gate.txt" 2>&1
-"$ROOT/tools/verifyphases" > "$DST/verifyphases.txt" 2>&1
-"$ROOT/tools/keycombphases_t8m0x1" > "$DST/keycombphases.txt" 2>&1   # 8 teeth, XCD-aware positions: the product's geometry for config 4
+[ -x "$ROOT/tools/verifyphases" ] && "$ROOT/tools/verifyphases" > "$DST/verifyphases.txt" 2>&1
+"$ROOT/tools/keycombphases" > "$DST/keycombphases.txt" 2>&1   # 9 teeth, 20-bit base table, XCD-aware positions: the product's geometry for config 4
 python3 "$ROOT/tools/probes/batch_sweep.py" > "$DST/batch_sweep.txt" 2>&1
 python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$DST"
 ls -la "$DST"
