@@ -318,9 +318,14 @@ def make_workload(name, cx, access):
         tag = {7: "", 8: "_wide", 9: "_xwide"}[teeth]
         V = WORKLOADS["verify"]
         macs = V["macs_key_comb" + tag] + V["macs_per_key_comb" + tag] * V["keys"] // n
-        return main, (main, "k_ed448_verify_keycomb_finish", "k_verify_base_part"), macs
+        return main, (main,) + VERIFY_STEP_KERNELS, macs
     return dict(step=step, kernel="k_ed448_verify_keycomb_xwide", check=check, sample=sample, kernels_after=kernels_after,
-                traffic_kernels=("k_ed448_verify_keycomb_xwide", "k_ed448_verify_keycomb_finish", "k_verify_base_part"))
+                traffic_kernels=("k_ed448_verify_keycomb_xwide",) + VERIFY_STEP_KERNELS)
+
+
+# the kernels of a key-comb verification step besides its main one (their traffic and instructions are summed into the
+# step's: until round 6 the keys' preparation -- teeth, comb entries, the hash set -- was left out of the sum)
+VERIFY_STEP_KERNELS = ("k_ed448_verify_keycomb_finish", "k_verify_base_part", "k_verify_key_teeth", "k_verify_key_combs", "k_verify_dedupe")
 
 
 def verify_inputs(cx, distinct=False):
