@@ -398,10 +398,9 @@ constexpr int KEY_COMBS_MAX = 1 << 17;     // the most keys of a batch that can 
 constexpr int KEY_COMBS_MIN_BATCH = 4096;   // combs are considered from so many signatures on (up to there a wave verifies each signature, section 7a)
 constexpr int KEY_SORT_BINS = 8192;        // up to so many keys the counting sort goes through per-block bins in LDS
 constexpr int KEY_TEETH_BY_WAVE_MAX = 4096;   // up to so many keys a WAVE computes a key's teeth (latency), beyond a lane (throughput)
-// the fewest entries of a key's comb that one lane of k_verify_key_combs builds and normalises with one shared inversion
-// (the kernel doubles it while the keys are too many for one wave per SIMD).  2^20 signatures of 2^10 keys, whole
-// step, alternating on one box: 32 entries per lane 8.25 - 8.28 ms, 16: 8.04 - 8.06, 8: 7.98 - 8.00
-// (profiles/r04/experiments.md H)
+// the fewest entries of a key's comb that one lane of k_verify_key_combs builds and normalises with one shared inversion,
+// the most, and the share of the resident lanes that its segments may be (kernels_verify.hip key_comb_segment picks
+// the length on the device from the number of keys; profiles/r04/experiments.md H, profiles/r06/combsphases.txt)
 #ifndef GD_KEY_COMB_SEG
 #define GD_KEY_COMB_SEG 8
 #endif
@@ -409,7 +408,6 @@ constexpr int KEY_TEETH_BY_WAVE_MAX = 4096;   // up to so many keys a WAVE compu
 #define GD_KEY_COMB_SEG_MAX 64
 #endif
 constexpr int KEY_COMB_SEG = GD_KEY_COMB_SEG, KEY_COMB_SEG_MAX = GD_KEY_COMB_SEG_MAX;   // (a comb of 7 teeth has 64 entries)
-// ... doubled while the segments would be more than KEY_COMB_OCC_NUM / KEY_COMB_OCC_DEN of the resident lanes
 #ifndef GD_KEY_COMB_OCC_NUM
 #define GD_KEY_COMB_OCC_NUM 1
 #endif
@@ -417,8 +415,7 @@ constexpr int KEY_COMB_SEG = GD_KEY_COMB_SEG, KEY_COMB_SEG_MAX = GD_KEY_COMB_SEG
 #define GD_KEY_COMB_OCC_DEN 2
 #endif
 constexpr uint32_t KEY_COMB_OCC_NUM = GD_KEY_COMB_OCC_NUM, KEY_COMB_OCC_DEN = GD_KEY_COMB_OCC_DEN;
-static_assert(KEY_COMB_SEG >= 1 && KEY_COMB_SEG <= KEY_COMB_SEG_MAX && KEY_COMB_SEG_MAX <= 64 &&
-              (KEY_COMB_SEG & (KEY_COMB_SEG - 1)) == 0 && (KEY_COMB_SEG_MAX & (KEY_COMB_SEG_MAX - 1)) == 0, "segments divide a comb");
+static_assert(KEY_COMB_SEG >= 1 && KEY_COMB_SEG <= KEY_COMB_SEG_MAX && KEY_COMB_SEG_MAX <= 64, "a comb of 7 teeth has 64 entries");
 constexpr int KEYCOMB_SLOT_U4 = 16;   // what a verification parks until its lane's shared inversion (kernels_verify.hip)
 // the launches of one group of key-comb verifications (one shared inversion per lane over all of them): where each
 // launch's positions start, relative to the group's, and how many they are
@@ -603,7 +600,7 @@ GD_KERNEL k_ed448_verify_keycomb(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                                  uint4 *__restrict__ park, const uint32_t *__restrict__ order,
                                  uint4 *__restrict__ chain_state, uint32_t resume,
-                                 const uint4 *__restrict__ qpark, uint32_t q_count);
+                                 const uint4 *__restrict__ qpark, uint32_t q_count, int32_t *__restrict__ finish_status);
 GD_KERNEL k_ed448_verify_keycomb_wide(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
@@ -613,7 +610,7 @@ GD_KERNEL k_ed448_verify_keycomb_wide(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                                  uint4 *__restrict__ park, const uint32_t *__restrict__ order,
                                  uint4 *__restrict__ chain_state, uint32_t resume,
-                                 const uint4 *__restrict__ qpark, uint32_t q_count);
+                                 const uint4 *__restrict__ qpark, uint32_t q_count, int32_t *__restrict__ finish_status);
 GD_KERNEL k_ed448_verify_keycomb_xwide(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ pk, const uint8_t *__restrict__ msgs,
                                  const uint64_t *__restrict__ msg_offsets, uint32_t msg_len, uint32_t prehashed,
@@ -623,7 +620,7 @@ GD_KERNEL k_ed448_verify_keycomb_xwide(const uint8_t *__restrict__ sig,
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                                  uint4 *__restrict__ park, const uint32_t *__restrict__ order,
                                  uint4 *__restrict__ chain_state, uint32_t resume,
-                                 const uint4 *__restrict__ qpark, uint32_t q_count);
+                                 const uint4 *__restrict__ qpark, uint32_t q_count, int32_t *__restrict__ finish_status);
 GD_KERNEL k_verify_base_part(uint4 *__restrict__ qpark, const uint8_t *__restrict__ sig, const uint32_t *__restrict__ order,
                              uint32_t q_count, const uint4 *__restrict__ bwt, const uint32_t *__restrict__ ctrl);
 GD_KERNEL k_ed448_verify_keycomb_finish(int32_t *__restrict__ status, const uint32_t *__restrict__ ctrl,

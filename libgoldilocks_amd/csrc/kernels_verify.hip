@@ -121,8 +121,8 @@ GD_KERNEL k_verify_key_tables(uint4 *__restrict__ pool, uint8_t *__restrict__ ke
 // call's capacity (2^15 by default, KEY_COMBS_MAX at most).
 //   k_verify_key_teeth     (kernels_wave.hip) wave k: decode key k, teeth 2^(16 m) * A_k, m < 28, by row arithmetic;
 //                          k_verify_key_teeth_lanes: a lane per key instead, when the keys are many
-//   k_verify_key_combs     a lane walks KEY_COMB_SEG (8) entries of one comb in Gray-code order (one addition of a
-//                          doubled tooth per entry) and normalises them with one shared inversion
+//   k_verify_key_combs     a lane walks a segment of one comb's entries in Gray-code order (one addition of a doubled
+//                          tooth per entry) and a wave normalises its segments with one shared inversion (key_combs.hpp)
 //   k_verify_key_count / _scan / _scatter   the signatures in the order of their keys (below)
 //   k_ed448_verify_keycomb the verification itself, two passes around the lane's shared inversion
 // The teeth of MANY keys (more than KEY_TEETH_BY_WAVE_MAX): a lane per key.  One lane's chain of 432 doublings takes
@@ -151,24 +151,34 @@ GD_KERNEL k_verify_key_teeth_lanes(uint4 *__restrict__ teeth, uint8_t *__restric
     }
 }
 // Entry 64 j + idx of a key's comb is T_(6+7j) + sum_{k<6} (+-) T_(k+7j), + iff bit k of idx.  A lane owns a SEGMENT of
-// SEG consecutive Gray codes of one comb of one key: its first entry is the signed sum of 7 teeth (6 additions), each
-// further one differs from its predecessor in one sign, i.e. by (+-) 2 T_k (1 addition) -- SEG + 5 additions for SEG
-// entries instead of 6 SEG -- and the SEG share one inversion (Montgomery's trick along the lane).
-// SEG is chosen on the device from the number of keys: few keys leave the device idle and the kernel is one lane's
-// LATENCY, which a short segment shortens (KEY_COMB_SEG = 8 entries: 13 additions and a 446-squaring inversion); many
-// keys make it a matter of THROUGHPUT, and a lane's inversion is shared by as many entries as one comb allows (up to
-// 64: 6 % of the work per entry that segments of 8 cost).  The smallest power of two from KEY_COMB_SEG on that leaves
-// at most one wave per SIMD.
+// SEG consecutive Gray codes of one comb of one key (the comb's last segment may be shorter): its first entry is the signed
+// sum of 7 teeth (6 additions), each further one differs from its predecessor in one sign, i.e. by (+-) 2 T_k (1 addition)
+// -- SEG + 5 additions for SEG entries instead of 6 SEG -- and the SEG share one inversion (one per wave, inv_wave.hpp).
+// SEG is chosen on the device from the number of keys.  Few keys leave the device idle and the kernel is one wave's
+// LATENCY (a lone wave issues an instruction every 7 cycles; tools/combsphases: 17 K cycles per addition, 330 K per
+// inversion, 18 K per entry of the second pass), which short segments shorten as long as every segment's wave finds a
+// SIMD at once: k_verify_base_part's persistent blocks hold one of a SIMD's two 256-register slots, so the segments are
+// as short as leaves at most KEY_COMB_OCC_NUM / KEY_COMB_OCC_DEN = one wave per SIMD (2^10 keys of 5 x 256 entries: 12
+// segments of 22 per comb, 960 waves: alone on the device 0.57 ms against 0.66 with 32 and 0.85 with 16, which needs a
+// second round on some SIMDs).  Many keys make it a matter of THROUGHPUT, and a wave's inversion is shared by as many
+// entries as KEY_COMB_SEG_MAX allows.
 // The entries wait unnormalised in their own slots of the comb; chain: 8 uint4 per (key, entry) for the trick.
+__host__ __device__ inline uint32_t key_comb_segment(uint32_t combed, uint32_t teeth_per, uint32_t resident_lanes) {
+    const uint32_t per_comb = 1u << (teeth_per - 1), combs = combed * key_comb_combs(teeth_per);
+    uint64_t room = (uint64_t)resident_lanes * KEY_COMB_OCC_NUM / ((uint64_t)KEY_COMB_OCC_DEN * combs);   // segments per comb
+    if (room > per_comb / (uint32_t)KEY_COMB_SEG) room = per_comb / (uint32_t)KEY_COMB_SEG;
+    if (room < 1) room = 1;
+    const uint32_t seg = (per_comb + (uint32_t)room - 1) / (uint32_t)room;
+    return seg > (uint32_t)KEY_COMB_SEG_MAX ? (uint32_t)KEY_COMB_SEG_MAX : seg;
+}
 GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict__ teeth, const uint32_t *__restrict__ ctrl,
                              uint4 *__restrict__ chain) {
     if (!ctrl[2]) return;                           // (ctrl[3] is 0 then: no geometry to derive)
     const uint32_t teeth_per = ctrl[3], NT = key_comb_combs(teeth_per) * teeth_per, per_comb = 1u << (teeth_per - 1),
                    entries = key_comb_entries(teeth_per);
     const uint32_t combed = ctrl[2], stride = gridDim.x * BLOCK;
-    uint32_t SEG = (uint32_t)KEY_COMB_SEG;
-    while (SEG < (uint32_t)KEY_COMB_SEG_MAX && (uint64_t)combed * (entries / SEG) * KEY_COMB_OCC_DEN > (uint64_t)stride * KEY_COMB_OCC_NUM) SEG *= 2;
-    const uint32_t per_key = entries / SEG, total = combed * per_key;
+    const uint32_t SEG = key_comb_segment(combed, teeth_per, stride), segs = (per_comb + SEG - 1) / SEG;
+    const uint32_t per_key = key_comb_combs(teeth_per) * segs, total = combed * per_key;
     // wave-uniform rounds: the segments' shared inversions are ONE inversion per wave (inv_wave.hpp) -- an exponentiation
     // was two thirds of this kernel's instructions (95 K against 21 additions' 51 K per segment of 16)
     __shared__ uint32_t s_inv[(BLOCK / 64) * INV_WAVE_LDS_WORDS];
@@ -176,7 +186,8 @@ GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict_
     for (uint32_t t0 = blockIdx.x * BLOCK + threadIdx.x; t0 - (threadIdx.x & 63u) < total; t0 += stride) {
         const bool live = t0 < total;
         const uint32_t t = live ? t0 : total - 1;       // (a lane beyond the end repeats the last segment and stores nothing)
-        const uint32_t k = t / per_key, j = (t % per_key) / (per_comb / SEG), g0 = (t % (per_comb / SEG)) * SEG;
+        const uint32_t k = t / per_key, j = (t % per_key) / segs, g0 = (t % segs) * SEG;
+        const uint32_t cnt = per_comb - g0 < SEG ? per_comb - g0 : SEG;
         const TeethAt tooth{teeth + (size_t)KEY_TEETH_U4 * k}, twice{teeth + (size_t)KEY_TEETH_U4 * k + 16 * NT};
         uint4 *const comb = combs + (size_t)key_comb_u4(teeth_per) * k + 12 * per_comb * j;
         uint4 *const slots = chain + ((size_t)entries * k + per_comb * j) * 8;
@@ -190,21 +201,26 @@ GD_KERNEL k_verify_key_combs(uint4 *__restrict__ combs, const uint4 *__restrict_
 #pragma unroll 1
         for (uint32_t s = 0;; s++) {
             uint4 *q = comb + 12 * idx;
+            // the next step's doubled tooth is requested BEFORE this entry's 20 scattered stores: memory operations return
+            // in order, and behind them the load would wait for their acknowledgements
+            const bool more = s + 1 < cnt;
+            const uint32_t b = more ? (uint32_t)__builtin_ctz(g0 + s + 1) : 0u;     // the Gray bit that flips
+            const pniels step = twice.load(b + teeth_per * j);
+            gd_keep_order();
             if (live) {
                 fe_store(q, fe_weak(fe_sub<2>(p.y, p.x)));
                 fe_store(q + 4, fe_weak(fe_add(p.x, p.y)));
                 fe_store(q + 8, fe_mulw(p.t, TWO_EFF_D));
             }
             ch.push(slots + 8 * idx, fe_add(p.z, p.z), live);
-            if (s + 1 == SEG) break;
-            const uint32_t g = g0 + s + 1, b = (uint32_t)__builtin_ctz(g);     // the Gray bit that flips
+            if (!more) break;
             idx ^= 1u << b;
-            pt_add_pniels(p, twice.load(b + teeth_per * j), ((idx >> b) & 1u) == 0, true);
+            pt_add_pniels(p, step, ((idx >> b) & 1u) == 0, true);
         }
         ch.invert_wave(inv_region, false);
         if (!live) continue;
 #pragma unroll 1
-        for (uint32_t s = SEG; s-- > 0;) {
+        for (uint32_t s = cnt; s-- > 0;) {
             const fe zi = ch.pop(slots + 8 * idx);
             uint4 *q = comb + 12 * idx;
             fe_store(q, fe_mul(fe_load(q), zi));
@@ -337,8 +353,9 @@ __device__ __forceinline__ void verify_keycomb_body(const uint8_t *__restrict__ 
                                  const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl,
                                  uint4 *__restrict__ park, const uint32_t *__restrict__ order,
                                  uint4 *__restrict__ chain_state, uint32_t resume,
-                                 const uint4 *__restrict__ qpark, uint32_t q_count) {
+                                 const uint4 *__restrict__ qpark, uint32_t q_count, int32_t *__restrict__ finish_status) {
     __shared__ uint32_t s_bits[VERIFY_LDS_WORDS * BLOCK];
+    __shared__ uint32_t s_inv[(BLOCK / 64) * INV_WAVE_LDS_WORDS];   // (the inline finish: a region of the wave's own, the block's other waves may still be hashing)
     if (ctrl[3] != (uint32_t)PLAN::TEETH) return;   // this batch's keys are served otherwise (k_ed448_verify, or the other comb)
     GlobalBwt bwt_tab{bwt};
     FixedBwt<GlobalBwt> b_tab{bwt_tab};
@@ -372,7 +389,27 @@ __device__ __forceinline__ void verify_keycomb_body(const uint8_t *__restrict__ 
         }
         ch.push(slot, pend.K, live);
     }
-    fe_store(state, ch.acc);
+    if (!finish_status) {
+        fe_store(state, ch.acc);
+        return;
+    }
+    // The group is this one launch (a device-resident batch): the wave inverts and walks back here instead of in
+    // k_ed448_verify_keycomb_finish -- the inversion is 42 K dependent instructions per wave, which a kernel of its own
+    // runs on an otherwise idle device (0.24 ms per 2^20) and this one beside the waves that are still verifying.
+    ch.acc = wave_shared_invert(ch.acc, s_inv + (threadIdx.x >> 6) * INV_WAVE_LDS_WORDS);
+    if (lane >= n) return;
+    for (uint32_t pos = lane + (n - 1 - lane) / stride * stride;; pos -= stride) {
+        const uint4 *slot = park + (size_t)KEYCOMB_SLOT_U4 * pos;
+        const fe inv_k = ch.pop(slot);
+        const uint4 flags = slot[12];
+        KeycombPending pend;
+        pend.L = fe_load(slot + 8);
+        pend.ok = flags.x != 0;
+        pend.sign = flags.y != 0;
+        pend.decided = flags.z != 0;
+        finish_status[order[pos]] = ed448_verify_keycomb_finish(pend, inv_k) ? -1 : 0;
+        if (pos < stride) break;
+    }
 }
 
 #define KEYCOMB_ARGS                                                                                                      \
@@ -382,18 +419,18 @@ __device__ __forceinline__ void verify_keycomb_body(const uint8_t *__restrict__ 
         const uint32_t *__restrict__ rep, const uint32_t *__restrict__ slot_of, const uint4 *__restrict__ combs,          \
         const uint8_t *__restrict__ key_ok, const uint32_t *__restrict__ ctrl, uint4 *__restrict__ park,                  \
         const uint32_t *__restrict__ order, uint4 *__restrict__ chain_state, uint32_t resume,                            \
-        const uint4 *__restrict__ qpark, uint32_t q_count
+        const uint4 *__restrict__ qpark, uint32_t q_count, int32_t *__restrict__ finish_status
 GD_KERNEL k_ed448_verify_keycomb(KEYCOMB_ARGS) {        // keys with 7 teeth per comb (4 x 7 x 16)
     verify_keycomb_body<comb_big>(sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
-                                  key_ok, ctrl, park, order, chain_state, resume, qpark, q_count);
+                                  key_ok, ctrl, park, order, chain_state, resume, qpark, q_count, finish_status);
 }
 GD_KERNEL k_ed448_verify_keycomb_xwide(KEYCOMB_ARGS) {  // keys with 9 (5 x 9 x 10): a thousand signatures per key
     verify_keycomb_body<comb_xwide>(sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
-                                    key_ok, ctrl, park, order, chain_state, resume, qpark, q_count);
+                                    key_ok, ctrl, park, order, chain_state, resume, qpark, q_count, finish_status);
 }
 GD_KERNEL k_ed448_verify_keycomb_wide(KEYCOMB_ARGS) {   // keys with 8 (4 x 8 x 14): hundreds of signatures per key
     verify_keycomb_body<comb_wide>(sig, pk, msgs, msg_offsets, msg_len, prehashed, ctx, ctx_len, n, bwt, rep, slot_of, combs,
-                                   key_ok, ctrl, park, order, chain_state, resume, qpark, q_count);
+                                   key_ok, ctrl, park, order, chain_state, resume, qpark, q_count, finish_status);
 }
 #undef KEYCOMB_ARGS
 // the lanes' inversions and the second pass over every launch of the group, last launch first: chunks.lo[c] is where

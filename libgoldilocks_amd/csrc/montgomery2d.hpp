@@ -19,7 +19,7 @@
 //   against the 10 M + 8 S + 2 of two ladders.  Which mixed corner is kept is not free: the corner that is dropped must
 //   never be the one the next doubling needs, which fixes it from the LOWER bits: the dropped corner at a level is the
 //   complement of the most recent lower bit pair of the other parity class (derivation and an integer model of the
-//   whole chain: docs/history/r06.md; tests/test_hostsim.py runs the chain against the oracle).  That control stream
+//   whole chain: docs/history/r06.md; tests/hostsim runs the chain on the host, against the CPU restatement).  That control stream
 //   c -- one bit per level -- is computed from the bottom in a pre-pass (ml2_control); like the scalars' own bits it
 //   only ever feeds selections.
 //

@@ -521,6 +521,46 @@ def test_config5_share_of_one_gpu_in_one_launch(ga, O, log2n):
     assert (st[pick_d].cpu().numpy() == want).all() and (want == 0).sum() >= 50
 
 
+@pytest.mark.parametrize("log2n,nk,teeth", [(19, 500, 9), (19, 1500, 8), (18, 3000, 7)])
+def test_key_combs_built_in_ragged_segments(ga, O, log2n, nk, teeth):
+    """k_verify_key_combs cuts a comb's Gray-code walk into segments whose length follows the number of keys
+    (kernels_verify.hip key_comb_segment): lengths that do not divide the comb leave a shorter last segment.  Key counts
+    that give such lengths for each comb geometry -- 500 keys of 9 teeth: 26 segments of 10 and one of 6 per comb; 1 500
+    keys of 8 teeth: 13, last 11; 3 000 keys of 7 teeth: 13, last 12 -- every verdict exact, a sample against the oracle."""
+    import torch
+    n = 1 << log2n
+    sk = torch.from_numpy(np.frombuffer(_gen.stream(b"ragged/sk%d" % nk, 57 * nk), np.uint8).reshape(nk, 57).copy()).cuda()
+    idx = torch.arange(n, device="cuda")
+    d_sk = sk[idx % nk].contiguous()
+    d_msg = torch.from_numpy(np.frombuffer(_gen.stream(b"ragged/msg", 32 * 4096), np.uint8).reshape(4096, 32)[np.arange(n) % 4096].copy()).cuda()
+    for b in range(3):
+        d_msg[:, b] = ((idx >> (8 * b)) & 0xff).to(torch.uint8)
+    d_pk = torch.empty((n, 57), dtype=torch.uint8, device="cuda")
+    d_sig = torch.empty((n, 114), dtype=torch.uint8, device="cuda")
+    ga.dev("ed448_derive_public_key", d_pk.data_ptr(), d_sk.data_ptr(), n, None)
+    ga.dev("ed448_sign", d_sig.data_ptr(), d_sk.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(), None, 32, 0, None, 0, n, None)
+    bad = (idx % 10) == 7
+    kind = (idx // 10) % 3
+    d_sig[bad & (kind == 0), 70] ^= 2       # S
+    d_sig[bad & (kind == 1), 8] ^= 0x10     # R
+    d_msg[bad & (kind == 2), 30] ^= 1       # the message
+    st = torch.full((n,), 7, dtype=torch.int32, device="cuda")
+    ga.dev("ed448_verify", st.data_ptr(), d_sig.data_ptr(), d_pk.data_ptr(), d_msg.data_ptr(), None, 32, 0, None, 0, n, None)
+    torch.cuda.synchronize()
+    assert ga.last_verify_key_counts() == (nk, 0, nk)
+    # the geometry this batch gets (k_verify_key_mode) and the segment length that follows from it
+    per_key = n // nk
+    assert teeth == (9 if nk * 1024 * (2 if nk > 1024 else 1) <= n else 8 if nk * 256 <= n else 7)
+    combs, per_comb = nk * (5 if teeth == 9 else 4), 1 << (teeth - 1)
+    room = max(1, min(per_comb // 8, 131072 // (2 * combs)))
+    assert per_comb % -(-per_comb // room) != 0, "this case is meant to leave a shorter last segment"
+    assert bool(((st == -1) == ~bad).all()), per_key
+    pick = np.unique(np.concatenate([np.random.default_rng(nk).integers(0, n, 64), 10 * np.random.default_rng(nk + 1).integers(0, n // 10, 32) + 7]))
+    pick_d = torch.from_numpy(pick).cuda()
+    want = _gen.oracle_verify(O, d_sig[pick_d].cpu().numpy(), d_pk[pick_d].cpu().numpy(), [m.tobytes() for m in d_msg[pick_d].cpu().numpy()])
+    assert (st[pick_d].cpu().numpy() == want).all() and (want == 0).sum() >= 30
+
+
 def test_verification_shares_the_tables_of_repeated_keys(ga, O):
     """For large batches the verification kernel decodes every DISTINCT public key once and builds its window table
     once (goldilocks_amd_set_verify_key_pool; kernels_verify.hip), or -- keys that sign many signatures each -- a

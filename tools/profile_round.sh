@@ -80,6 +80,7 @@ for o in sequential scattered; do for s in none memcpy; do "$ROOT/tools/hostfeed
 "$ROOT/tools/fieldbench" > "$DST/fieldbench.txt" 2>&1
 "$ROOT/tools/stepbench" > "$DST/stepbench.txt" 2>&1
 "$ROOT/tools/fp64gate" > "$DST/fp64gate.txt" 2>&1
+[ -x "$ROOT/tools/combsphases" ] && "$ROOT/tools/combsphases" > "$DST/combsphases.txt" 2>&1
 [ -x "$ROOT/tools/verifyphases" ] && "$ROOT/tools/verifyphases" > "$DST/verifyphases.txt" 2>&1
 "$ROOT/tools/keycombphases" > "$DST/keycombphases.txt" 2>&1   # 9 teeth, 20-bit base table, XCD-aware positions: the product's geometry for config 4
 python3 "$ROOT/tools/probes/batch_sweep.py" > "$DST/batch_sweep.txt" 2>&1
