@@ -324,8 +324,9 @@ def make_workload(name, cx, access):
 
 
 # the kernels of a key-comb verification step besides its main one (their traffic and instructions are summed into the
-# step's: until round 6 the keys' preparation -- teeth, comb entries, the hash set -- was left out of the sum)
-VERIFY_STEP_KERNELS = ("k_ed448_verify_keycomb_finish", "k_verify_base_part", "k_verify_key_teeth", "k_verify_key_combs", "k_verify_dedupe")
+# step's: until round 6 the keys' preparation -- teeth, comb entries, the hash set -- was left out of the sum; the main
+# kernel of a device-resident batch finishes its own positions, k_ed448_verify_keycomb_finish is the host-array pipeline's)
+VERIFY_STEP_KERNELS = ("k_verify_base_part", "k_verify_key_teeth", "k_verify_key_combs", "k_verify_dedupe")
 
 
 def verify_inputs(cx, distinct=False):

@@ -18,8 +18,7 @@ BENCH="$ROOT/bench.py"
 FAST="--table-access fast"            # the opt-in for public scalars; bench.py's default is the library's (index-independent)
 Q="--no-cpu-baseline --no-configs --no-end-to-end"
 
-# the driver's command: headline + configs + cpu_baseline on one line
-python3 "$BENCH" > "$DST/bench_default.json" 2> "$OUT/bench_default.err"
+# the driver's command: headline + configs + cpu_baseline on one line (written at the end, with this library's counters)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_default" -- \
     python3 "$BENCH" --steps 5 --warmup 1 > "$OUT/stats_default.log" 2>&1
 # ... and without its end_to_end leg (which runs the same kernels in one-residency chunks): per-kernel averages of
@@ -28,14 +27,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_defaultresid
     python3 "$BENCH" --steps 5 --warmup 1 --no-end-to-end > "$OUT/stats_defaultresident.log" 2>&1
 
 for wl in varbase fixed base verify verify_distinct sign x448 direct; do
-    python3 "$BENCH" --workload $wl $Q > "$DST/bench_$wl.json" 2> "$OUT/bench_$wl.err"
     rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats_$wl" -- \
         python3 "$BENCH" --workload $wl --steps 5 --warmup 1 $Q > "$OUT/stats_$wl.log" 2>&1
 done
-for wl in base sign; do   # the opt-in mode: digit-addressed tables (one scalar times a variable base runs the ladder in both modes)
-    python3 "$BENCH" --workload $wl $FAST $Q > "$DST/bench_${wl}_fast.json" 2> "$OUT/bench_${wl}_fast.err"
-done
-
 pmc() {   # pmc <tag> <workload> <extra bench args...> -- <counters...>
     local tag=$1 wl=$2; shift 2
     local extra=()
@@ -85,4 +79,14 @@ for o in sequential scattered; do for s in none memcpy; do "$ROOT/tools/hostfeed
 "$ROOT/tools/keycombphases" > "$DST/keycombphases.txt" 2>&1   # 9 teeth, 20-bit base table, XCD-aware positions: the product's geometry for config 4
 python3 "$ROOT/tools/probes/batch_sweep.py" > "$DST/batch_sweep.txt" 2>&1
 python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$DST"
+# the bench lines once more, now that the counters of THIS library are in place (bench.py reports `traffic` and `valu_issue`
+# only from counters stamped with the current kernel sources: the lines above were written before there were any)
+cp "$DST/pmc_traffic.json" "$ROOT/profiles/pmc_traffic.json"
+python3 "$BENCH" > "$DST/bench_default.json" 2> "$OUT/bench_default.err"
+for wl in varbase fixed base verify verify_distinct sign x448 direct; do
+    python3 "$BENCH" --workload $wl $Q > "$DST/bench_$wl.json" 2> "$OUT/bench_$wl.err"
+done
+for wl in base sign; do
+    python3 "$BENCH" --workload $wl $FAST $Q > "$DST/bench_${wl}_fast.json" 2> "$OUT/bench_${wl}_fast.err"
+done
 ls -la "$DST"
