@@ -23,7 +23,7 @@ def test_traffic_is_reported_only_for_the_sources_it_was_measured_on():
     else:
         assert r["traffic"] is None and r["traffic_stale"] == d["k_point_scalarmul_ct"]
     # a verification step is three kernels: their traffic is summed
-    names = ("k_ed448_verify_keycomb_wide", "k_ed448_verify_keycomb_finish", "k_verify_base_part")
+    names = ("k_ed448_verify_keycomb_xwide", "k_verify_key_combs", "k_verify_base_part")
     total, info = bench.pmc_traffic(names)
     assert total == sum(d[k] for k in names) and info["kernels"] == list(names)
 
@@ -32,7 +32,7 @@ def test_multiply_accumulates_and_gathers_follow_the_width_of_the_base_table():
     """The verification and base-point figures are priced for 28 digits of 16 bits; the device's table may have wider
     digits (fewer additions, each 7 multiplications of 192 multiply-accumulates), and its gathers -- one 192-byte entry,
     two 128-byte lines, per digit -- are named beside the measured traffic."""
-    n, names = 1 << 20, ("k_ed448_verify_keycomb_wide", "k_ed448_verify_keycomb_finish", "k_verify_base_part")
+    n, names = 1 << 20, ("k_ed448_verify_keycomb_xwide", "k_verify_key_combs", "k_verify_base_part")
     at = lambda bits: bench.roofline("verify", names[0], n, 7.6, "index-independent", names, bits)
     assert at(16)["mac"]["macs_per_op"] == bench.WORKLOADS["verify"]["macs"] == at(0)["mac"]["macs_per_op"]
     assert at(24)["mac"]["macs_per_op"] == bench.WORKLOADS["verify"]["macs"] - 9 * 7 * 192         # 19 digits instead of 28
