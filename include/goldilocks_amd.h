@@ -165,6 +165,14 @@ GOLDILOCKS_AMD_API void goldilocks_448_point_double(goldilocks_448_point_p two_a
 /* nega = -a.  ref: point_448.h:343-346, src/goldilocks.c:260-268 */
 GOLDILOCKS_AMD_API void goldilocks_448_point_negate(goldilocks_448_point_p nega,
         const goldilocks_448_point_p a);
+/* The reference's two debugging helpers, which its own test suite (test/test_goldilocks.cxx:379-381, :588, :609) uses to
+ * show that a point's OTHER representations -- shifted by the 2-torsion point (-x, -y, z, t), or with all four coordinates
+ * scaled by a field element (56 bytes, little-endian, any value; 0 counts as 1) -- encode and behave alike.
+ * ref: point_448.h:593-617, src/goldilocks.c:675-701 */
+GOLDILOCKS_AMD_API void goldilocks_448_point_debugging_torque(goldilocks_448_point_p q,
+        const goldilocks_448_point_p p);
+GOLDILOCKS_AMD_API void goldilocks_448_point_debugging_pscale(goldilocks_448_point_p q,
+        const goldilocks_448_point_p p, const uint8_t factor[56]);
 /* Memory-only helpers of the reference API (no field arithmetic, so nothing to launch):
  * constant-time select between two points, pick_b nonzero -> b (ref: point_448.h:558-563,
  * src/goldilocks.c:879-886), secure erase (ref: point_448.h:734-745, src/goldilocks.c:1332-1342);
@@ -499,7 +507,8 @@ GOLDILOCKS_AMD_API int goldilocks_amd_point_encode_eddsa_dev(void *enc /* n*57 B
         void *stream);
 GOLDILOCKS_AMD_API int goldilocks_amd_point_decode_eddsa_dev(void *pt, void *status /* int32[n] */,
         const void *enc, size_t n, void *stream);
-/* op: 0 add, 1 sub, 2 double, 3 negate (b ignored); out/a/b: point_s[n] */
+/* op: 0 add, 1 sub, 2 double, 3 negate (b ignored), 4 debugging_torque (b ignored), 5 debugging_pscale (b: 56 bytes per
+ * point, the factors); out/a/b: point_s[n] */
 GOLDILOCKS_AMD_API int goldilocks_amd_point_op_dev(void *out, const void *a, const void *b, int op, size_t n,
         void *stream);
 /* op: 0 eq(a,b), 1 valid(a); status: int32[n] (-1 / 0) */

@@ -46,6 +46,8 @@ FUNCTIONS = {
     "goldilocks_448_point_sub": (None, "ppp"),
     "goldilocks_448_point_double": (None, "pp"),
     "goldilocks_448_point_negate": (None, "pp"),
+    "goldilocks_448_point_debugging_torque": (None, "pp"),
+    "goldilocks_448_point_debugging_pscale": (None, "ppp"),
     "goldilocks_448_point_cond_sel": (None, "pppQ"),
     "goldilocks_448_point_destroy": (None, "p"),
     "goldilocks_448_precomputed_destroy": (None, "p"),

@@ -136,6 +136,19 @@ GD_KERNEL k_point_op(uint64_t *out, const uint64_t *a, const uint64_t *__restric
             pt_double(p, true);
         } else if (op == 3) {
             p = pt_negate(p);
+        } else if (op == 4) {                     // the same point of the quotient group: + the 2-torsion point (ref: src/goldilocks.c:675-683)
+            p.x = fe_neg(p.x);
+            p.y = fe_neg(p.y);
+        } else if (op == 5) {                     // the same point, other projective coordinates (ref: src/goldilocks.c:685-701)
+            uint32_t w[14];                       // b: 56 bytes per point, the factor (anything, >= p included; 0 counts as 1)
+            load_bytes_as_words(w, reinterpret_cast<const uint8_t *>(b) + 56 * (size_t)i, 56, 14);
+            fe f;
+            (void)fe_deserialize_words(f, w);
+            f = fe_select(f, fe_one(), fe_is_zero(f));
+            p.x = fe_mul(p.x, f);
+            p.y = fe_mul(p.y, f);
+            p.z = fe_mul(p.z, f);
+            p.t = fe_mul(p.t, f);
         } else {
             pt q = pt_load_abi(b + 32 * (size_t)i);
             p = pt_add(p, q, op == 1);

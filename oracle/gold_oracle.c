@@ -465,6 +465,22 @@ void orc_point_negate(orc_point *p, const orc_point *q) { /* goldilocks.c:260-26
     fe_sub(&p->t, &FE_ZERO, &q->t);
 }
 
+void orc_point_debugging_torque(orc_point *q, const orc_point *p) { /* goldilocks.c:675-683 */
+    fe_sub(&q->x, &FE_ZERO, &p->x);
+    fe_sub(&q->y, &FE_ZERO, &p->y);
+    q->z = p->z;
+    q->t = p->t;
+}
+void orc_point_debugging_pscale(orc_point *q, const orc_point *p, const uint8_t factor[56]) { /* goldilocks.c:685-701 */
+    orc_gf f, t;
+    (void)orc_gf_deserialize(&f, factor, 0);
+    if (orc_gf_eq(&f, &FE_ZERO)) f = FE_ONE;   /* gf_cond_sel(gfac, gfac, ONE, gf_eq(gfac, ZERO)) -- test infrastructure: a branch will do */
+    fe_mul(&t, &p->x, &f); q->x = t;
+    fe_mul(&t, &p->y, &f); q->y = t;
+    fe_mul(&t, &p->z, &f); q->z = t;
+    fe_mul(&t, &p->t, &f); q->t = t;
+}
+
 static void niels_cond_neg(orc_niels *n, mask_t neg) { /* goldilocks.c:271-278 */
     fe_cond_swap(&n->a, &n->b, neg);
     fe_cond_neg(&n->c, neg);

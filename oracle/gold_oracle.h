@@ -72,6 +72,8 @@ ORC_API void orc_point_add(orc_point *p, const orc_point *q, const orc_point *r)
 ORC_API void orc_point_sub(orc_point *p, const orc_point *q, const orc_point *r);
 ORC_API void orc_point_double(orc_point *p, const orc_point *q);
 ORC_API void orc_point_negate(orc_point *p, const orc_point *q);
+ORC_API void orc_point_debugging_torque(orc_point *q, const orc_point *p);                         /* goldilocks.c:675-683 */
+ORC_API void orc_point_debugging_pscale(orc_point *q, const orc_point *p, const uint8_t factor[56]);  /* goldilocks.c:685-701 */
 ORC_API int  orc_point_eq(const orc_point *p, const orc_point *q);       /* -1 / 0 */
 ORC_API int  orc_point_valid(const orc_point *p);                       /* -1 / 0 */
 ORC_API void orc_point_encode(uint8_t out[56], const orc_point *p);

@@ -107,6 +107,8 @@ def oracle():
         "orc_point_sub": (None, [pp, pp, pp]),
         "orc_point_double": (None, [pp, pp]),
         "orc_point_negate": (None, [pp, pp]),
+        "orc_point_debugging_torque": (None, [pp, pp]),
+        "orc_point_debugging_pscale": (None, [pp, pp, C.c_void_p]),
         "orc_point_eq": (C.c_int, [pp, pp]),
         "orc_point_valid": (C.c_int, [pp]),
         "orc_point_encode": (None, [vp, pp]),
@@ -184,6 +186,8 @@ def ref():
         "goldilocks_448_point_add": (None, [pp, pp, pp]),
         "goldilocks_448_point_sub": (None, [pp, pp, pp]),
         "goldilocks_448_point_double": (None, [pp, pp]),
+        "goldilocks_448_point_debugging_torque": (None, [pp, pp]),
+        "goldilocks_448_point_debugging_pscale": (None, [pp, pp, vp]),
         "goldilocks_448_point_eq": (C.c_uint64, [pp, pp]),
         "goldilocks_448_point_valid": (C.c_uint64, [pp]),
         "goldilocks_448_scalar_decode_long": (None, [ps, vp, C.c_size_t]),

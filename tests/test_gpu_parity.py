@@ -228,6 +228,49 @@ def test_group_ops(ga, O):
     assert (st.cpu().numpy() == 0).all()
 
 
+def _coords(points):
+    """[n, 4] Python integers mod p of point_s rows (4 x 8 limbs of 56 bits, not necessarily reduced)"""
+    from _libs import P
+    rows = np.ascontiguousarray(points).view(np.uint64).reshape(-1, 4, 8)
+    return [[sum(int(l) << (56 * i) for i, l in enumerate(c)) % P for c in r] for r in rows]
+
+
+def test_debugging_torque_and_pscale_vs_oracle(ga, O):
+    """goldilocks_448_point_debugging_torque / _pscale (ref: src/goldilocks.c:675-701; the reference's own tests lean on
+    them, test/test_goldilocks.cxx:379-381): the coordinates the oracle gets, modulo p, lane by lane; the results are the
+    same point (encodings, point_eq) in other coordinates; the drop-in names agree with the batch."""
+    import torch
+    from _libs import P, Point
+    n = 192
+    a = _gen.oracle_fixed(O, _gen.random_scalars(n, b"t-dbg"))
+    fac = np.frombuffer(_gen.stream(b"t-dbg-f", 56 * n), np.uint8).reshape(n, 56).copy()
+    for i, x in enumerate((0, 1, P - 1, P, P + 1, 2**448 - 1)):
+        fac[i] = np.frombuffer(x.to_bytes(56, "little"), np.uint8)
+    da, df = torch.from_numpy(a.view(np.int64)).cuda(), torch.from_numpy(fac).cuda()
+    out = torch.empty_like(da)
+    want_t, want_s = np.empty_like(a), np.empty_like(a)
+    for i in range(n):
+        pin = C.cast(a[i].ctypes.data_as(C.c_void_p), C.POINTER(Point))
+        O.orc_point_debugging_torque(C.cast(want_t[i].ctypes.data_as(C.c_void_p), C.POINTER(Point)), pin)
+        O.orc_point_debugging_pscale(C.cast(want_s[i].ctypes.data_as(C.c_void_p), C.POINTER(Point)), pin, fac[i].ctypes.data_as(C.c_void_p))
+    st = torch.empty(n, dtype=torch.int32, device="cuda")
+    for op, want, b in ((4, want_t, None), (5, want_s, df)):
+        ga.dev("point_op", out.data_ptr(), da.data_ptr(), b.data_ptr() if b is not None else None, op, n, None)
+        got = out.cpu().numpy().view(np.uint64)
+        assert _coords(got) == _coords(want), op
+        assert _coords(got) != _coords(a)
+        assert (enc(ga, got) == enc(ga, a)).all()
+        ga.dev("point_pred", st.data_ptr(), out.data_ptr(), da.data_ptr(), 0, n, None)
+        assert (st.cpu().numpy() == -1).all()
+    L = ga.lib()
+    for i in (0, 3, 7):
+        q = np.zeros(32, np.uint64)
+        L.goldilocks_448_point_debugging_torque(q.ctypes.data, a[i].ctypes.data)
+        assert _coords(q) == _coords(want_t[i:i + 1])
+        L.goldilocks_448_point_debugging_pscale(q.ctypes.data, a[i].ctypes.data, fac[i].ctypes.data)
+        assert _coords(q) == _coords(want_s[i:i + 1])
+
+
 def test_precompute_matches_oracle_table(ga, O):
     from _libs import Point, Precomputed
     base = ga.point_base()

@@ -198,6 +198,24 @@ def test_x448_conversions_differential(O):
         assert bytes(o1) == bytes(o2), it
 
 
+def test_debugging_helpers_differential(O):
+    """goldilocks_448_point_debugging_torque / _pscale (src/goldilocks.c:675-701): raw limbs of the oracle's restatement
+    against the reference compiled here -- random factors, 0 (counts as 1), p (reads as 0 too), values beyond p."""
+    from _libs import P
+    R = ref()
+    rnd = random.Random(15)
+    factors = [x.to_bytes(56, "little") for x in (0, 1, P - 1, P, P + 1, 2**448 - 1)]
+    for it in range(60):
+        p, a, b = Point(), Point(), Point()
+        R.goldilocks_448_point_from_hash_uniform(C.byref(p), buf(bytes(rnd.getrandbits(8) for _ in range(112))))
+        R.goldilocks_448_point_debugging_torque(C.byref(a), C.byref(p)); O.orc_point_debugging_torque(C.byref(b), C.byref(p))
+        assert bytes(a) == bytes(b)
+        f = factors[it] if it < len(factors) else bytes(rnd.getrandbits(8) for _ in range(56))
+        R.goldilocks_448_point_debugging_pscale(C.byref(a), C.byref(p), buf(f)); O.orc_point_debugging_pscale(C.byref(b), C.byref(p), buf(f))
+        assert bytes(a) == bytes(b), it
+        assert R.goldilocks_448_point_eq(C.byref(a), C.byref(p)) and R.goldilocks_448_point_valid(C.byref(a))
+
+
 def R_identity(R):
     return C.addressof(Point.in_dll(R, "goldilocks_448_point_identity"))
 
