@@ -90,6 +90,8 @@ typedef struct goldilocks_448_precomputed_s goldilocks_448_precomputed_s;
 
 /* ref: point_448.h:273-278 */
 static inline void goldilocks_448_point_copy(goldilocks_448_point_p a, const goldilocks_448_point_p b) { *a = *b; }
+/* ref: point_448.h:218-223 */
+static inline void goldilocks_448_scalar_copy(goldilocks_448_scalar_p out, const goldilocks_448_scalar_p a) { *out = *a; }
 #else
 /* the reference names the scalar struct only by its tag; the batch prototypes below use this name */
 typedef struct goldilocks_448_scalar_s goldilocks_448_scalar_s;
@@ -106,6 +108,35 @@ GOLDILOCKS_AMD_API extern const goldilocks_448_point_p goldilocks_448_point_base
 GOLDILOCKS_AMD_API extern const goldilocks_448_precomputed_s *goldilocks_448_precomputed_base; /* ref: point_448.h:101 */
 
 /* ------------------------------------------------------------------ (1) drop-in single ops */
+
+/* Scalars modulo the group order q (ref: point_448.h:100-260, :565-580, :722-729; src/scalar.c).  Arguments are canonical
+ * (below q), results are; outputs may alias inputs.  The arithmetic runs on the device like everything else, one launch per
+ * call (k_scalar_op); encode, eq, set_unsigned, cond_sel, copy and destroy touch memory only.
+ *   decode: GOLDILOCKS_SUCCESS iff the 56 bytes are below q; out = their value mod q either way   (src/scalar.c:233-250)
+ *   decode_long: the value of ser_len little-endian bytes (any length, 0 included) mod q            (src/scalar.c:257-293)
+ *   invert: out = 1/a; GOLDILOCKS_FAILURE (and out = 0) for a = 0                                   (src/scalar.c:107-166)
+ *   halve: out = a/2                                                                                (src/scalar.c:316-332) */
+GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_448_scalar_decode(goldilocks_448_scalar_p out,
+        const unsigned char ser[GOLDILOCKS_448_SCALAR_BYTES]);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_decode_long(goldilocks_448_scalar_p out, const unsigned char *ser,
+        size_t ser_len);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_encode(unsigned char ser[GOLDILOCKS_448_SCALAR_BYTES],
+        const goldilocks_448_scalar_p s);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_add(goldilocks_448_scalar_p out, const goldilocks_448_scalar_p a,
+        const goldilocks_448_scalar_p b);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_sub(goldilocks_448_scalar_p out, const goldilocks_448_scalar_p a,
+        const goldilocks_448_scalar_p b);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_mul(goldilocks_448_scalar_p out, const goldilocks_448_scalar_p a,
+        const goldilocks_448_scalar_p b);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_halve(goldilocks_448_scalar_p out, const goldilocks_448_scalar_p a);
+GOLDILOCKS_AMD_API goldilocks_error_t goldilocks_448_scalar_invert(goldilocks_448_scalar_p out,
+        const goldilocks_448_scalar_p a);
+GOLDILOCKS_AMD_API goldilocks_bool_t goldilocks_448_scalar_eq(const goldilocks_448_scalar_p a,
+        const goldilocks_448_scalar_p b);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_set_unsigned(goldilocks_448_scalar_p out, uint64_t a);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_cond_sel(goldilocks_448_scalar_p out, const goldilocks_448_scalar_p a,
+        const goldilocks_448_scalar_p b, goldilocks_word_t pick_b);
+GOLDILOCKS_AMD_API void goldilocks_448_scalar_destroy(goldilocks_448_scalar_p scalar);
 
 /* scaled = scalar * base.  Output may alias input.  ref: point_448.h:355-359, src/goldilocks.c:405-465 */
 GOLDILOCKS_AMD_API void goldilocks_448_point_scalarmul(goldilocks_448_point_p scaled,
@@ -300,6 +331,9 @@ GOLDILOCKS_AMD_API int goldilocks_448_point_from_hash_batch(goldilocks_448_point
 /* out[i] = point_mul_by_ratio_and_encode_like_x448(pt[i]); x[i] = ed448_convert_public_key_to_x448(ed[i]) */
 GOLDILOCKS_AMD_API int goldilocks_448_point_mul_by_ratio_and_encode_like_x448_batch(uint8_t *out /* n*56 */,
         const goldilocks_448_point_s *pt, size_t n);
+/* the scalar operations of goldilocks_amd_scalar_op_dev on host arrays (status: goldilocks_error_t[n] for ops 4 and 5, or NULL) */
+GOLDILOCKS_AMD_API int goldilocks_amd_scalar_op_batch(goldilocks_448_scalar_s *out, goldilocks_error_t *status, const void *a,
+        const goldilocks_448_scalar_s *b, int op, size_t len, size_t n);
 GOLDILOCKS_AMD_API int goldilocks_ed448_convert_public_key_to_x448_batch(uint8_t *x /* n*56 */, const uint8_t *ed /* n*57 */,
         size_t n);
 GOLDILOCKS_AMD_API int goldilocks_ed448_derive_secret_scalar_batch(goldilocks_448_scalar_s *secret,
@@ -511,6 +545,11 @@ GOLDILOCKS_AMD_API int goldilocks_amd_point_decode_eddsa_dev(void *pt, void *sta
  * point, the factors); out/a/b: point_s[n] */
 GOLDILOCKS_AMD_API int goldilocks_amd_point_op_dev(void *out, const void *a, const void *b, int op, size_t n,
         void *stream);
+/* Scalars mod q, n operations.  op: 0 add, 1 sub, 2 mul (out, a, b: scalar_s[n]), 3 halve, 4 invert (status: int32[n],
+ * success iff a != 0), 5 decode (a: 56 bytes per operation; status: success iff below q), 6 decode_long (a: len bytes per
+ * operation).  status may be NULL for the other operations.  ref: src/scalar.c */
+GOLDILOCKS_AMD_API int goldilocks_amd_scalar_op_dev(void *out, void *status, const void *a, const void *b, int op,
+        size_t len, size_t n, void *stream);
 /* op: 0 eq(a,b), 1 valid(a); status: int32[n] (-1 / 0) */
 GOLDILOCKS_AMD_API int goldilocks_amd_point_pred_dev(void *status, const void *a, const void *b, int op,
         size_t n, void *stream);

@@ -48,6 +48,18 @@ FUNCTIONS = {
     "goldilocks_448_point_negate": (None, "pp"),
     "goldilocks_448_point_debugging_torque": (None, "pp"),
     "goldilocks_448_point_debugging_pscale": (None, "ppp"),
+    "goldilocks_448_scalar_decode": (C.c_int, "pp"),
+    "goldilocks_448_scalar_decode_long": (None, "ppz"),
+    "goldilocks_448_scalar_encode": (None, "pp"),
+    "goldilocks_448_scalar_add": (None, "ppp"),
+    "goldilocks_448_scalar_sub": (None, "ppp"),
+    "goldilocks_448_scalar_mul": (None, "ppp"),
+    "goldilocks_448_scalar_halve": (None, "pp"),
+    "goldilocks_448_scalar_invert": (C.c_int, "pp"),
+    "goldilocks_448_scalar_eq": (C.c_uint64, "pp"),
+    "goldilocks_448_scalar_set_unsigned": (None, "pQ"),
+    "goldilocks_448_scalar_cond_sel": (None, "pppQ"),
+    "goldilocks_448_scalar_destroy": (None, "p"),
     "goldilocks_448_point_cond_sel": (None, "pppQ"),
     "goldilocks_448_point_destroy": (None, "p"),
     "goldilocks_448_precomputed_destroy": (None, "p"),
@@ -116,6 +128,8 @@ FUNCTIONS = {
     "goldilocks_amd_point_encode_eddsa_dev": (C.c_int, "ppzp"),
     "goldilocks_amd_point_decode_eddsa_dev": (C.c_int, "pppzp"),
     "goldilocks_amd_point_op_dev": (C.c_int, "pppizp"),
+    "goldilocks_amd_scalar_op_dev": (C.c_int, "ppppizzp"),
+    "goldilocks_amd_scalar_op_batch": (C.c_int, "ppppizz"),
     "goldilocks_amd_point_pred_dev": (C.c_int, "pppizp"),
     "goldilocks_amd_precompute_dev": (C.c_int, "ppzp"),
     "goldilocks_amd_ed448_verify_dev": (C.c_int, "pppppzBpBzp"),

@@ -661,6 +661,7 @@ GD_KERNEL k_x448(uint8_t *__restrict__ shared, int32_t *__restrict__ status, con
 GD_KERNEL k_point_encode(uint8_t *__restrict__ ser, const uint64_t *__restrict__ pts, uint32_t n, int eddsa);
 GD_KERNEL k_bwt_export(uint8_t *__restrict__ out, const uint4 *__restrict__ bwt, uint64_t first, uint32_t count);
 GD_KERNEL k_ed448_expand_secret(uint8_t *__restrict__ out, const uint8_t *__restrict__ sk, uint32_t n, int as_scalar);
+GD_KERNEL k_scalar_op(uint64_t *out, int32_t *__restrict__ status, const uint8_t *a, const uint64_t *b, uint32_t n, int op, uint32_t len);
 GD_KERNEL k_x448_from_edwards(uint8_t *__restrict__ out, const uint8_t *__restrict__ ed, const uint64_t *__restrict__ pts,
                               uint32_t n);
 GD_KERNEL k_point_decode(uint64_t *__restrict__ pts, int32_t *__restrict__ status,

@@ -157,6 +157,78 @@ GD_KERNEL k_point_op(uint64_t *out, const uint64_t *a, const uint64_t *__restric
     }
 }
 
+// Scalars mod q, one operation per lane (ref: src/scalar.c; the reference's API of point_448.h:100-260):
+//   0 add  1 sub  2 mul  3 halve          out, a, b: scalar_s (7 x u64, canonical)
+//   4 invert: out = a^(q-2) (0 for a = 0), status = success iff that is not 0      (src/scalar.c:107-166)
+//   5 decode: a = 56 bytes per operation, out = their value mod q, status = success iff the value was below q   (:233-250)
+//   6 decode_long: a = len bytes per operation (any length, 0 included), out = their value mod q                   (:257-293)
+GD_KERNEL k_scalar_op(uint64_t *out, int32_t *__restrict__ status, const uint8_t *a, const uint64_t *b, uint32_t n, int op,
+                      uint32_t len) {
+    const uint32_t stride = gridDim.x * BLOCK;
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        sc r;
+        if (op <= 4) {
+            const sc x = sc_from_abi(reinterpret_cast<const uint64_t *>(a) + 7 * (size_t)i);
+            if (op == 0) r = sc_add(x, sc_from_abi(b + 7 * (size_t)i));
+            else if (op == 1) r = sc_sub(x, sc_from_abi(b + 7 * (size_t)i));
+            else if (op == 2) r = sc_mul(x, sc_from_abi(b + 7 * (size_t)i));
+            else if (op == 3) r = sc_halve(x);
+            else {
+                r = x;                                               // the exponent's leading bit
+#pragma unroll 1
+                for (int k = 444; k >= 0; k--) {                     // q - 2: public, every lane the same branch
+                    r = sc_mul(r, r);
+                    const uint32_t word = SC_Q[k >> 5] - (k < 32 ? 2u : 0u);
+                    if ((word >> (k & 31)) & 1u) r = sc_mul(r, x);
+                }
+                uint32_t any = 0;
+#pragma unroll
+                for (int k = 0; k < 14; k++) any |= r.w[k];
+                status[i] = any ? -1 : 0;
+            }
+        } else {
+            const uint32_t nbytes = op == 5 ? 56u : len;
+            const uint8_t *src = a + (size_t)nbytes * i;
+            // 56-byte pieces from the top: acc = acc * 2^448 + piece (mod q)
+            sc two448 = sc_zero();                                   // 2^448 mod q = 4 c  (q = 2^446 - c)
+            {
+                uint64_t carry = 0;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    carry += k < 7 ? (uint64_t)SC_C[k] << 2 : 0;
+                    two448.w[k] = (uint32_t)carry;
+                    carry >>= 32;
+                }
+            }
+            r = sc_zero();
+            bool below_q = true;
+            const uint32_t pieces = (nbytes + 55) / 56;
+#pragma unroll 1
+            for (uint32_t pc = pieces; pc-- > 0;) {
+                sc piece;
+#pragma unroll 1
+                for (int k = 0; k < 14; k++) {
+                    uint32_t w = 0;
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t at = 56 * pc + 4 * k + j;
+                        w |= at < nbytes ? (uint32_t)src[at] << (8 * j) : 0u;
+                    }
+                    piece.w[k] = w;
+                }
+                if (op == 5) {                                      // the range check of scalar_decode
+                    int64_t acc = 0;
+#pragma unroll
+                    for (int k = 0; k < 14; k++) acc = (acc + (int64_t)piece.w[k] - (int64_t)SC_Q[k]) >> 32;
+                    below_q = acc != 0;
+                }
+                r = sc_add(sc_mul(r, two448), sc_reduce(piece));
+            }
+            if (op == 5) status[i] = below_q ? -1 : 0;
+        }
+        sc_to_abi(out + 7 * (size_t)i, r);
+    }
+}
+
 GD_KERNEL k_point_pred(int32_t *__restrict__ status, const uint64_t *__restrict__ a,
                        const uint64_t *__restrict__ b, uint32_t n, int op) {
     const uint32_t stride = gridDim.x * BLOCK;

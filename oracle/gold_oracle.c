@@ -354,6 +354,19 @@ void orc_scalar_halve(orc_scalar *o, const orc_scalar *a) { /* scalar.c:316-332 
     for (int i = 0; i < 6; i++) o->limb[i] = t[i] >> 1 | t[i + 1] << 63;
     o->limb[6] = t[6] >> 1 | (uint64_t)chain << 63;
 }
+int orc_scalar_invert(orc_scalar *o, const orc_scalar *a) { /* scalar.c:107-166: a^(q-2); the reference's sliding window
+                                                              * is one way to that value, plain square-and-multiply another */
+    orc_scalar r = *a, x = *a;
+    for (int k = 444; k >= 0; k--) {
+        const uint64_t word = SC_Q.limb[k >> 6] - (k < 64 ? 2 : 0);
+        orc_scalar_mul(&r, &r, &r);
+        if ((word >> (k & 63)) & 1) orc_scalar_mul(&r, &r, &x);
+    }
+    *o = r;
+    uint64_t any = 0;
+    for (int i = 0; i < 7; i++) any |= r.limb[i];
+    return any ? -1 : 0;                                      /* goldilocks_succeed_if(~scalar_eq(out, zero)) */
+}
 static void sc_decode_short(orc_scalar *s, const uint8_t *in, size_t n) { /* scalar.c:219-232 */
     size_t k = 0;
     for (int i = 0; i < 7; i++) {

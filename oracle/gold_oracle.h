@@ -58,6 +58,7 @@ ORC_API void orc_scalar_add(orc_scalar *o, const orc_scalar *a, const orc_scalar
 ORC_API void orc_scalar_sub(orc_scalar *o, const orc_scalar *a, const orc_scalar *b);
 ORC_API void orc_scalar_mul(orc_scalar *o, const orc_scalar *a, const orc_scalar *b);
 ORC_API void orc_scalar_halve(orc_scalar *o, const orc_scalar *a);
+ORC_API int  orc_scalar_invert(orc_scalar *o, const orc_scalar *a);   /* scalar.c:107-166 */
 ORC_API int  orc_scalar_decode(orc_scalar *o, const uint8_t in[56]);
 ORC_API void orc_scalar_decode_long(orc_scalar *o, const uint8_t *in, size_t len);
 ORC_API void orc_scalar_encode(uint8_t out[56], const orc_scalar *a);

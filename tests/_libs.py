@@ -96,6 +96,7 @@ def oracle():
         "orc_scalar_sub": (None, [ps, ps, ps]),
         "orc_scalar_mul": (None, [ps, ps, ps]),
         "orc_scalar_halve": (None, [ps, ps]),
+        "orc_scalar_invert": (C.c_int, [ps, ps]),
         "orc_scalar_decode": (C.c_int, [ps, vp]),
         "orc_scalar_decode_long": (None, [ps, vp, C.c_size_t]),
         "orc_scalar_encode": (None, [vp, ps]),
@@ -197,6 +198,7 @@ def ref():
         "goldilocks_448_scalar_sub": (None, [ps, ps, ps]),
         "goldilocks_448_scalar_mul": (None, [ps, ps, ps]),
         "goldilocks_448_scalar_halve": (None, [ps, ps]),
+        "goldilocks_448_scalar_invert": (C.c_int, [ps, ps]),
         "goldilocks_448_direct_scalarmul": (C.c_int, [vp, vp, ps, C.c_uint64, C.c_uint64]),
         "goldilocks_ed448_derive_public_key": (None, [vp, vp]),
         "goldilocks_ed448_sign": (None, [vp, vp, vp, vp, C.c_size_t, C.c_uint8, vp, C.c_uint8]),

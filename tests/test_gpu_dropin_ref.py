@@ -63,7 +63,9 @@ def test_reference_test_suite_binds_the_library_for_everything_it_tests():
             "goldilocks_448_point_dual_scalarmul", "goldilocks_448_direct_scalarmul", "goldilocks_448_precompute",
             "goldilocks_448_point_debugging_torque", "goldilocks_448_point_debugging_pscale",
             "goldilocks_ed448_convert_public_key_to_x448", "goldilocks_ed448_convert_private_key_to_x448",
-            "goldilocks_448_point_from_hash_uniform", "goldilocks_448_point_mul_by_ratio_and_encode_like_x448"} <= wanted
+            "goldilocks_448_point_from_hash_uniform", "goldilocks_448_point_mul_by_ratio_and_encode_like_x448",
+            "goldilocks_448_scalar_add", "goldilocks_448_scalar_sub", "goldilocks_448_scalar_mul", "goldilocks_448_scalar_invert",
+            "goldilocks_448_scalar_halve", "goldilocks_448_scalar_decode_long", "goldilocks_448_scalar_eq"} <= wanted
     assert wanted <= set(ga.FUNCTIONS) | set(ga.DATA_SYMBOLS), wanted - set(ga.FUNCTIONS) - set(ga.DATA_SYMBOLS)
     defined = subprocess.check_output(["nm", "--defined-only", "-g", SUITE], text=True)
     assert "goldilocks_ed448_sign\n" not in defined and "goldilocks_448_point_add" not in defined
@@ -72,14 +74,15 @@ def test_reference_test_suite_binds_the_library_for_everything_it_tests():
 @needs_suite
 @pytest.mark.gpu
 def test_reference_test_suite_passes_on_the_library():
-    """The reference's OWN property suite (test/test_goldilocks.cxx:316-437 test_ec -- round trips, torque and projective
+    """The reference's OWN property suite (test/test_goldilocks.cxx: test_arithmetic -- the scalars' ring laws and inversion --,
+    :316-437 test_ec -- round trips, torque and projective
     scaling, commutativity, associativity, distributivity, double / dual / precomputed / direct multiplications, the
     Elligator sum, the EdDSA encoding round trip --, test_eddsa, test_x448, test_convert_eddsa_to_x, test_cfrg_crypto,
-    test_cfrg_vectors with RFC 7748's iterated ladder and RFC 8032's vectors, test_dalek_vectors) with every point, EdDSA
-    and X448 call served by this library, one GPU call each.  Here with 150 iterations per loop; the full 10 000 of the
+    test_cfrg_vectors with RFC 7748's iterated ladder and RFC 8032's vectors, test_dalek_vectors) with every scalar, point,
+    EdDSA and X448 call served by this library, one GPU call each.  Here with 150 iterations per loop; the full 10 000 of the
     reference's source: `oracle/_ref/dropin_test_suite` without the variable (profiles/r06/reference_test_suite.txt)."""
     env = dict(os.environ, GOLDILOCKS_REF_NTESTS="150")
     r = subprocess.run([SUITE], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0 and "Passed all tests." in r.stdout and "FAIL" not in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
-    for name in ("EC", "EdDSA", "X448 Encoding/Decoding", "ECDH using EdDSA keys", "CFRG crypto", "CFRG test vectors", "Test vectors from Dalek"):
+    for name in ("Arithmetic", "EC", "EdDSA", "X448 Encoding/Decoding", "ECDH using EdDSA keys", "CFRG crypto", "CFRG test vectors", "Test vectors from Dalek"):
         assert name + "..." in r.stdout, name

@@ -228,6 +228,65 @@ def test_group_ops(ga, O):
     assert (st.cpu().numpy() == 0).all()
 
 
+def test_scalar_api_vs_oracle(ga, O):
+    """The reference's scalar API (point_448.h:100-260, src/scalar.c:30-332) on the device (k_scalar_op): add, sub, mul,
+    halve, invert, decode with its range check, decode_long at lengths 0 ... 250 -- every lane against the oracle and
+    against Python's integers; edge values 0, 1, q - 1, q, 2^448 - 1; then the drop-in names one call at a time."""
+    from _libs import Scalar
+    n = 300
+    rnd = np.random.default_rng(21)
+    ints = [0, 1, 2, Q - 1, Q - 2, (Q + 1) // 2] + [int.from_bytes(rnd.bytes(56), "little") % Q for _ in range(n - 6)]
+    a = _gen.scalars_from_ints(ints)
+    b = _gen.scalars_from_ints(ints[3:] + ints[:3])
+    tob = lambda xs: np.frombuffer(b"".join((x % Q).to_bytes(56, "little") for x in xs), np.uint64).reshape(-1, 7)
+    L = ga.lib()
+    def run(op, x, y=None, length=0, status=False):
+        out = np.zeros((n, 7), np.uint64)
+        st = np.full(n, 7, np.int32)
+        ga._check(L.goldilocks_amd_scalar_op_batch(out.ctypes.data, st.ctypes.data if status else None, x.ctypes.data,
+                                                   y.ctypes.data if y is not None else None, op, length, n))
+        return (out, st) if status else out
+    ia, ib = ints, ints[3:] + ints[:3]
+    assert (run(0, a, b) == tob([x + y for x, y in zip(ia, ib)])).all()
+    assert (run(1, a, b) == tob([x - y for x, y in zip(ia, ib)])).all()
+    assert (run(2, a, b) == tob([x * y for x, y in zip(ia, ib)])).all()
+    assert (run(3, a) == tob([x * pow(2, -1, Q) for x in ia])).all()
+    inv, st = run(4, a, status=True)
+    assert (inv == tob([pow(x, -1, Q) if x else 0 for x in ia])).all() and (st == [-1 if x else 0 for x in ia]).all()
+    for i in (0, 1, 3, 17):       # ... and the oracle's own word on a few
+        o = Scalar()
+        assert O.orc_scalar_invert(C.byref(o), C.cast(a[i].ctypes.data_as(C.c_void_p), C.POINTER(Scalar))) == st[i] and bytes(o) == inv[i].tobytes()
+    raws = [0, Q - 1, Q, Q + 1, 2**448 - 1, 2**446] + [int.from_bytes(rnd.bytes(56), "little") for _ in range(n - 6)]
+    ser = np.frombuffer(b"".join(x.to_bytes(56, "little") for x in raws), np.uint8).reshape(n, 56).copy()
+    dec, st = run(5, ser, status=True)
+    assert (dec == tob(raws)).all() and (st == [-1 if x < Q else 0 for x in raws]).all()
+    for length in (0, 1, 55, 56, 57, 72, 112, 113, 114, 250):
+        blob = np.frombuffer(rnd.bytes(max(length * n, 1)), np.uint8).copy()
+        want = tob([int.from_bytes(blob[length * i:length * (i + 1)].tobytes(), "little") for i in range(n)])
+        assert (run(6, blob, length=length) == want).all(), length
+        o = Scalar()
+        O.orc_scalar_decode_long(C.byref(o), blob[length * 5:].ctypes.data_as(C.c_void_p), length)
+        assert bytes(o) == want[5].tobytes()
+    # the drop-in names
+    x, y, o = a[7].copy(), b[7].copy(), np.zeros(7, np.uint64)
+    L.goldilocks_448_scalar_mul(o.ctypes.data, x.ctypes.data, y.ctypes.data); assert (o == tob([ia[7] * ib[7]])[0]).all()
+    L.goldilocks_448_scalar_add(x.ctypes.data, x.ctypes.data, y.ctypes.data); assert (x == tob([ia[7] + ib[7]])[0]).all()   # in place
+    L.goldilocks_448_scalar_sub(o.ctypes.data, x.ctypes.data, y.ctypes.data); assert (o == a[7]).all()
+    L.goldilocks_448_scalar_halve(o.ctypes.data, a[7].ctypes.data); assert (o == tob([ia[7] * pow(2, -1, Q)])[0]).all()
+    assert L.goldilocks_448_scalar_invert(o.ctypes.data, a[7].ctypes.data) == -1 and (o == tob([pow(ia[7], -1, Q)])[0]).all()
+    assert L.goldilocks_448_scalar_invert(o.ctypes.data, a[0].ctypes.data) == 0 and not o.any()
+    assert L.goldilocks_448_scalar_decode(o.ctypes.data, ser[2].ctypes.data) == 0 and not o.any()           # q itself: rejected, reads as 0
+    assert L.goldilocks_448_scalar_decode(o.ctypes.data, ser[1].ctypes.data) == -1 and (o == tob([Q - 1])[0]).all()
+    L.goldilocks_448_scalar_decode_long(o.ctypes.data, ser[4].ctypes.data, 56); assert (o == tob([2**448 - 1])[0]).all()
+    enc56 = np.zeros(56, np.uint8)
+    L.goldilocks_448_scalar_encode(enc56.ctypes.data, a[9].ctypes.data); assert enc56.tobytes() == a[9].tobytes()
+    assert L.goldilocks_448_scalar_eq(a[9].ctypes.data, a[9].ctypes.data) == 2**64 - 1 and L.goldilocks_448_scalar_eq(a[9].ctypes.data, a[10].ctypes.data) == 0
+    L.goldilocks_448_scalar_set_unsigned(o.ctypes.data, 0xfedcba9876543210); assert o[0] == 0xfedcba9876543210 and not o[1:].any()
+    L.goldilocks_448_scalar_cond_sel(o.ctypes.data, a[9].ctypes.data, a[10].ctypes.data, 0); assert (o == a[9]).all()
+    L.goldilocks_448_scalar_cond_sel(o.ctypes.data, a[9].ctypes.data, a[10].ctypes.data, 5); assert (o == a[10]).all()
+    L.goldilocks_448_scalar_destroy(o.ctypes.data); assert not o.any()
+
+
 def _coords(points):
     """[n, 4] Python integers mod p of point_s rows (4 x 8 limbs of 56 bits, not necessarily reduced)"""
     from _libs import P

@@ -198,6 +198,40 @@ def test_x448_conversions_differential(O):
         assert bytes(o1) == bytes(o2), it
 
 
+def test_scalar_arithmetic_differential(O):
+    """src/scalar.c:30-332 as an API: add, sub, mul, halve, invert, decode (56 bytes, range check) and decode_long at
+    lengths 0 ... 200 -- the oracle's restatements against the reference compiled here, on random scalars and 0, 1, q - 1."""
+    from _libs import Q
+    R = ref()
+    rnd = random.Random(16)
+    def sc(x):
+        s = Scalar()
+        C.memmove(C.byref(s), (x % Q).to_bytes(56, "little"), 56)
+        return s
+    edge = [0, 1, 2, Q - 1, Q - 2, (Q + 1) // 2]
+    for it in range(120):
+        x = edge[it % len(edge)] if it < 12 else rnd.getrandbits(446) % Q
+        y = edge[(it // len(edge)) % len(edge)] if it < 36 else rnd.getrandbits(446) % Q
+        a, b, o1, o2 = sc(x), sc(y), Scalar(), Scalar()
+        for name in ("add", "sub", "mul"):
+            getattr(R, "goldilocks_448_scalar_" + name)(C.byref(o1), C.byref(a), C.byref(b))
+            getattr(O, "orc_scalar_" + name)(C.byref(o2), C.byref(a), C.byref(b))
+            assert bytes(o1) == bytes(o2) == ({"add": x + y, "sub": x - y, "mul": x * y}[name] % Q).to_bytes(56, "little"), (name, it)
+        R.goldilocks_448_scalar_halve(C.byref(o1), C.byref(a)); O.orc_scalar_halve(C.byref(o2), C.byref(a))
+        assert bytes(o1) == bytes(o2) == (x * pow(2, -1, Q) % Q).to_bytes(56, "little")
+        if it % 6 == 0:
+            r1 = R.goldilocks_448_scalar_invert(C.byref(o1), C.byref(a)); r2 = O.orc_scalar_invert(C.byref(o2), C.byref(a))
+            assert bytes(o1) == bytes(o2) == (pow(x, -1, Q) if x else 0).to_bytes(56, "little") and r1 == r2 == (-1 if x else 0)
+        raw = [0, Q - 1, Q, Q + 1, 2**448 - 1][it] if it < 5 else rnd.getrandbits(448)
+        ser = raw.to_bytes(56, "little")
+        r1 = R.goldilocks_448_scalar_decode(C.byref(o1), buf(ser)); r2 = O.orc_scalar_decode(C.byref(o2), buf(ser))
+        assert bytes(o1) == bytes(o2) == (raw % Q).to_bytes(56, "little") and r1 == r2 == (-1 if raw < Q else 0)
+        n = it if it < 80 else rnd.randrange(80, 201)
+        long = bytes(rnd.getrandbits(8) for _ in range(n)) if it != 57 else b"\xff" * 57
+        R.goldilocks_448_scalar_decode_long(C.byref(o1), buf(long + b"\0"), n); O.orc_scalar_decode_long(C.byref(o2), buf(long + b"\0"), n)
+        assert bytes(o1) == bytes(o2) == (int.from_bytes(long, "little") % Q).to_bytes(56, "little"), n
+
+
 def test_debugging_helpers_differential(O):
     """goldilocks_448_point_debugging_torque / _pscale (src/goldilocks.c:675-701): raw limbs of the oracle's restatement
     against the reference compiled here -- random factors, 0 (counts as 1), p (reads as 0 too), values beyond p."""
