@@ -72,6 +72,9 @@ AUDIT = {
     "k_derive_wave": ("kernels_wave.hip", [1], {}),
     "k_ed448_sign_wave": ("kernels_wave.hip", [1], {}),
     "k_x448_wave": ("kernels_wave.hip", [3], {}),
+    # the reference's scalar API (src/scalar.c): secret scalars are its everyday arguments (a: scalars or their bytes, b)
+    "k_scalar_op": ("kernels_misc.hip", [2, 3], {}),
+    "k_ed448_expand_secret": ("kernels_misc.hip", [1], {}),
 }
 
 # Negative controls: the digit-addressed ("fast", opt-in) twins of two audited kernels.  The audit MUST flag them --
@@ -116,6 +119,17 @@ def kernel_arg_offsets(text, kernel):
                 offs.append((int(off.group(1)), int(size.group(1)), kind.group(1) == "global_buffer"))
         return offs
     raise KeyError(kernel)
+
+
+def kernarg_sgpr(text, kernel):
+    """index of the first of the two user SGPRs that hold the kernel-argument segment's address: they follow the private
+    segment buffer (4 registers), the dispatch packet's pointer (2) and the queue's (2) where the kernel descriptor asks for
+    those (a kernel that reads its grid size from the dispatch packet has the arguments behind s[2:3], not s[0:1])"""
+    m = re.search(r"\.amdhsa_kernel %s\n(.*?)\.end_amdhsa_kernel" % re.escape(kernel), text, re.S)
+    if not m:
+        return 0
+    flag = lambda name: int((re.search(r"\.amdhsa_user_sgpr_%s\s+(\d+)" % name, m.group(1)) or [0, 0])[1])
+    return 4 * flag("private_segment_buffer") + 2 * flag("dispatch_ptr") + 2 * flag("queue_ptr")
 
 
 # ------------------------------------------------------------------------------------------------ operands
@@ -235,7 +249,8 @@ def combine(vals):
 
 
 class Audit:
-    def __init__(self, kernel, body, first_line, arg_offsets, secret_args, verbose=False):
+    def __init__(self, kernel, body, first_line, arg_offsets, secret_args, verbose=False, kernarg_at=0):
+        self.kernarg_at = kernarg_at
         self.kernel, self.verbose = kernel, verbose
         self.arg_offsets = arg_offsets
         self.secret = set(secret_args)        # grows: arguments through which tainted data was stored
@@ -356,9 +371,9 @@ class Audit:
             at, ap = combine(st.get(r) for r in base + off_regs)
             if at:
                 violate("address", "scalar load from a secret-dependent address", ap)
-            # the kernarg segment: s[0:1] at entry, or a copy of it (a kernel with many arguments moves the pointer aside
-            # before s0 is reused: the copy carries the provenance "kernarg")
-            if not off_regs and ((base == ["s0", "s1"] and not ap) or ap == frozenset(["kernarg"])):
+            # the kernarg segment: its two user SGPRs at entry (kernarg_sgpr), or a copy of them (a kernel with many arguments
+            # moves the pointer aside before the registers are reused: the copy carries the provenance "kernarg")
+            if not off_regs and ap == frozenset(["kernarg"]):
                 imm = int(ops[2], 0) if len(ops) > 2 else 0
                 for k, r in enumerate(dst):
                     a = self.argument_of(imm + 4 * k)
@@ -559,8 +574,8 @@ class Audit:
             self.changed = False
             entry = [None] * n
             entry[0] = State()
-            entry[0].set("s0", (False, frozenset(["kernarg"])))
-            entry[0].set("s1", (False, frozenset(["kernarg"])))
+            entry[0].set("s%d" % self.kernarg_at, (False, frozenset(["kernarg"])))
+            entry[0].set("s%d" % (self.kernarg_at + 1), (False, frozenset(["kernarg"])))
             work = [0]
             while work:
                 i = work.pop()
@@ -598,7 +613,7 @@ def audit_kernel(kernel, verbose=False, force=False):
     if kernel not in funcs:
         raise KeyError("%s not in %s" % (kernel, tu))
     first = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":")) + 2
-    a = Audit(kernel, funcs[kernel], first, kernel_arg_offsets(text, kernel), secret_args, verbose)
+    a = Audit(kernel, funcs[kernel], first, kernel_arg_offsets(text, kernel), secret_args, verbose, kernarg_sgpr(text, kernel))
     violations = a.run()
     allowed, bad = [], []
     for v in violations:
@@ -659,14 +674,14 @@ def explain(kernel, line, reg=None, depth=40, exec_predication=True):
     text = open(compile_isa(tu)).read()
     lines = text.split("\n")
     first = next(i for i, l in enumerate(lines) if l.startswith(kernel + ":")) + 2
-    a = Audit(kernel, isa_loops.functions(text)[kernel], first, kernel_arg_offsets(text, kernel), secret_args)
+    a = Audit(kernel, isa_loops.functions(text)[kernel], first, kernel_arg_offsets(text, kernel), secret_args, False, kernarg_sgpr(text, kernel))
     a.exec_predication = exec_predication
     a.run()
     n = len(a.ins)
     entry = [None] * n
     entry[0] = State()
-    entry[0].set("s0", (False, frozenset(["kernarg"])))
-    entry[0].set("s1", (False, frozenset(["kernarg"])))
+    entry[0].set("s%d" % a.kernarg_at, (False, frozenset(["kernarg"])))
+    entry[0].set("s%d" % (a.kernarg_at + 1), (False, frozenset(["kernarg"])))
     work = [0]
     while work:
         i = work.pop()
