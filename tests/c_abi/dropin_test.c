@@ -78,6 +78,48 @@ int main(void) {
         return 1;
     }
 
+    /* the scalar API (round 6): (x * y) / y == x, x - x == 0, 2 * (x / 2) == x, decode / encode, and a point identity through it:
+       (x + y) * B == x * B + y * B */
+    {
+        goldilocks_448_scalar_p x, y, t, u;
+        uint8_t ser[56], back[56];
+        goldilocks_448_point_p xb, yb, sum, direct;
+        for (int i = 0; i < 56; i++) ser[i] = (uint8_t)(29 * i + 3);
+        ser[55] &= 0x3f;                                     /* below q */
+        if (goldilocks_448_scalar_decode(x, ser) != GOLDILOCKS_SUCCESS) { puts("scalar_decode"); return 1; }
+        goldilocks_448_scalar_encode(back, x);
+        if (memcmp(ser, back, 56)) { puts("scalar_encode"); return 1; }
+        goldilocks_448_scalar_decode_long(y, (const unsigned char *)"a long string of more than fifty-six bytes, reduced modulo the group order", 73);
+        goldilocks_448_scalar_mul(t, x, y);
+        if (goldilocks_448_scalar_invert(u, y) != GOLDILOCKS_SUCCESS) { puts("scalar_invert"); return 1; }
+        goldilocks_448_scalar_mul(t, t, u);                  /* in place */
+        if (!goldilocks_448_scalar_eq(t, x)) { puts("(x * y) / y != x"); return 1; }
+        goldilocks_448_scalar_sub(t, x, x);
+        if (!goldilocks_448_scalar_eq(t, goldilocks_448_scalar_zero) || goldilocks_448_scalar_invert(u, t) != GOLDILOCKS_FAILURE) {
+            puts("x - x, 1 / 0");
+            return 1;
+        }
+        goldilocks_448_scalar_halve(t, x);
+        goldilocks_448_scalar_add(t, t, t);
+        if (!goldilocks_448_scalar_eq(t, x)) { puts("2 * (x / 2) != x"); return 1; }
+        goldilocks_448_scalar_set_unsigned(u, 5);
+        goldilocks_448_scalar_cond_sel(t, x, u, 1);
+        if (!goldilocks_448_scalar_eq(t, u) || u->limb[0] != 5) { puts("set_unsigned / cond_sel"); return 1; }
+        goldilocks_448_scalar_add(t, x, y);
+        goldilocks_448_point_scalarmul(xb, goldilocks_448_point_base, x);
+        goldilocks_448_point_scalarmul(yb, goldilocks_448_point_base, y);
+        goldilocks_448_point_add(sum, xb, yb);
+        goldilocks_448_precomputed_scalarmul(direct, goldilocks_448_precomputed_base, t);
+        if (!goldilocks_448_point_eq(sum, direct)) { puts("(x + y) * B != x * B + y * B"); return 1; }
+        goldilocks_448_point_debugging_torque(sum, sum);
+        goldilocks_448_point_debugging_pscale(sum, sum, ser);
+        goldilocks_448_point_encode(ser1, sum);
+        goldilocks_448_point_encode(ser2, direct);
+        if (memcmp(ser1, ser2, 56)) { puts("torque / pscale changed the encoding"); return 1; }
+        goldilocks_448_scalar_destroy(x);
+        if (!goldilocks_448_scalar_eq(x, goldilocks_448_scalar_zero)) { puts("scalar_destroy"); return 1; }
+    }
+
     /* batch entry points: host arrays, then the same batch sharded over "two GPUs" (device 0 listed
        twice on a one-GPU box) and with index-independent table access; all must agree */
     enum { NB = 300 };
