@@ -423,6 +423,36 @@ def x448_from_edwards_batch(kind, rows):
     return out
 
 
+SCALAR_OPS = {"add": 0, "sub": 1, "mul": 2, "halve": 3, "invert": 4, "decode": 5, "decode_long": 6}
+
+
+def scalar_op_batch(op, a, b=None, length=0):
+    """The reference's scalar API over host arrays (src/scalar.c; goldilocks_amd_scalar_op_batch).  op: a key of SCALAR_OPS.
+    a, b: [n, 7] uint64 scalars (add, sub, mul, halve, invert); decode: a = [n, 56] bytes; decode_long: a = n * length bytes.
+    Returns the [n, 7] results; for invert and decode a pair (results, int32 status: -1 success / 0 failure)."""
+    code = SCALAR_OPS[op]
+    if code <= 4:
+        a = _u64(a, 7)
+        n = len(a)
+    elif code == 5:
+        a = _u8(a, 56)
+        n = len(a)
+    else:
+        if length <= 0:
+            raise ValueError("decode_long: the strings' common length in bytes")
+        a = np.ascontiguousarray(np.frombuffer(bytes(a), dtype=np.uint8) if isinstance(a, (bytes, bytearray)) else a, dtype=np.uint8).reshape(-1)
+        n = len(a) // length
+    if code <= 2:
+        b = _u64(b, 7)
+        if len(b) != n:
+            raise ValueError("operand arrays differ in length")
+    out = np.empty((n, 7), dtype=np.uint64)
+    st = np.empty(n, dtype=np.int32)
+    _check(lib().goldilocks_amd_scalar_op_batch(_ptr(out), _ptr(st) if code in (4, 5) else None, _ptr(a),
+                                                 _ptr(b) if code <= 2 else None, code, length, n))
+    return (out, st) if code in (4, 5) else out
+
+
 # ----------------------------------------------------------------------------- single ops (drop-in names)
 
 

@@ -250,6 +250,7 @@ def test_scalar_api_vs_oracle(ga, O):
     assert (run(0, a, b) == tob([x + y for x, y in zip(ia, ib)])).all()
     assert (run(1, a, b) == tob([x - y for x, y in zip(ia, ib)])).all()
     assert (run(2, a, b) == tob([x * y for x, y in zip(ia, ib)])).all()
+    assert (ga.scalar_op_batch("mul", a, b) == run(2, a, b)).all() and (ga.scalar_op_batch("halve", a) == run(3, a)).all()   # the package's wrapper
     assert (run(3, a) == tob([x * pow(2, -1, Q) for x in ia])).all()
     inv, st = run(4, a, status=True)
     assert (inv == tob([pow(x, -1, Q) if x else 0 for x in ia])).all() and (st == [-1 if x else 0 for x in ia]).all()
@@ -260,10 +261,14 @@ def test_scalar_api_vs_oracle(ga, O):
     ser = np.frombuffer(b"".join(x.to_bytes(56, "little") for x in raws), np.uint8).reshape(n, 56).copy()
     dec, st = run(5, ser, status=True)
     assert (dec == tob(raws)).all() and (st == [-1 if x < Q else 0 for x in raws]).all()
+    dec2, st2 = ga.scalar_op_batch("decode", ser)
+    assert (dec2 == dec).all() and (st2 == st).all()
     for length in (0, 1, 55, 56, 57, 72, 112, 113, 114, 250):
         blob = np.frombuffer(rnd.bytes(max(length * n, 1)), np.uint8).copy()
         want = tob([int.from_bytes(blob[length * i:length * (i + 1)].tobytes(), "little") for i in range(n)])
         assert (run(6, blob, length=length) == want).all(), length
+        if length:
+            assert (ga.scalar_op_batch("decode_long", blob[:length * n], length=length) == want).all()
         o = Scalar()
         O.orc_scalar_decode_long(C.byref(o), blob[length * 5:].ctypes.data_as(C.c_void_p), length)
         assert bytes(o) == want[5].tobytes()
